@@ -1,0 +1,146 @@
+// Relation-guided box head, fused tail:
+//   x[r,n]  = Q[r] + S[img(r)*N + n]          (the two halves of the 2048->1024 1x1 conv)
+//   y       = ReLU(GroupNorm32(x))            fgn_roi_head.py:272-274
+//   pooled  = mean_{7x7}(y)                   mmdet BBoxHead.forward (with_avg_pool)
+//   cls,reg = fc_cls(pooled), fc_reg(pooled)  -> [R*N,2], [R*N,4]   fgn_roi_head.py:338
+//
+// The reference concatenates (RoI feature, class-mean support feature) on channels and
+// runs one 2048->1024 1x1 conv per (RoI, class) (fgn_roi_head.py:260-270).  The conv is
+// linear, so W = [Wq | Ws] is split: Q = Wq * roi_feat is computed once per RoI and
+// S = Ws * support + bias once per class by the MFMA conv kernel; this kernel does the
+// per-(RoI,class) part, which is HBM/L2-bound: it reads Q once (not N times), never
+// materialises the [R*N,2048,7,7] concat or the [R*N,1024,7,7] normalised tensor, and
+// writes 6 floats per (RoI, class).
+//
+// Mapping: one workgroup per RoI, 4 waves; a wave owns one GroupNorm group
+// (32 channels x 49 pixels = 1568 values = 24.5 per lane): lane = (pixel slot 0..7,
+// channel quad 0..7), 7 float4 per lane stay in registers across the N classes.
+// Statistics are two-pass in registers (mean, then centred sum of squares) with
+// wavefront xor-shuffle reductions.
+#include "common.h"
+
+constexpr int REL_MAX_N = 8;
+
+__global__ __launch_bounds__(256) void relation_head_kernel(
+    const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ rois,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ fcw,
+    const float* __restrict__ fcb, float* __restrict__ cls_out, float* __restrict__ reg_out,
+    const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, float eps) {
+    constexpr int P = 49;
+    __shared__ float fc_acc[4][REL_MAX_N][6];
+    const int r = blockIdx.x;
+    int nr = n_rois;
+    if (n_rois_dev) nr = min(nr, *n_rois_dev);
+    if (r >= nr) return;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int quad = lane & 7, slot = lane >> 3;
+    const int img = (int)rois[(size_t)r * 5];
+    for (int i = t; i < 4 * REL_MAX_N * 6; i += 256) (&fc_acc[0][0][0])[i] = 0.f;
+    __syncthreads();
+
+    const float inv_cnt = 1.f / (32.f * (float)P);
+    const int groups = C / 32;
+    for (int g = wv; g < groups; g += 4) {
+        const int c = g * 32 + quad * 4;
+        float4 q[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int p = slot + 8 * i;
+            q[i] = (p < P) ? *reinterpret_cast<const float4*>(Q + ((size_t)r * P + p) * C + c)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float4 fw[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const float4*>(fcw + (size_t)j * C + c);
+
+        for (int n = 0; n < n_ways; ++n) {
+            const float* Sn = S + ((size_t)(img * n_ways + n) * P) * C + c;
+            float4 x[7];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int p = slot + 8 * i;
+                if (p < P) {
+                    const float4 s = *reinterpret_cast<const float4*>(Sn + (size_t)p * C);
+                    x[i] = make_float4(q[i].x + s.x, q[i].y + s.y, q[i].z + s.z, q[i].w + s.w);
+                    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+                } else {
+                    x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const float mean = wave_reduce_sum(sum) * inv_cnt;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int p = slot + 8 * i;
+                if (p < P) {
+                    const float a = x[i].x - mean, b = x[i].y - mean, d = x[i].z - mean, e = x[i].w - mean;
+                    sq += (a * a + b * b) + (d * d + e * e);
+                }
+            }
+            const float var = wave_reduce_sum(sq) * inv_cnt;
+            const float rstd = 1.f / sqrtf(var + eps);
+            float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int p = slot + 8 * i;
+                if (p < P) {
+                    pool.x += fmaxf((x[i].x - mean) * rstd * ga.x + be.x, 0.f);
+                    pool.y += fmaxf((x[i].y - mean) * rstd * ga.y + be.y, 0.f);
+                    pool.z += fmaxf((x[i].z - mean) * rstd * ga.z + be.z, 0.f);
+                    pool.w += fmaxf((x[i].w - mean) * rstd * ga.w + be.w, 0.f);
+                }
+            }
+            // reduce over the 8 pixel slots (lanes differing in bits 3..5), then over quads
+            float dots[6];
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                pool.x += __shfl_xor(pool.x, off, 64);
+                pool.y += __shfl_xor(pool.y, off, 64);
+                pool.z += __shfl_xor(pool.z, off, 64);
+                pool.w += __shfl_xor(pool.w, off, 64);
+            }
+            const float ip = 1.f / (float)P;
+            pool.x *= ip; pool.y *= ip; pool.z *= ip; pool.w *= ip;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float d = (pool.x * fw[j].x + pool.y * fw[j].y) + (pool.z * fw[j].z + pool.w * fw[j].w);
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                dots[j] = d;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) fc_acc[wv][n][j] += dots[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (t < n_ways * 6) {
+        const int n = t / 6, j = t - n * 6;
+        const float v = ((fc_acc[0][n][j] + fc_acc[1][n][j]) + (fc_acc[2][n][j] + fc_acc[3][n][j])) + fcb[j];
+        const size_t row = (size_t)r * n_ways + n;
+        if (j < 2) cls_out[row * 2 + j] = v;
+        else reg_out[row * 4 + (j - 2)] = v;
+    }
+}
+
+extern "C" int fgn_relation_gn_head_f32(const float* Q, const float* S, const float* rois, const float* gn_weight,
+                                        const float* gn_bias, const float* fc_weight, const float* fc_bias,
+                                        float* cls_out, float* reg_out, const int32_t* n_rois_dev, int n_rois,
+                                        int n_ways, int C, int gn_groups, int roi_size, float eps,
+                                        hipStream_t stream) {
+    if (!Q || !S || !rois || !gn_weight || !gn_bias || !fc_weight || !fc_bias || !cls_out || !reg_out)
+        return FGN_ERR_ARG;
+    if (roi_size != 7 || gn_groups <= 0 || C != gn_groups * 32 || n_ways < 1 || n_ways > REL_MAX_N)
+        return FGN_ERR_SHAPE;
+    if (n_rois == 0) return FGN_OK;
+    hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois), dim3(256), 0, stream, Q, S, rois, gn_weight, gn_bias,
+                       fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, eps);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}

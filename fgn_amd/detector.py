@@ -1,0 +1,377 @@
+"""FGN detector: the drop-in boundary of the hot path.
+
+Mirrors the reference's detector API (subprojects/sp02_omniiseg_fgn_mmdet/fgn.py:28-303):
+``FGN(n_ways, k_shots, backbone=..., rpn_head=..., roi_head=..., train_cfg=..., test_cfg=...)``,
+``forward(return_loss, **batch)``, ``simple_test(**batch, rescale=True)`` with the
+FewShotISEG batch dict in and the per-image result dicts out (same keys, numpy values,
+YXYX boxes, COCO RLE masks).  The constructor accepts the reference's mmcv-style config
+dicts (fgn_r50_c4_densecl.py:13-186) unchanged.
+
+Host code is Python/PyTorch plumbing (device memory, streams).  Every arithmetic step
+runs in libfgn_hip.so (hand-written gfx950 HIP kernels, include/fgn_hip.h); there is no
+eager/CPU fallback: without the library or without a GPU ``simple_test`` raises.
+
+Data layout in HBM: all feature maps NHWC fp32; RoI tensors [R,7,7,C] (a RoI is an
+"image" of the conv kernel); weights pre-packed [CoutPad][KH][KW][Cin]; eval-mode BN
+folded into a per-channel scale/shift epilogue.  Data-dependent counts (proposals,
+detections) stay in device int32 counters consumed by the kernels, so an episode runs
+without host synchronisation until the final device-to-host copy of the results.
+"""
+from __future__ import annotations
+
+import copy
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import config as _config
+from . import ops, rle
+from .weights import init_state_dict
+
+
+# ------------------------------------------------------------------------------------------
+# reference-style (mmcv) config -> flat config
+# ------------------------------------------------------------------------------------------
+_R50_BLOCKS = (3, 4, 6, 3)
+
+
+def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=None, test_cfg=None) -> dict:
+    """Accept either this package's flat dicts or the reference's mmcv config dicts."""
+    cfg = _config.fgn_r50_c4_config(n_ways, k_shots)
+    if backbone:
+        if 'stage_blocks' in backbone:
+            cfg['backbone'].update(backbone)
+        else:   # mmdet ResNet dict (fgn_r50_c4_densecl.py:15-42); layer4 is dropped (main.py:403-405)
+            if backbone.get('depth', 50) != 50 or backbone.get('deep_stem') or backbone.get('avg_down'):
+                raise NotImplementedError('only the DenseCL ResNet-50-C4 backbone variant is built')
+            last = max(backbone.get('out_indices', (2,)))
+            cfg['backbone'].update(stage_blocks=_R50_BLOCKS[:last + 1],
+                                   stage_planes=(64, 128, 256, 512)[:last + 1],
+                                   strides=tuple(backbone.get('strides', (1, 2, 2, 2)))[:last + 1])
+    if rpn_head:
+        r = cfg['rpn_head']
+        if 'anchor_generator' in rpn_head:
+            ag, bc = rpn_head['anchor_generator'], rpn_head.get('bbox_coder', {})
+            r.update(in_channels=rpn_head.get('in_channels', r['in_channels']),
+                     feat_channels=rpn_head.get('feat_channels', r['feat_channels']),
+                     anchor_scales=tuple(ag['scales']), anchor_ratios=tuple(ag['ratios']),
+                     anchor_stride=ag['strides'][0],
+                     target_means=tuple(bc.get('target_means', r['target_means'])),
+                     target_stds=tuple(bc.get('target_stds', r['target_stds'])))
+        else:
+            r.update(rpn_head)
+    if roi_head:
+        h = cfg['roi_head']
+        if 'bbox_roi_extractor' in roi_head:
+            ex = roi_head['bbox_roi_extractor']
+            h.update(roi_out_size=ex['roi_layer']['output_size'],
+                     roi_sampling_ratio=ex['roi_layer'].get('sampling_ratio', 0),
+                     featmap_stride=ex['featmap_strides'][0])
+            bh, mh = roi_head.get('bbox_head', {}), roi_head.get('mask_head', {})
+            bc = bh.get('bbox_coder', {})
+            h['bbox_head'].update(in_channels=bh.get('in_channels', 1024), num_classes=bh.get('num_classes', 1),
+                                  target_means=tuple(bc.get('target_means', (0., 0., 0., 0.))),
+                                  target_stds=tuple(bc.get('target_stds', (.1, .1, .2, .2))))
+            h['mask_head'].update({k: mh[k] for k in ('num_convs', 'in_channels', 'conv_out_channels',
+                                                      'num_classes') if k in mh})
+        else:
+            for k, v in roi_head.items():
+                if isinstance(v, dict) and k in h:
+                    h[k].update(v)
+                else:
+                    h[k] = v
+    if test_cfg:
+        t = cfg['test_cfg']
+        for part in ('rpn', 'rcnn'):
+            src = dict(test_cfg.get(part, {}))
+            if 'nms' in src:
+                src['nms_iou_threshold'] = src.pop('nms')['iou_threshold']
+            t[part].update(src)
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------
+class _Bottleneck:
+    def __init__(self, sd, prefix, stride, eps):
+        bn = lambda n: {k: sd[f'{prefix}.{n}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+        self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'], bn=bn('bn1'), relu=True, eps=eps)
+        self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], bn=bn('bn2'), stride=stride, pad=1, relu=True,
+                                   eps=eps)
+        self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'], bn=bn('bn3'), relu=True, eps=eps)
+        self.down = None
+        if (prefix + '.downsample.0.weight') in sd:
+            dbn = {k: sd[f'{prefix}.downsample.1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+            self.down = ops.pack_conv(sd[prefix + '.downsample.0.weight'], bn=dbn, stride=stride, eps=eps)
+
+    def layers(self):
+        return [l for l in (self.conv1, self.conv2, self.conv3, self.down) if l is not None]
+
+    def __call__(self, x, n_img_dev=None):
+        idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
+        y = ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
+        y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
+        return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
+
+
+class FGN(torch.nn.Module):
+    """Fully Guided Network, inference path, on MI355X HIP kernels."""
+    fp16_enabled = False
+    subsampling_ratio = 16
+
+    def __init__(self, n_ways: int, k_shots: int, backbone: Optional[dict] = None, rpn_head: Optional[dict] = None,
+                 roi_head: Optional[dict] = None, train_cfg: Optional[dict] = None, test_cfg: Optional[dict] = None,
+                 neck=None, pretrained=None, init_cfg=None, state_dict: Optional[dict] = None, seed: int = 0,
+                 type: Optional[str] = None, **kwargs):
+        super().__init__()
+        if type not in (None, 'FGN'):
+            raise ValueError(f'cannot build detector type {type!r}')
+        self.n_ways, self.k_shots = int(n_ways), int(k_shots)
+        self.cfg = normalise_config(self.n_ways, self.k_shots, backbone, rpn_head, roi_head, test_cfg)
+        self.train_cfg = train_cfg
+        self.test_cfg = self.cfg['test_cfg']
+        self._sd = OrderedDict((k, v.detach().float().cpu()) for k, v in
+                               (state_dict if state_dict is not None else init_state_dict(self.cfg, seed)).items())
+        self._packed_device = None
+        self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
+
+    @classmethod
+    def from_config(cls, model_cfg: dict, **kw) -> 'FGN':
+        """``build_detector(cfg.model, ...)`` equivalent (main.py:390-394)."""
+        model_cfg = copy.deepcopy(dict(model_cfg))
+        model_cfg.pop('type', None)
+        model_cfg.update(kw)
+        return cls(**model_cfg)
+
+    # --- weights --------------------------------------------------------------------------
+    def state_dict(self, *a, **k):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = state_dict.get('state_dict', state_dict)
+        missing = [k for k in self._sd if k not in sd]
+        if strict and missing:
+            raise KeyError(f'missing keys in state_dict: {missing[:5]} ...')
+        for k in self._sd:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(self._sd[k].shape):
+                    raise ValueError(f'shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._sd[k].shape)}')
+                self._sd[k] = sd[k].detach().float().cpu()
+        self._packed_device = None
+
+    def _pack(self, device):
+        """Fold BN, re-layout weights for the kernels and move them to ``device``."""
+        sd, cfg = self._sd, self.cfg
+        eps = cfg['backbone']['bn_eps']
+        P = {}
+        bn1 = {k: sd[f'backbone.bn1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+        P['stem'] = ops.pack_conv(sd['backbone.conv1.weight'], bn=bn1, stride=2, pad=3, relu=True, eps=eps,
+                                  pad_cin_to=4)
+        P['stages'] = []
+        for li, (nblk, stride) in enumerate(zip(cfg['backbone']['stage_blocks'], cfg['backbone']['strides'])):
+            P['stages'].append([_Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps)
+                                for b in range(nblk)])
+        P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
+                                      relu=True)
+        # objectness and delta 1x1 convs fused into one launch: channels [0,A) | [A,5A)
+        P['rpn_head'] = ops.pack_conv(
+            torch.cat([sd['rpn_head.rpn_cls.weight'], sd['rpn_head.rpn_reg.weight']], 0),
+            bias=torch.cat([sd['rpn_head.rpn_cls.bias'], sd['rpn_head.rpn_reg.bias']], 0))
+        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps)
+                       for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
+        # relation conv split along its input channels: [Wq | Ws] (fgn_roi_head.py:270)
+        wrel = sd['roi_head.cls_reg_shared_conv.weight']
+        c = wrel.shape[1] // 2
+        P['rel_q'] = ops.pack_conv(wrel[:, :c].contiguous())
+        P['rel_s'] = ops.pack_conv(wrel[:, c:].contiguous(), bias=sd['roi_head.cls_reg_shared_conv.bias'])
+        P['gn_w'] = sd['roi_head.cls_reg_shared_conv_norm.weight'].clone()
+        P['gn_b'] = sd['roi_head.cls_reg_shared_conv_norm.bias'].clone()
+        P['fc_w'] = torch.cat([sd['roi_head.bbox_head.fc_cls.weight'], sd['roi_head.bbox_head.fc_reg.weight']], 0)
+        P['fc_b'] = torch.cat([sd['roi_head.bbox_head.fc_cls.bias'], sd['roi_head.bbox_head.fc_reg.bias']], 0)
+        mh = cfg['roi_head']['mask_head']
+        P['mask_convs'] = [ops.pack_conv(sd[f'roi_head.mask_head.convs.{i}.conv.weight'],
+                                         bias=sd[f'roi_head.mask_head.convs.{i}.conv.bias'], pad=1, relu=True)
+                           for i in range(mh['num_convs'])]
+        # ConvTranspose2d(k=2,s=2) [Cin,Cout,2,2] -> 1x1 conv with 4*Cout outputs, n=(dy*2+dx)*Cout+co
+        wt = sd['roi_head.mask_head.upsample.weight']
+        cin_u, cout_u = wt.shape[:2]
+        w4 = wt.permute(2, 3, 1, 0).reshape(4 * cout_u, cin_u, 1, 1).contiguous()
+        P['upsample'] = ops.pack_conv(w4, bias=sd['roi_head.mask_head.upsample.bias'].repeat(4), relu=True)
+        P['logit_w'] = sd['roi_head.mask_head.conv_logits.weight'].reshape(-1).clone()
+        P['logit_b'] = float(sd['roi_head.mask_head.conv_logits.bias'][0])
+        rp = cfg['rpn_head']
+        P['anchors'] = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'],
+                                                         rp['anchor_stride']))
+
+        def mv(o):
+            if isinstance(o, torch.Tensor):
+                return o.float().contiguous().to(device)
+            if isinstance(o, ops.ConvLayer):
+                return o.to(device)
+            if isinstance(o, _Bottleneck):
+                for l in o.layers():
+                    l.to(device)
+                return o
+            if isinstance(o, list):
+                return [mv(x) for x in o]
+            return o
+        self._P = {k: mv(v) for k, v in P.items()}
+        self._packed_device = torch.device(device)
+
+    # --- stages ---------------------------------------------------------------------------
+    def extract_feat(self, img_nchw: torch.Tensor) -> torch.Tensor:
+        """ResNet-50 stages 1-3 (fgn.py:67-77): NCHW fp32 in, NHWC [B,h,w,1024] out."""
+        P = self._P
+        x = ops.nchw3_to_nhwc4(img_nchw.contiguous())
+        x = ops.conv2d(x, P['stem'])
+        x = ops.maxpool3x3s2(x)
+        for stage in P['stages']:
+            for blk in stage:
+                x = blk(x)
+        return x
+
+    def _shared_head(self, x, n_img_dev=None):
+        for blk in self._P['shared']:
+            x = blk(x, n_img_dev)
+        return x
+
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.simple_test(**kwargs)
+
+    def forward_train(self, **kwargs):
+        raise NotImplementedError('training (fgn.py:125-185) is outside the accelerated path; '
+                                  'train with the reference and load the checkpoint here')
+
+    @torch.no_grad()
+    def simple_test(self, qry_img, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None, qry_bboxes_ignore=None,
+                    spp_imgs=None, spp_bboxes=None, spp_isegmaps=None, qry_child_idx=None, img_shape=None,
+                    rescale=False, cats_ids_to_sample_real=None, spp_insts_ids=None, idx=None,
+                    **kwargs) -> List[Dict]:
+        """Test without augmentation (fgn.py:187-303)."""
+        dets = self.detect_device(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape)
+        return self.pack_results(dets, qry_img.shape[0], qry_bboxes=qry_bboxes, qry_cat_ids=qry_cat_ids,
+                                 qry_isegmaps=qry_isegmaps, img_shape=img_shape, qry_child_idx=qry_child_idx,
+                                 cats_ids_to_sample_real=cats_ids_to_sample_real, spp_insts_ids=spp_insts_ids,
+                                 idx=idx)
+
+    @torch.no_grad()
+    def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape) -> list:
+        """Everything up to (not including) the device->host copy.  Returns, per image, a
+        dict of device tensors: det_bboxes [D,5], det_labels [D], n_dets [1], masks u8 [D,H,W]."""
+        if not torch.cuda.is_available():
+            raise ops._lib.FgnHipError('FGN.simple_test needs a GPU: the HIP path has no CPU fallback')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if self._packed_device != dev:
+            self._pack(dev)
+        P, cfg = self._P, self.cfg
+        N, K = self.n_ways, self.k_shots
+        tr = self.debug_trace
+        B, _, H, W = qry_img.shape
+        rh, rp, tc = cfg['roi_head'], cfg['rpn_head'], cfg['test_cfg']
+        PS = rh['roi_out_size']
+        inv_stride = 1.0 / rh['featmap_stride']
+
+        # modify_input (fgn.py:79-108): H2D, YXYX -> XYXY on private copies
+        qry = qry_img.to(dev, torch.float32, non_blocking=True)
+        spp = spp_imgs.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, *spp_imgs.shape[-3:])
+        spp_xyxy = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)[:, [1, 0, 3, 2]]
+        spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
+
+        qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
+        spp_fmaps = self.extract_feat(spp)                      # [B*N*K,s,s,C]
+        fh, fw, C = qry_fmap.shape[1:]
+        if tr is not None:
+            tr['qry_fmap'], tr['spp_fmaps'] = qry_fmap, spp_fmaps
+
+        # ---- AG-RPN (fgn_ag_rpn_head.py:26-118) -------------------------------------------
+        vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
+        x = ops.conv2d(qry_fmap, P['rpn_conv'], in_scale=vec, a_img_div=N)      # guidance fused
+        head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
+        A = P['anchors'].shape[0]
+        logits, scores, deltas = ops.rpn_merge(head, B, N, A)
+        ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
+        if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
+            raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
+        props, n_props = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
+                                           rp['target_means'], rp['target_stds'], tc['rpn']['nms_pre'],
+                                           tc['rpn']['min_bbox_size'], tc['rpn']['nms_iou_threshold'],
+                                           tc['rpn']['max_per_img'])
+        if tr is not None:
+            tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
+                      n_props=n_props)
+
+        # ---- count_spp (fgn_roi_head.py:419-449) ------------------------------------------
+        bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
+        spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
+        masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
+        # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
+        sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
+        sfeat = self._shared_head(sfeat)
+        cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
+        cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
+        S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
+        if tr is not None:
+            tr.update(spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
+
+        # ---- per image: box head, detections, mask head -----------------------------------
+        outs = []
+        rel = rh['relation']
+        bh = rh['bbox_head']
+        for i in range(B):
+            cnt = n_props[i:i + 1]
+            rois = torch.cat([torch.full((props.shape[1], 1), float(i), device=dev), props[i, :, :4]], 1).contiguous()
+            feats = ops.roi_align(qry_fmap, rois, PS, inv_stride, rh['roi_sampling_ratio'], True, cnt)
+            feats = self._shared_head(feats, cnt)
+            Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt)
+            cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
+                                                    rel['gn_groups'], rel['gn_eps'], cnt)
+            det, lab, n_det = ops.det_post(rois, cls_raw, reg_raw, N, ih, iw, bh['target_means'], bh['target_stds'],
+                                           tc['rcnn']['score_thr'], tc['rcnn']['nms_iou_threshold'],
+                                           tc['rcnn']['max_per_img'], cnt)
+            # mask branch (fgn_roi_head.py:704-718, 360-382)
+            mrois = torch.cat([torch.full((det.shape[0], 1), float(i), device=dev), det[:, :4]], 1).contiguous()
+            vmask = ops.gather_support_vectors(cat_mean_mp, lab, mrois, N, n_det)
+            mf = ops.roi_align(qry_fmap, mrois, PS, inv_stride, rh['roi_sampling_ratio'], True, n_det)
+            mf = self._shared_head(mf, n_det)
+            m = ops.conv2d(mf, P['mask_convs'][0], in_scale=vmask, n_img_dev=n_det)   # guidance fused
+            for layer in P['mask_convs'][1:]:
+                m = ops.conv2d(m, layer, n_img_dev=n_det)
+            up = ops.conv2d(m, P['upsample'], n_img_dev=n_det)                   # [D,7,7,4*C']
+            mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, n_det)
+            masks = ops.mask_paste(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+            if tr is not None:
+                tr.setdefault('per_image', []).append(dict(
+                    rois=rois, roi_feats=feats, Q=Q, cls_raw=cls_raw, reg_raw=reg_raw, det=det, lab=lab,
+                    n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
+            outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, masks=masks))
+        return outs
+
+    def pack_results(self, dets: list, batch: int, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None,
+                     img_shape=None, qry_child_idx=None, cats_ids_to_sample_real=None, spp_insts_ids=None,
+                     idx=None) -> List[Dict]:
+        """Device->host copy and result dicts (fgn.py:240-303).  Passthrough boxes stay YXYX
+        (SERVER semantics); caller tensors are never mutated."""
+        passthrough = {'idx': idx, 'qry_bboxes': qry_bboxes, 'qry_img_shape': img_shape,
+                       'qry_cat_ids': qry_cat_ids, 'qry_child_idx': qry_child_idx,
+                       'cats_ids_to_sample_real': cats_ids_to_sample_real, 'spp_insts_ids': spp_insts_ids}
+        counts = torch.cat([d['n_dets'] for d in dets]).cpu().numpy()   # the one host sync
+        results = []
+        for i in range(batch):
+            n = int(counts[i])
+            db = dets[i]['det_bboxes'][:n].cpu().numpy()
+            one = {'dt_scores': db[:, 4].reshape(-1).copy(),
+                   'dt_bboxes': db[:, [1, 0, 3, 2]].reshape(-1, 4).copy(),
+                   'dt_cat_ids': dets[i]['det_labels'][:n].cpu().numpy().reshape(-1),
+                   'dt_isegmaps_rle': rle.encode_many(dets[i]['masks'][:n].cpu().numpy())}
+            for key, val in passthrough.items():
+                v = val[i] if val is not None else None
+                one[key] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v
+            gt = qry_isegmaps[i] if qry_isegmaps is not None else None
+            if gt is not None:
+                gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
+                one['qry_isegmaps_rle'] = rle.encode_many(gt)
+            results.append(one)
+        return results

@@ -1,0 +1,75 @@
+"""ctypes binding of libfgn_hip.so (include/fgn_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent this module
+raises, and every op raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfgn_hip.so')
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); mirrors include/fgn_hip.h one to one
+SIGNATURES = {
+    'fgn_abi_version': (_i, []),
+    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p]),
+    'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
+    'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    'fgn_roi_align_mask_u8': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    'fgn_support_class_vectors_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'fgn_support_kmean_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'fgn_gather_support_vectors_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p]),
+    'fgn_rpn_merge_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'fgn_rpn_proposals_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_rpn_proposals_f32': (_i, [_p] * 7 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
+                                            _f, _i, _f, _f, _i, _p]),
+    'fgn_det_post_scratch_bytes': (C.c_size_t, [_i, _i]),
+    'fgn_det_post_f32': (_i, [_p] * 9 + [_i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f), _f, _f, _f, _i, _p]),
+    'fgn_mask_logits_f32': (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
+    'fgn_mask_paste_u8': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class FgnHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and bind every symbol of the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FgnHipError(
+            f'{LIB_PATH} is missing: build it with `python -m fgn_amd.build` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise FgnHipError(f'libfgn_hip.so does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.fgn_abi_version()
+    if v != ABI_VERSION:
+        raise FgnHipError(f'libfgn_hip.so ABI {v} != expected {ABI_VERSION}; rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: 'unsupported shape', -2: 'bad argument'}.get(rc, f'hipError_t {rc}')
+        raise FgnHipError(f'{what} failed: {kind}')

@@ -1,0 +1,369 @@
+"""Thin tensor-level wrappers over the C-ABI (fgn_amd.lib).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every op validates
+operand shapes on the host (a mis-shaped launch can fault the GPU), passes raw device
+pointers plus the current stream to libfgn_hip.so, and raises on any error.  Tensors
+are NHWC fp32 and must be contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.FgnHipError(f'{name} must be a device tensor (no CPU fallback)')
+    if t.dtype != dtype:
+        raise _lib.FgnHipError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.FgnHipError(f'{name} must be contiguous')
+
+
+def _f4(vals):
+    return (C.c_float * 4)(*[float(v) for v in vals])
+
+
+# --------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------
+@dataclass
+class ConvLayer:
+    """A packed convolution: weights [cout_pad, KH*KW*Cin (padded to x32)], folded
+    per-channel epilogue scale/shift (eval-mode BN or bias)."""
+    w: torch.Tensor
+    scale: Optional[torch.Tensor]
+    shift: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    cout_pad: int
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+    relu: bool
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        self.scale = None if self.scale is None else self.scale.to(device)
+        self.shift = None if self.shift is None else self.shift.to(device)
+        return self
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
+              stride: int = 1, pad: int = 0, relu: bool = False, eps: float = 1e-5,
+              pad_cin_to: Optional[int] = None) -> ConvLayer:
+    """weight [Cout,Cin,KH,KW] (torch layout) -> ConvLayer.  ``bn`` = dict(weight, bias,
+    running_mean, running_var) folds eval-mode BatchNorm into scale/shift."""
+    weight = weight.detach().float()
+    cout, cin, kh, kw = weight.shape
+    if pad_cin_to is not None and pad_cin_to > cin:
+        weight = torch.cat([weight, weight.new_zeros(cout, pad_cin_to - cin, kh, kw)], dim=1)
+        cin = pad_cin_to
+    cout_pad = (cout + 127) // 128 * 128
+    k = kh * kw * cin
+    k_pad = (k + 31) // 32 * 32
+    w = weight.new_zeros(cout_pad, k_pad)
+    w[:cout, :k] = weight.permute(0, 2, 3, 1).reshape(cout, k)
+    scale = shift = None
+    if bn is not None:
+        scale = (bn['weight'].float() / torch.sqrt(bn['running_var'].float() + eps))
+        shift = bn['bias'].float() - bn['running_mean'].float() * scale
+        if bias is not None:
+            shift = shift + bias.float() * scale
+    elif bias is not None:
+        shift = bias.detach().float().clone()
+    return ConvLayer(w.contiguous(), None if scale is None else scale.contiguous(),
+                     None if shift is None else shift.contiguous(), cin, cout, cout_pad, kh, kw,
+                     stride, pad, relu)
+
+
+def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] = None,
+           in_scale: Optional[torch.Tensor] = None, n_img_dev: Optional[torch.Tensor] = None,
+           n_img: Optional[int] = None, a_img_div: int = 1, out: Optional[torch.Tensor] = None,
+           tile_hint: int = 0) -> torch.Tensor:
+    """x [n_in, H, W, Cin] -> y [n_img, Ho, Wo, Cout]; n_img defaults to n_in * a_img_div."""
+    _chk(x, 'x')
+    n_in, H, W, cin = x.shape
+    if cin != layer.cin:
+        raise _lib.FgnHipError(f'conv2d: Cin {cin} != layer Cin {layer.cin}')
+    if n_img is None:
+        n_img = n_in * a_img_div
+    if n_img > n_in * a_img_div:
+        raise _lib.FgnHipError('conv2d: n_img exceeds the input batch')
+    ho = (H + 2 * layer.pad - layer.kh) // layer.stride + 1
+    wo = (W + 2 * layer.pad - layer.kw) // layer.stride + 1
+    if out is None:
+        out = torch.empty((n_img, ho, wo, layer.cout), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        if tuple(out.shape) != (n_img, ho, wo, layer.cout):
+            raise _lib.FgnHipError('conv2d: bad out shape')
+    if residual is not None:
+        _chk(residual, 'residual')
+        if residual.shape != out.shape:
+            raise _lib.FgnHipError('conv2d: residual shape mismatch')
+    if in_scale is not None:
+        _chk(in_scale, 'in_scale')
+        if tuple(in_scale.shape) != (n_img, cin):
+            raise _lib.FgnHipError(f'conv2d: in_scale must be [{n_img},{cin}], got {tuple(in_scale.shape)}')
+    if n_img_dev is not None:
+        _chk(n_img_dev, 'n_img_dev', torch.int32)
+    rc = _lib.load().fgn_conv2d_nhwc_f32(
+        _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
+        _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
+        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _stream())
+    _lib.check(rc, 'fgn_conv2d_nhwc_f32')
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# spatial ops
+# --------------------------------------------------------------------------------------
+def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    if c != 3:
+        raise _lib.FgnHipError('nchw3_to_nhwc4: expects 3 channels')
+    y = torch.empty((n, h, w, 4), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fgn_nchw3_to_nhwc4_f32(_ptr(x), _ptr(y), n, h, w, _stream()),
+               'fgn_nchw3_to_nhwc4_f32')
+    return y
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fgn_maxpool3x3s2_nhwc_f32(_ptr(x), _ptr(y), n, h, w, c, _stream()),
+               'fgn_maxpool3x3s2_nhwc_f32')
+    return y
+
+
+def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
+              sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fmap [B,H,W,C], rois [R,5] -> [R,P,P,C]."""
+    _chk(fmap, 'fmap')
+    _chk(rois, 'rois')
+    b, h, w, c = fmap.shape
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise _lib.FgnHipError('roi_align: rois must be [R,5]')
+    r = rois.shape[0]
+    out = torch.empty((r, out_size, out_size, c), device=fmap.device, dtype=torch.float32)
+    if n_rois_dev is not None:
+        _chk(n_rois_dev, 'n_rois_dev', torch.int32)
+    rc = _lib.load().fgn_roi_align_nhwc_f32(_ptr(fmap), _ptr(rois), _ptr(out), _ptr(n_rois_dev), r, b, h, w, c,
+                                            out_size, float(spatial_scale), sampling_ratio, int(aligned),
+                                            _stream())
+    _lib.check(rc, 'fgn_roi_align_nhwc_f32')
+    return out
+
+
+def roi_align_mask(mask_u8: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
+                   sampling_ratio: int, aligned: bool) -> torch.Tensor:
+    """mask [B,H,W] uint8 -> [R,P,P] fp32."""
+    _chk(mask_u8, 'mask', torch.uint8)
+    _chk(rois, 'rois')
+    b, h, w = mask_u8.shape
+    r = rois.shape[0]
+    out = torch.empty((r, out_size, out_size), device=mask_u8.device, dtype=torch.float32)
+    rc = _lib.load().fgn_roi_align_mask_u8(_ptr(mask_u8), _ptr(rois), _ptr(out), r, b, h, w, out_size,
+                                           float(spatial_scale), sampling_ratio, int(aligned), _stream())
+    _lib.check(rc, 'fgn_roi_align_mask_u8')
+    return out
+
+
+def support_class_vectors(x: torch.Tensor, weights: Optional[torch.Tensor], n_groups: int, k: int) -> torch.Tensor:
+    """x [n_groups*k, P.., C] -> [n_groups, C] mean over (k, P) of x * weights."""
+    _chk(x, 'x')
+    c = x.shape[-1]
+    p = x[0].numel() // c
+    if x.shape[0] != n_groups * k:
+        raise _lib.FgnHipError('support_class_vectors: leading dim != n_groups*k')
+    if weights is not None:
+        _chk(weights, 'weights')
+        if weights.numel() != n_groups * k * p:
+            raise _lib.FgnHipError('support_class_vectors: weights shape mismatch')
+    out = torch.empty((n_groups, c), device=x.device, dtype=torch.float32)
+    rc = _lib.load().fgn_support_class_vectors_f32(_ptr(x), _ptr(weights), _ptr(out), n_groups, k, p, c, _stream())
+    _lib.check(rc, 'fgn_support_class_vectors_f32')
+    return out
+
+
+def support_kmean(x: torch.Tensor, n_groups: int, k: int) -> torch.Tensor:
+    _chk(x, 'x')
+    if x.shape[0] != n_groups * k:
+        raise _lib.FgnHipError('support_kmean: leading dim != n_groups*k')
+    c = x.shape[-1]
+    p = x[0].numel() // c
+    out = torch.empty((n_groups,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    rc = _lib.load().fgn_support_kmean_f32(_ptr(x), _ptr(out), n_groups, k, p, c, _stream())
+    _lib.check(rc, 'fgn_support_kmean_f32')
+    return out
+
+
+def gather_support_vectors(table: torch.Tensor, labels: torch.Tensor, rois: Optional[torch.Tensor],
+                           n_ways: int, n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(table, 'table')
+    _chk(labels, 'labels', torch.int64)
+    n, c = labels.shape[0], table.shape[-1]
+    if rois is not None:
+        _chk(rois, 'rois')
+        if rois.shape[0] < n or rois.shape[1] != 5:
+            raise _lib.FgnHipError('gather_support_vectors: rois must be [>=n,5]')
+    out = torch.zeros((n, c), device=table.device, dtype=torch.float32)
+    rc = _lib.load().fgn_gather_support_vectors_f32(_ptr(table), _ptr(labels), _ptr(rois), _ptr(out), _ptr(n_dev),
+                                                    n, n_ways, c, _stream())
+    _lib.check(rc, 'fgn_gather_support_vectors_f32')
+    return out
+
+
+def relation_gn_head(q: torch.Tensor, s: torch.Tensor, rois: torch.Tensor, gn_w, gn_b, fc_w, fc_b,
+                     n_ways: int, gn_groups: int, eps: float, n_rois_dev: Optional[torch.Tensor] = None):
+    """q [R,7,7,C]; s [B*N,7,7,C]; rois [R,5] -> cls_raw [R*N,2], reg_raw [R*N,4]."""
+    for t, nm in ((q, 'Q'), (s, 'S'), (rois, 'rois'), (gn_w, 'gn_w'), (gn_b, 'gn_b'), (fc_w, 'fc_w'), (fc_b, 'fc_b')):
+        _chk(t, nm)
+    r, p, _, c = q.shape
+    if s.shape[1:] != q.shape[1:] or s.shape[0] % n_ways or rois.shape[0] < r or fc_w.shape != (6, c):
+        raise _lib.FgnHipError('relation_gn_head: operand shapes inconsistent')
+    cls = torch.zeros((r * n_ways, 2), device=q.device, dtype=torch.float32)
+    reg = torch.zeros((r * n_ways, 4), device=q.device, dtype=torch.float32)
+    rc = _lib.load().fgn_relation_gn_head_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
+                                              _ptr(fc_b), _ptr(cls), _ptr(reg), _ptr(n_rois_dev), r, n_ways, c,
+                                              gn_groups, p, float(eps), _stream())
+    _lib.check(rc, 'fgn_relation_gn_head_f32')
+    return cls, reg
+
+
+# --------------------------------------------------------------------------------------
+# selection stages
+# --------------------------------------------------------------------------------------
+MAX_RATIO = float(np.float32(abs(math.log(16.0 / 1000.0))))
+
+
+def base_anchors(scales, ratios, base_size) -> np.ndarray:
+    """mmdet AnchorGenerator base anchors (ratio-major, centre 0, not rounded), fp32."""
+    f = np.float32
+    w = h = f(base_size)
+    ratios = np.asarray(ratios, f)
+    scales = np.asarray(scales, f)
+    h_ratios = np.sqrt(ratios)
+    w_ratios = (f(1) / h_ratios).astype(f)
+    ws = (w * w_ratios[:, None] * scales[None, :]).reshape(-1).astype(f)
+    hs = (h * h_ratios[:, None] * scales[None, :]).reshape(-1).astype(f)
+    c = f(0.0) * w
+    return np.stack([c - f(0.5) * ws, c - f(0.5) * hs, c + f(0.5) * ws, c + f(0.5) * hs], -1).astype(f)
+
+
+def rpn_merge(head: torch.Tensor, batch: int, n_ways: int, n_anchors: int):
+    """head [B*N, h, w, CH] -> logits, scores [B, h*w*A], deltas [B, h*w*A, 4]."""
+    _chk(head, 'head')
+    bn, h, w, ch = head.shape
+    if bn != batch * n_ways:
+        raise _lib.FgnHipError('rpn_merge: leading dim != batch*n_ways')
+    n = h * w * n_anchors
+    logits = torch.empty((batch, n), device=head.device, dtype=torch.float32)
+    scores = torch.empty_like(logits)
+    deltas = torch.empty((batch, n, 4), device=head.device, dtype=torch.float32)
+    rc = _lib.load().fgn_rpn_merge_f32(_ptr(head), _ptr(logits), _ptr(scores), _ptr(deltas), batch, n_ways, h * w,
+                                       n_anchors, ch, _stream())
+    _lib.check(rc, 'fgn_rpn_merge_f32')
+    return logits, scores, deltas
+
+
+def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torch.Tensor, feat_h: int, feat_w: int,
+                  stride: int, img_h: int, img_w: int, means, stds, nms_pre: int, min_bbox_size: float,
+                  iou_thr: float, max_per_img: int, debug_topk: bool = False):
+    _chk(scores, 'scores')
+    _chk(deltas, 'deltas')
+    _chk(anchors_base, 'anchors_base')
+    batch, n_total = scores.shape
+    a = anchors_base.shape[0]
+    if n_total != feat_h * feat_w * a or tuple(deltas.shape) != (batch, n_total, 4):
+        raise _lib.FgnHipError('rpn_proposals: operand shapes inconsistent')
+    L = _lib.load()
+    scratch = torch.empty(L.fgn_rpn_proposals_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
+                          dtype=torch.uint8)
+    props = torch.empty((batch, max_per_img, 5), device=scores.device, dtype=torch.float32)
+    n_props = torch.zeros((batch,), device=scores.device, dtype=torch.int32)
+    dbg = None
+    if debug_topk:
+        dbg = torch.full((batch, 8192), -1, device=scores.device, dtype=torch.int32)
+    rc = L.fgn_rpn_proposals_f32(_ptr(scores), _ptr(deltas), _ptr(anchors_base), _ptr(scratch), _ptr(props),
+                                 _ptr(n_props), _ptr(dbg), batch, feat_h, feat_w, a, stride, float(img_h),
+                                 float(img_w), _f4(means), _f4(stds), MAX_RATIO, nms_pre, float(min_bbox_size),
+                                 float(iou_thr), max_per_img, _stream())
+    _lib.check(rc, 'fgn_rpn_proposals_f32')
+    if debug_topk:
+        return props, n_props, dbg
+    return props, n_props
+
+
+def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n_ways: int, img_h: int, img_w: int,
+             means, stds, score_thr: float, iou_thr: float, max_per_img: int,
+             n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False):
+    for t, nm in ((rois, 'rois'), (cls_raw, 'cls_raw'), (reg_raw, 'reg_raw')):
+        _chk(t, nm)
+    r = rois.shape[0]
+    if rois.shape[1] != 5 or tuple(cls_raw.shape) != (r * n_ways, 2) or tuple(reg_raw.shape) != (r * n_ways, 4):
+        raise _lib.FgnHipError('det_post: operand shapes inconsistent')
+    L = _lib.load()
+    scratch = torch.empty(L.fgn_det_post_scratch_bytes(r, n_ways), device=rois.device, dtype=torch.uint8)
+    det = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32)
+    lab = torch.empty((max_per_img,), device=rois.device, dtype=torch.int64)
+    n_det = torch.zeros((1,), device=rois.device, dtype=torch.int32)
+    dbg = torch.zeros((r, n_ways + 1), device=rois.device, dtype=torch.float32) if debug_scores else None
+    rc = L.fgn_det_post_f32(_ptr(rois), _ptr(cls_raw), _ptr(reg_raw), _ptr(n_rois_dev), _ptr(scratch), _ptr(det),
+                            _ptr(lab), _ptr(n_det), _ptr(dbg), r, n_ways, float(img_h), float(img_w), _f4(means),
+                            _f4(stds), MAX_RATIO, float(score_thr), float(iou_thr), max_per_img, _stream())
+    _lib.check(rc, 'fgn_det_post_f32')
+    if debug_scores:
+        return det, lab, n_det, dbg
+    return det, lab, n_det
+
+
+def mask_logits(x: torch.Tensor, w: torch.Tensor, bias: float, roi_size: int,
+                n_dev: Optional[torch.Tensor] = None):
+    """x [D, P, P, 4*C] (deconv output, sub-position major) -> logits, prob [D, 2P, 2P]."""
+    _chk(x, 'x')
+    _chk(w, 'w')
+    d = x.shape[0]
+    c = w.numel()
+    if x[0].numel() != roi_size * roi_size * 4 * c:
+        raise _lib.FgnHipError('mask_logits: x shape inconsistent with weight')
+    logits = torch.zeros((d, 2 * roi_size, 2 * roi_size), device=x.device, dtype=torch.float32)
+    prob = torch.zeros_like(logits)
+    rc = _lib.load().fgn_mask_logits_f32(_ptr(x), _ptr(w), float(bias), _ptr(logits), _ptr(prob), _ptr(n_dev), d,
+                                         roi_size, c, _stream())
+    _lib.check(rc, 'fgn_mask_logits_f32')
+    return logits, prob
+
+
+def mask_paste(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,
+               n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """prob [D, M, M], boxes [D, >=4] (x1,y1,x2,y2 first) -> uint8 [D, H, W]."""
+    _chk(prob, 'prob')
+    _chk(boxes, 'boxes')
+    d, m, _ = prob.shape
+    if boxes.shape[0] != d or boxes.shape[1] < 4:
+        raise _lib.FgnHipError('mask_paste: boxes shape mismatch')
+    out = torch.empty((d, img_h, img_w), device=prob.device, dtype=torch.uint8)
+    rc = _lib.load().fgn_mask_paste_u8(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(out), _ptr(n_dev), d, img_h,
+                                       img_w, m, float(thr), _stream())
+    _lib.check(rc, 'fgn_mask_paste_u8')
+    return out

@@ -1,0 +1,126 @@
+/* libfgn_hip.so -- C-ABI of the MI355X (gfx950) FGN inference kernels.
+ *
+ * The reference (tooHotSpot/FGN) has no native/FFI layer: its hot path is Python
+ * (subprojects/sp02_omniiseg_fgn_mmdet/fgn.py:187-303) calling CUDA kernels inside the
+ * mmdet / mmcv / torchvision / torch wheels.  Each entry point below replaces one of
+ * those third-party kernel families at the call site cited; a maintainer binds them
+ * with ctypes or any other FFI: plain pointers and sizes only, no
+ * torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; tensors are fp32, NHWC
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing here
+ *     allocates, frees or synchronises: the caller owns workspaces, calls are
+ *     asynchronous and safe to capture in a hipGraph
+ *   - `n_*_dev` arguments are optional device int32 counters: when non-NULL the kernel
+ *     processes min(*n_dev, n) items, so data-dependent counts (proposals, detections)
+ *     never round-trip through the host
+ *   - return value: 0 on success, <0 for FGN_ERR_* (bad argument / unsupported shape),
+ *     >0 for a hipError_t from the launch
+ */
+#ifndef FGN_HIP_H
+#define FGN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGN_OK 0
+#define FGN_ERR_SHAPE (-1)
+#define FGN_ERR_ARG (-2)
+
+int fgn_abi_version(void);
+
+/* Implicit-GEMM convolution on the fp32 MFMA pipe with fused epilogue
+ *   y = conv(x * in_scale?, w) * scale[c] + shift[c] (+ residual) (ReLU)
+ * Replaces cuDNN conv + BN(eval) + ReLU of mmdet ResNet (fgn.py:212,215), RPNHead
+ * (fgn_ag_rpn_head.py:48), shared_head ResLayer (fgn_roi_head.py:236,369,436), the two
+ * halves of cls_reg_shared_conv (fgn_roi_head.py:270), FCNMaskHead convs and the 2x2
+ * deconv (fgn_roi_head.py:380); in_scale fuses the guidance multiplies at
+ * fgn_ag_rpn_head.py:44 and fgn_roi_head.py:379.
+ *   x [n_img/a_img_div, H, W, Cin]   w_packed [cout_pad, KH, KW, Cin] (K padded to x32,
+ *   cout_pad multiple of 128, zero rows)   y [n_img, Ho, Wo, Cout]
+ *   scale/shift [Cout] or NULL; residual like y or NULL; in_scale [n_img, Cin] or NULL
+ *   Cin must be a multiple of 32, or exactly 4 (stem, NHWC4 input)
+ *   tile_hint 0 = auto, 1..4 = force a tile configuration (tests) */
+int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
+                        const float* shift, const float* residual, const float* in_scale,
+                        const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
+                        int cout_pad, int KH, int KW, int stride, int pad, int a_img_div, int relu,
+                        int tile_hint, void* stream);
+
+/* NCHW [n,3,H,W] -> NHWC4 [n,H,W,4] (input side of fgn.py:212,215) */
+int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, void* stream);
+
+/* 3x3/2 pad 1 max-pool of the ResNet stem */
+int fgn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n_img, int H, int W, int C, void* stream);
+
+/* RoIAlign (avg), rois [R,5] = (batch_idx,x1,y1,x2,y2), out [R,P,P,C].
+ * aligned=1,sampling_ratio=0 : mmcv.ops.RoIAlign (fgn_roi_head.py:331,366)
+ * aligned=0,sampling_ratio=-1: torchvision.ops.roi_align (fgn_roi_head.py:429,432) */
+int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, float* out, const int32_t* n_rois_dev,
+                           int n_rois, int n_img, int H, int W, int C, int out_size, float spatial_scale,
+                           int sampling_ratio, int aligned, void* stream);
+/* same for a single-channel uint8/bool map [n_img,H,W] -> [R,P,P] (support masks,
+ * fgn_roi_head.py:429) */
+int fgn_roi_align_mask_u8(const uint8_t* mask, const float* rois, float* out, int n_rois, int n_img, int H,
+                          int W, int out_size, float spatial_scale, int sampling_ratio, int aligned,
+                          void* stream);
+
+/* out[g][c] = mean_{k<K,p<P} x[g*K+k][p][c] * (weights ? weights[g*K+k][p] : 1)
+ * (fgn_ag_rpn_head.py:38-41 with weights=NULL; fgn_roi_head.py:444-447 with the pooled masks) */
+int fgn_support_class_vectors_f32(const float* x, const float* weights, float* out, int n_groups, int K,
+                                  int P, int C, void* stream);
+/* out[g][p][c] = mean_k x[g*K+k][p][c]   (fgn_roi_head.py:439-442) */
+int fgn_support_kmean_f32(const float* x, float* out, int n_groups, int K, int P, int C, void* stream);
+/* out[i][:] = table[labels[i] + n_ways*img(i)][:]  (fgn_roi_head.py:707-714); rois may be NULL (img 0) */
+int fgn_gather_support_vectors_f32(const float* table, const int64_t* labels, const float* rois, float* out,
+                                   const int32_t* n_dev, int n, int n_ways, int C, void* stream);
+
+/* Fused tail of count_one_roi_by_n_spp + BBoxHead.forward (fgn_roi_head.py:253-279,338):
+ * x = Q[r] + S[img*N+n]; GroupNorm(32)+ReLU; 7x7 avg-pool; fc_cls/fc_reg.
+ * Q [R,49,C], S [B*N,49,C] (bias included), fc_weight [6,C] (2 cls rows then 4 reg rows) */
+int fgn_relation_gn_head_f32(const float* Q, const float* S, const float* rois, const float* gn_weight,
+                             const float* gn_bias, const float* fc_weight, const float* fc_bias, float* cls_out,
+                             float* reg_out, const int32_t* n_rois_dev, int n_rois, int n_ways, int C,
+                             int gn_groups, int roi_size, float eps, void* stream);
+
+/* AG-RPN merge: per-anchor arg-max over the N guided passes (fgn_ag_rpn_head.py:81-113) + sigmoid.
+ * head [B*N,HW,head_channels]: channels [0,A) objectness, [A,5A) deltas. Outputs in (y,x,a) order. */
+int fgn_rpn_merge_f32(const float* head, float* logits, float* scores, float* deltas, int batch, int n_ways,
+                      int HW, int n_anchors, int head_channels, void* stream);
+
+/* Proposals (mmdet RPNHead._get_bboxes_single/_bbox_post_process via fgn.py:229-235):
+ * top nms_pre -> delta2bbox -> min size -> NMS -> max_per_img.  proposals [B,max_per_img,5],
+ * n_props [B]. scratch: fgn_rpn_proposals_scratch_bytes(). dbg_topk_idx optional [B,cap]. */
+size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre);
+int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float* base_anchors, void* scratch,
+                          float* proposals, int32_t* n_props, int32_t* dbg_topk_idx, int batch, int feat_h,
+                          int feat_w, int n_anchors, int stride, float img_h, float img_w,
+                          const float* host_means4, const float* host_stds4, float max_ratio, int nms_pre,
+                          float min_bbox_size, float iou_thr, int max_per_img, void* stream);
+
+/* count_modified_cls_bbox + BBoxHead.get_bboxes + multiclass_nms for one image
+ * (fgn_roi_head.py:302-326, 606-613). det_bboxes [max_per_img,5], det_labels int64 [max_per_img]. */
+size_t fgn_det_post_scratch_bytes(int max_rois, int n_ways);
+int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_raw, const int32_t* n_rois_dev,
+                     void* scratch, float* det_bboxes, int64_t* det_labels, int32_t* n_dets, float* dbg_scores,
+                     int n_rois, int n_ways, float img_h, float img_w, const float* host_means4,
+                     const float* host_stds4, float max_ratio, float score_thr, float iou_thr, int max_per_img,
+                     void* stream);
+
+/* conv_logits (1x1, one class) + sigmoid on the un-shuffled deconv output [D,P*P,4,C];
+ * logits/prob [D,2P,2P] (FCNMaskHead, fgn_roi_head.py:380; sigmoid of get_seg_masks) */
+int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logits, float* prob,
+                        const int32_t* n_dev, int n_det, int roi_size, int C, void* stream);
+
+/* _do_paste_mask + threshold (fgn_roi_head.py:668-671): out uint8 [D,H,W] */
+int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uint8_t* out, const int32_t* n_dev,
+                      int n_det, int img_h, int img_w, int mask_size, float thr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

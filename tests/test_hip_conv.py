@@ -1,0 +1,114 @@
+"""MFMA implicit-GEMM conv (fgn_conv2d_nhwc_f32) vs a plain PyTorch fp32 reference.
+Tolerance: fp32 accumulation-order differences only (rel 2e-5 of the output scale)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x_nchw, w, bias, bn, stride, pad, residual, relu, in_scale=None, a_img_div=1):
+    x = x_nchw.double()
+    if a_img_div > 1:
+        x = x.repeat_interleave(a_img_div, dim=0)
+    if in_scale is not None:
+        x = x * in_scale.double()[:, :, None, None]
+    y = F.conv2d(x, w.double(), None if bias is None else bias.double(), stride=stride, padding=pad)
+    if bn is not None:
+        y = F.batch_norm(y, bn['running_mean'].double(), bn['running_var'].double(), bn['weight'].double(),
+                         bn['bias'].double(), False, 0.0, 1e-5)
+    if residual is not None:
+        y = y + residual.double()
+    if relu:
+        y = F.relu(y)
+    return y.float()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad, bn, bias, residual, relu
+    (2, 64, 17, 23, 64, 1, 1, 0, True, False, False, True),
+    (2, 64, 17, 23, 256, 1, 1, 0, True, False, True, True),
+    (1, 128, 20, 31, 128, 3, 2, 1, True, False, False, True),
+    (3, 256, 7, 7, 128, 3, 1, 1, True, False, False, True),
+    (1, 256, 9, 13, 75, 1, 1, 0, False, True, False, False),
+    (2, 512, 8, 8, 1024, 1, 2, 0, True, False, False, False),
+    (1, 32, 40, 50, 32, 3, 1, 1, False, True, False, True),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+def test_conv_matches_torch(case, tile):
+    from fgn_amd import ops
+    n, cin, h, w, cout, k, stride, pad, use_bn, use_bias, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g) if use_bias else None
+    bn = None
+    if use_bn:
+        bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+                  running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    ref = _ref(x, wt, bias, bn, stride, pad, res, relu)
+    layer = ops.pack_conv(wt, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu).to('cuda')
+    y = ops.conv2d(_nhwc(x).cuda(), layer, residual=None if res is None else _nhwc(res).cuda(), tile_hint=tile)
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item() + 1e-6
+    assert (got - ref).abs().max().item() <= 2e-5 * scale + 1e-6
+
+
+def test_stem_conv_cin4():
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 37, 53, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    bn = dict(weight=torch.rand(64, generator=g) + 0.5, bias=torch.randn(64, generator=g) * 0.1,
+              running_mean=torch.randn(64, generator=g) * 0.1, running_var=torch.rand(64, generator=g) + 0.5)
+    ref = _ref(x, wt, None, bn, 2, 3, None, True)
+    layer = ops.pack_conv(wt, bn=bn, stride=2, pad=3, relu=True, pad_cin_to=4).to('cuda')
+    x4 = ops.nchw3_to_nhwc4(x.cuda())
+    assert torch.equal(x4[..., :3].cpu(), _nhwc(x)) and float(x4[..., 3].abs().max()) == 0.0
+    for tile in (0, 1, 3):
+        y = ops.conv2d(x4, layer, tile_hint=tile).cpu().permute(0, 3, 1, 2)
+        assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_input_scale_and_image_div_and_device_count():
+    """AG-RPN style launch: N guided passes share one input map; per-(image,cin) scale; and a
+    device-side image count that cuts the launch short."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, n_ways, cin, h, w, cout = 2, 3, 64, 9, 11, 96
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    bias = torch.randn(cout, generator=g)
+    vec = torch.rand(b * n_ways, cin, generator=g) + 0.5
+    ref = _ref(x, wt, bias, None, 1, 1, None, True, in_scale=vec, a_img_div=n_ways)
+    layer = ops.pack_conv(wt, bias=bias, pad=1, relu=True).to('cuda')
+    y = ops.conv2d(_nhwc(x).cuda(), layer, in_scale=vec.cuda(), a_img_div=n_ways)
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # device count: only the first 4 of 6 output images are produced
+    out = torch.full((b * n_ways, h, w, cout), -7.0, device='cuda')
+    cnt = torch.tensor([4], dtype=torch.int32, device='cuda')
+    ops.conv2d(_nhwc(x).cuda(), layer, in_scale=vec.cuda(), a_img_div=n_ways, n_img_dev=cnt, out=out)
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert (got[:4] - ref[:4]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert float((got[4:] + 7.0).abs().max()) == 0.0
+
+
+def test_bad_shapes_are_refused():
+    from fgn_amd import ops
+    from fgn_amd.lib import FgnHipError
+    layer = ops.pack_conv(torch.randn(8, 24, 1, 1)).to('cuda')      # Cin=24: not a multiple of 32
+    with pytest.raises(FgnHipError):
+        ops.conv2d(torch.randn(1, 4, 4, 24, device='cuda'), layer)
+    with pytest.raises(FgnHipError):
+        ops.conv2d(torch.randn(1, 4, 4, 24), layer)                    # CPU tensor: no fallback

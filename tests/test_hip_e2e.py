@@ -1,0 +1,65 @@
+"""End-to-end: FGN.simple_test on the HIP path vs the oracle on the same seeded episodes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _iou(a, b):
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
+
+
+def _run(cfg, batch):
+    from fgn_amd.detector import FGN
+    from fgn_amd.weights import init_state_dict
+    from oracle import fgn_ref_cpu as O
+    sd = init_state_dict(cfg, 0)
+    tr_ref = {}
+    ref = O.simple_test(sd, cfg, **batch, trace=tr_ref)
+    model = FGN(cfg['n_ways'], cfg['k_shots'], backbone=cfg['backbone'], rpn_head=cfg['rpn_head'],
+                roi_head=cfg['roi_head'], test_cfg=cfg['test_cfg'], state_dict=sd)
+    model.debug_trace = {}
+    got = model.simple_test(**batch, rescale=True)
+    return ref, tr_ref, got, model.debug_trace
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize('n_ways,k_shots,hw', [(3, 2, (160, 224)), (1, 1, (128, 128))])
+def test_e2e_half_width(n_ways, k_shots, hw):
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    cfg = tiny_config(n_ways, k_shots, width_div=2)
+    batch = make_batch(0, 2, n_ways, k_shots, hw[0], hw[1], 64)
+    ref, tr_ref, got, tr = _run(cfg, batch)
+    # feature maps: fp32 accumulation-order tolerance
+    for name in ('qry_fmap', 'spp_fmaps'):
+        r = tr_ref[name]
+        d = (_nchw(tr[name]) - r).abs().max().item()
+        assert d <= 1e-4 * r.abs().max().item(), (name, d)
+    d = (tr['spp_cat_mean_mp'].cpu().reshape(-1) - tr_ref['spp_cat_mean_mp'].reshape(-1)).abs().max().item()
+    assert d <= 1e-4 * tr_ref['spp_cat_mean_mp'].abs().max().item()
+    # detections: same count, boxes/scores within tolerance after matching, same labels
+    for i in range(2):
+        rb, gb = ref[i]['dt_bboxes'], got[i]['dt_bboxes']
+        assert got[i]['dt_bboxes'].dtype == np.float32 and got[i]['dt_cat_ids'].dtype == np.int64
+        assert abs(len(rb) - len(gb)) <= max(2, len(rb) // 20)
+        if len(rb) == 0:
+            continue
+        iou = _iou(rb[:, [1, 0, 3, 2]], gb[:, [1, 0, 3, 2]])
+        j = iou.argmax(1)
+        ok = (iou.max(1) > 0.98) & (ref[i]['dt_cat_ids'] == got[i]['dt_cat_ids'][j]) & \
+             (np.abs(ref[i]['dt_scores'] - got[i]['dt_scores'][j]) < 1e-3)
+        assert ok.mean() >= 0.9, ok.mean()
+        # passthrough keys
+        for key in ('idx', 'qry_bboxes', 'qry_cat_ids', 'qry_img_shape', 'spp_insts_ids'):
+            assert np.array_equal(np.asarray(ref[i][key]), np.asarray(got[i][key])), key
+        assert len(got[i]['dt_isegmaps_rle']) == len(gb)
+        assert got[i]['qry_isegmaps_rle'] == ref[i]['qry_isegmaps_rle']
