@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""FGN inference throughput on MI355X: query-images / s for full ``FGN.simple_test``.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: plain python)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic episode per GPU (cfg3 of
+BASELINE.json: COCO2VOC 3-way 3-shot, query 3x800x1333, 9 supports 3x256x256, seeded
+random-init ResNet-50-C4 FGN weights).  Inputs are resident in HBM before the timed
+region; the step includes everything the reference's ``simple_test`` does, up to and
+including the device->host copy of the detections and COCO-RLE packing of the masks.
+Episodes are independent, so N GPUs run N episodes per step (weak scaling) and the
+per-step detections are gathered to every rank with one RCCL all-gather of fixed-size
+padded buffers.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def algorithmic_gflop(cfg, H, W, S, R, D):
+    """Reference-formulation FLOPs per episode, 2 x MAC."""
+    N, K = cfg['n_ways'], cfg['k_shots']
+
+    def c4(h, w):
+        mac = 0
+        ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        mac += ho * wo * 64 * 3 * 49
+        ho, wo = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+        cin = 64
+        for nblk, planes, stride in zip((3, 4, 6), (64, 128, 256), (1, 2, 2)):
+            for b in range(nblk):
+                s = stride if b == 0 else 1
+                mac += ho * wo * cin * planes
+                ho2, wo2 = (ho - 1) // s + 1, (wo - 1) // s + 1
+                mac += ho2 * wo2 * planes * planes * 9 + ho2 * wo2 * planes * planes * 4
+                if b == 0:
+                    mac += ho2 * wo2 * cin * planes * 4
+                ho, wo, cin = ho2, wo2, planes * 4
+        return mac, ho, wo
+    cq, h, w = c4(H, W)
+    cs, _, _ = c4(S, S)
+    sh = 3 * (2 * 1024 * 512 + 9 * 512 * 512) * 49
+    mh = 49 * 9 * (1024 * 256 + 3 * 256 * 256) + 49 * 4 * 256 * 256 + 196 * 256
+    mac = cq + N * K * cs + N * h * w * (9 * 1024 * 1024 + 75 * 1024) + (N * K + R + D) * sh + \
+        R * N * 49 * 2048 * 1024 + R * N * 6 * 1024 + D * mh
+    return 2 * mac / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='cfg3')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-episodes', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from fgn_amd import ops
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import CONFIGS, make_batch
+    from fgn_amd.weights import init_state_dict
+
+    shape = CONFIGS[args.workload]
+    cfg = fgn_r50_c4_config(shape['n_ways'], shape['k_shots'])
+    sd = init_state_dict(cfg, 0)
+    model = FGN(cfg['n_ways'], cfg['k_shots'], state_dict=sd)
+
+    # distinct seeded episodes per rank, inputs resident in HBM before timing
+    n_distinct = 4
+    episodes = []
+    for j in range(n_distinct):
+        b = make_batch(rank * n_distinct + j, 1, **shape)
+        episodes.append({k: (v.to(dev) if isinstance(v, torch.Tensor) else
+                             [t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in b.items()})
+    for e in episodes:
+        e['img_shape'] = e['img_shape'].cpu()     # shape metadata is host data in the reference too
+
+    max_det = cfg['test_cfg']['rcnn']['max_per_img']
+    gather_buf = torch.zeros((world, max_det, 6), device=dev) if world > 1 else None
+
+    def step(i, profile=None):
+        e = episodes[i % n_distinct]
+        ops.PROFILE = profile
+        dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'])
+        ops.PROFILE = None
+        if world > 1:
+            d = dets[0]
+            mine = torch.cat([d['det_bboxes'], d['det_labels'].float()[:, None]], 1)
+            dist.all_gather_into_tensor(gather_buf, mine.contiguous())
+        res = model.pack_results(dets, 1, qry_bboxes=e['qry_bboxes'], qry_cat_ids=e['qry_cat_ids'],
+                                 qry_isegmaps=None, img_shape=e['img_shape'], idx=e['idx'])
+        return res
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = []
+    n_r = n_d = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i, prof)
+        n_d += len(res[0]['dt_scores'])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
+    conv_ms = 0.0
+    conv_flop = 0.0
+    for (e0, e1, flop_per_img, n_img, n_img_dev) in prof:
+        conv_ms += e0.elapsed_time(e1)
+        n = n_img if n_img_dev is None else min(n_img, int(n_img_dev.item()))
+        conv_flop += flop_per_img * n
+    n_launch = max(len(prof), 1)
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+
+    if rank == 0:
+        R = cfg['test_cfg']['rpn']['max_per_img']
+        gflop = algorithmic_gflop(cfg, shape['height'], shape['width'], shape['spp_size'], R, n_d / args.steps)
+        out = {
+            'metric': 'query-imgs/sec (3-way 3-shot, 800x1333 FGN simple_test)',
+            'value': world * args.steps / dt,
+            'unit': 'img/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: COCO2VOC {shape["n_ways"]}-way {shape["k_shots"]}-shot, '
+                                   f'query 3x{shape["height"]}x{shape["width"]}, supports '
+                                   f'{shape["n_ways"] * shape["k_shots"]}x3x{shape["spp_size"]}^2, ResNet-50-C4, '
+                                   f'R<={R} proposals, D<={max_det} detections, 1 episode per GPU per step',
+                       'avg_detections': n_d / args.steps,
+                       'algorithmic_gflop_per_episode': round(gflop, 1),
+                       'algorithmic_tflops': round(gflop * world * args.steps / dt / 1e3, 2)},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all instances)',
+                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'launches_per_step': n_launch / args.steps,
+                         'avg_launch_us': round(conv_ms * 1e3 / n_launch, 2),
+                         'conv_ms_per_step': round(conv_ms / args.steps, 3),
+                         'executed_conv_gflop_per_step': round(conv_flop / args.steps / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import fgn_ref_cpu as O
+            cpu_eps = [make_batch(j, 1, **shape) for j in range(args.cpu_episodes)]
+            O.simple_test(sd, cfg, **cpu_eps[0])          # warm-up
+            t0 = time.perf_counter()
+            for b in cpu_eps:
+                O.simple_test(sd, cfg, **b)
+            cdt = time.perf_counter() - t0
+            out['cpu_baseline'] = {'value': args.cpu_episodes / cdt, 'unit': 'img/s',
+                                   'cores': torch.get_num_threads(), 'kind': 'port',
+                                   'sample': f'{args.cpu_episodes} {args.workload} episodes (after 1 warm-up) through '
+                                             'oracle/fgn_ref_cpu.py (PyTorch fp32 CPU restatement)'}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

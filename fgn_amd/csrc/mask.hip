@@ -60,18 +60,48 @@ extern "C" int fgn_mask_logits_f32(const float* x, const float* w, float bias, f
 // (_do_paste_mask with skip_empty=True, one mask per chunk).  grid_sample semantics:
 // align_corners=False, zero padding.  HBM-bound: D*H*W bytes written, 4 pixels per lane.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ float paste_sample(const float* __restrict__ m, int MS, float gx, float gy) {
-    // unnormalise: ((g + 1) * size - 1) / 2
-    const float ix = ((gx + 1.f) * (float)MS - 1.f) / 2.f;
-    const float iy = ((gy + 1.f) * (float)MS - 1.f) / 2.f;
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    const float wx1 = ix - fx, wx0 = 1.f - wx1;
-    const float wy1 = iy - fy, wy0 = 1.f - wy1;
-    auto at = [&](int yy, int xx) -> float {
-        return ((unsigned)yy < (unsigned)MS && (unsigned)xx < (unsigned)MS) ? m[yy * MS + xx] : 0.f;
-    };
-    return at(y0, x0) * (wx0 * wy0) + at(y0, x1) * (wx1 * wy0) + at(y1, x0) * (wx0 * wy1) + at(y1, x1) * (wx1 * wy1);
+// One mask sample, separable form shared by the dense paste kernel and the RLE kernel (so both
+// produce the same bits): horizontal lerp of the two neighbouring mask rows, then vertical lerp.
+// grid_sample semantics: pixel = ((g + 1) * size - 1) / 2, bilinear, zeros outside the map.
+struct PasteBox {
+    float bx0, by0, bx1, by1;
+    int x0i, y0i, x1i, y1i;   // integer-expanded region [x0i,x1i) x [y0i,y1i)
+};
+__device__ __forceinline__ PasteBox make_paste_box(const float* b, int H, int W) {
+    PasteBox p;
+    p.bx0 = b[0]; p.by0 = b[1]; p.bx1 = b[2]; p.by1 = b[3];
+    p.x0i = max((int)floorf(p.bx0) - 1, 0);
+    p.y0i = max((int)floorf(p.by0) - 1, 0);
+    p.x1i = min((int)ceilf(p.bx1) + 1, W);
+    p.y1i = min((int)ceilf(p.by1) + 1, H);
+    return p;
+}
+struct AxisLerp {
+    int lo;        // low index (may be -1 .. MS-1); high = lo + 1
+    float w_hi;    // weight of the high neighbour; low weight = 1 - w_hi
+};
+__device__ __forceinline__ AxisLerp paste_axis(int pix, float b0, float b1, int MS) {
+    float g = ((float)pix + 0.5f - b0) / (b1 - b0) * 2.f - 1.f;
+    if (isinf(g)) g = 0.f;
+    const float c = ((g + 1.f) * (float)MS - 1.f) / 2.f;
+    const float f = floorf(c);
+    AxisLerp a;
+    // clamp far-outside coordinates so the int conversion is defined; they contribute 0 anyway
+    a.lo = (int)fminf(fmaxf(f, -2.f), (float)MS);
+    a.w_hi = c - f;
+    return a;
+}
+__device__ __forceinline__ float paste_row_lerp(const float* __restrict__ m, int MS, int row, const AxisLerp& ax) {
+    if ((unsigned)row >= (unsigned)MS) return 0.f;
+    const float v0 = ((unsigned)ax.lo < (unsigned)MS) ? m[row * MS + ax.lo] : 0.f;
+    const float v1 = ((unsigned)(ax.lo + 1) < (unsigned)MS) ? m[row * MS + ax.lo + 1] : 0.f;
+    return v0 * (1.f - ax.w_hi) + v1 * ax.w_hi;
+}
+__device__ __forceinline__ float paste_value(const float* __restrict__ m, int MS, const AxisLerp& ax,
+                                             const AxisLerp& ay) {
+    const float r0 = paste_row_lerp(m, MS, ay.lo, ax);
+    const float r1 = paste_row_lerp(m, MS, ay.lo + 1, ax);
+    return r0 * (1.f - ay.w_hi) + r1 * ay.w_hi;
 }
 
 __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict__ prob,
@@ -94,17 +124,11 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict
             if (d >= D) continue;
             const int rem = (int)(i - (long long)d * HW);
             const int y = rem / W, x = rem - y * W;
-            const float* b = boxes + (size_t)d * box_stride;
-            const float bx0 = b[0], by0 = b[1], bx1 = b[2], by1 = b[3];
-            const int x0i = max((int)floorf(bx0) - 1, 0), y0i = max((int)floorf(by0) - 1, 0);
-            const int x1i = min((int)ceilf(bx1) + 1, W), y1i = min((int)ceilf(by1) + 1, H);
-            if (x < x0i || x >= x1i || y < y0i || y >= y1i) continue;
-            float gx = ((float)x + 0.5f - bx0) / (bx1 - bx0) * 2.f - 1.f;
-            float gy = ((float)y + 0.5f - by0) / (by1 - by0) * 2.f - 1.f;
-            if (isinf(gx)) gx = 0.f;
-            if (isinf(gy)) gy = 0.f;
-            const float v = paste_sample(prob + (size_t)d * MS * MS, MS, gx, gy);
-            if (v >= thr) packed |= 1u << (8 * k);
+            const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W);
+            if (x < pb.x0i || x >= pb.x1i || y < pb.y0i || y >= pb.y1i) continue;
+            const AxisLerp ax = paste_axis(x, pb.bx0, pb.bx1, MS);
+            const AxisLerp ay = paste_axis(y, pb.by0, pb.by1, MS);
+            if (paste_value(prob + (size_t)d * MS * MS, MS, ax, ay) >= thr) packed |= 1u << (8 * k);
         }
         if ((q + 1) * 4 <= (long long)n_det * HW) {
             reinterpret_cast<uint32_t*>(out)[q] = packed;
@@ -123,6 +147,183 @@ extern "C" int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_
     const int grid = (int)std::min<long long>((total4 + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(mask_paste_kernel, dim3(grid), dim3(256), 0, stream, prob, boxes, box_stride, out, n_dev,
                        n_det, img_h, img_w, mask_size, thr);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// paste + threshold + COCO RLE, fused: the D x H x W masks are never materialised.
+// Replaces get_seg_masks -> .cpu().numpy() -> pycocotools encode (fgn_roi_head.py:668-671,
+// fgn.py:267,281): instead of writing D*H*W bytes, copying them over PCIe and run-length
+// encoding on a host core, one workgroup per detection
+//   1. counts the value transitions of every image column inside the pasted box
+//      (column-major = pycocotools' Fortran order), one thread per column,
+//   2. block-scans the counts and writes the transition positions in order,
+//   3. turns positions into run lengths, delta-codes them against the run two back and
+//      emits the COCO 5-bit/continuation ASCII string, again through a block scan.
+// Only the strings (a few hundred bytes per detection) cross PCIe.
+// Overflow of either cap sets overflow[d]; the host then falls back to the dense kernel for
+// that detection, so results never depend on the caps.
+// ----------------------------------------------------------------------------------------------
+constexpr int RLE_THREADS = 1024;
+
+__device__ inline int block_exclusive_scan(int v, int* wave_sums, int* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    __syncthreads();   // protects wave_sums reuse across calls
+    if (lane == 63) wave_sums[wv] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < RLE_THREADS / 64; ++w) {
+        const int s = wave_sums[w];
+        if (w < wv) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ int rle_char_count(long long x) {
+    int n = 0;
+    bool more = true;
+    while (more) {
+        const int c = (int)(x & 0x1f);
+        x >>= 5;
+        more = (c & 0x10) ? (x != -1) : (x != 0);
+        ++n;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
+    const float* __restrict__ prob, const float* __restrict__ boxes, int box_stride, uint32_t* __restrict__ trans,
+    uint8_t* __restrict__ out_bytes, int32_t* __restrict__ out_len, int32_t* __restrict__ overflow,
+    const int32_t* __restrict__ n_dev, int n_det, int H, int W, int MS, float thr, int trans_cap, int byte_cap) {
+    __shared__ float m[32 * 32];
+    __shared__ int wave_sums[RLE_THREADS / 64];
+    const int d = blockIdx.x, t = threadIdx.x;
+    int D = n_det;
+    if (n_dev) D = min(D, *n_dev);
+    if (d >= D) {
+        if (t == 0) { out_len[d] = 0; overflow[d] = 0; }
+        return;
+    }
+    for (int i = t; i < MS * MS; i += RLE_THREADS) m[i] = prob[(size_t)d * MS * MS + i];
+    __syncthreads();
+    const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W);
+    // columns x0i .. min(x1i, W-1): one past the region closes a run that wraps a full-height column
+    const int xs = pb.x0i, xe = min(pb.x1i, W - 1);
+    const int ncols = max(xe - xs + 1, 0);
+    const int cpt = (ncols + RLE_THREADS - 1) / RLE_THREADS;   // contiguous columns per thread
+    // one row past the region closes a run; a region touching the bottom edge wraps into the next
+    // column's row 0, so such columns are scanned from row 0
+    const int ys = (pb.y1i >= H) ? 0 : pb.y0i, ye = min(pb.y1i, H - 1);
+
+    auto value_at = [&](int x, int y, const AxisLerp& ax) -> int {
+        if (x < pb.x0i || x >= pb.x1i || y < pb.y0i || y >= pb.y1i) return 0;
+        const AxisLerp ay = paste_axis(y, pb.by0, pb.by1, MS);
+        return paste_value(m, MS, ax, ay) >= thr ? 1 : 0;
+    };
+    auto scan_column = [&](int x, uint32_t* dst) -> int {   // dst == nullptr: count only
+        const AxisLerp ax = paste_axis(x, pb.bx0, pb.bx1, MS);
+        int prev = 0;
+        if (ys == 0 && x > 0) {
+            const AxisLerp axp = paste_axis(x - 1, pb.bx0, pb.bx1, MS);
+            prev = value_at(x - 1, H - 1, axp);
+        }
+        int n = 0;
+        for (int y = ys; y <= ye; ++y) {
+            const int v = value_at(x, y, ax);
+            if (v != prev) {
+                if (dst) dst[n] = (uint32_t)x * (uint32_t)H + (uint32_t)y;
+                ++n;
+                prev = v;
+            }
+        }
+        return n;
+    };
+
+    // ---- 1. count transitions per thread (contiguous columns) -------------------------------
+    int cnt = 0;
+    for (int j = 0; j < cpt; ++j) {
+        const int c = t * cpt + j;
+        if (c < ncols) cnt += scan_column(xs + c, nullptr);
+    }
+    int T;
+    const int off = block_exclusive_scan(cnt, wave_sums, &T);
+    if (T > trans_cap) {
+        if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
+        return;
+    }
+    // ---- 2. write positions in order ----------------------------------------------------------
+    uint32_t* tr = trans + (size_t)d * trans_cap;
+    {
+        int o = off;
+        for (int j = 0; j < cpt; ++j) {
+            const int c = t * cpt + j;
+            if (c < ncols) o += scan_column(xs + c, tr + o);
+        }
+    }
+    __syncthreads();
+    // ---- 3. run lengths -> COCO string ---------------------------------------------------------
+    const long long HWl = (long long)H * W;
+    auto run_len = [&](int i) -> long long {   // i in [0, T]
+        const long long hi = (i < T) ? (long long)tr[i] : HWl;
+        const long long lo = (i > 0) ? (long long)tr[i - 1] : 0;
+        return hi - lo;
+    };
+    const int n_runs = T + 1;
+    const int rpt = (n_runs + RLE_THREADS - 1) / RLE_THREADS;
+    int nchar = 0;
+    for (int j = 0; j < rpt; ++j) {
+        const int i = t * rpt + j;
+        if (i < n_runs) {
+            long long x = run_len(i);
+            if (i > 2) x -= run_len(i - 2);
+            nchar += rle_char_count(x);
+        }
+    }
+    int total_chars;
+    int o = block_exclusive_scan(nchar, wave_sums, &total_chars);
+    if (total_chars > byte_cap) {
+        if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
+        return;
+    }
+    uint8_t* ob = out_bytes + (size_t)d * byte_cap;
+    for (int j = 0; j < rpt; ++j) {
+        const int i = t * rpt + j;
+        if (i < n_runs) {
+            long long x = run_len(i);
+            if (i > 2) x -= run_len(i - 2);
+            bool more = true;
+            while (more) {
+                int c = (int)(x & 0x1f);
+                x >>= 5;
+                more = (c & 0x10) ? (x != -1) : (x != 0);
+                if (more) c |= 0x20;
+                ob[o++] = (uint8_t)(c + 48);
+            }
+        }
+    }
+    if (t == 0) { out_len[d] = total_chars; overflow[d] = 0; }
+}
+
+extern "C" int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
+                            uint8_t* out_bytes, int32_t* out_len, int32_t* overflow, const int32_t* n_dev,
+                            int n_det, int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap,
+                            hipStream_t stream) {
+    if (!prob || !boxes || !trans_scratch || !out_bytes || !out_len || !overflow) return FGN_ERR_ARG;
+    if (mask_size > 32 || mask_size < 1 || trans_cap < 1 || byte_cap < 8) return FGN_ERR_SHAPE;
+    if ((long long)img_h * img_w >= (1ll << 32)) return FGN_ERR_SHAPE;
+    if (n_det == 0) return FGN_OK;
+    hipLaunchKernelGGL(mask_rle_kernel, dim3(n_det), dim3(RLE_THREADS), 0, stream, prob, boxes, box_stride,
+                       trans_scratch, out_bytes, out_len, overflow, n_dev, n_det, img_h, img_w, mask_size, thr,
+                       trans_cap, byte_cap);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -341,12 +341,15 @@ class FGN(torch.nn.Module):
                 m = ops.conv2d(m, layer, n_img_dev=n_det)
             up = ops.conv2d(m, P['upsample'], n_img_dev=n_det)                   # [D,7,7,4*C']
             mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, n_det)
-            masks = ops.mask_paste(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+            # paste + threshold + COCO RLE fused on device: the D x H x W masks are never written
+            rle_bytes, rle_len, rle_ovf = ops.mask_rle(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
             if tr is not None:
+                masks = ops.mask_paste(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
                 tr.setdefault('per_image', []).append(dict(
                     rois=rois, roi_feats=feats, Q=Q, cls_raw=cls_raw, reg_raw=reg_raw, det=det, lab=lab,
                     n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
-            outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, masks=masks))
+            outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mprob, rle_bytes=rle_bytes,
+                             rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
         return outs
 
     def pack_results(self, dets: list, batch: int, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None,
@@ -361,11 +364,24 @@ class FGN(torch.nn.Module):
         results = []
         for i in range(batch):
             n = int(counts[i])
-            db = dets[i]['det_bboxes'][:n].cpu().numpy()
+            di = dets[i]
+            db = di['det_bboxes'][:n].cpu().numpy()
+            lens = di['rle_len'][:n].cpu().numpy()
+            ovf = di['rle_overflow'][:n].cpu().numpy()
+            ih, iw = di['img_hw']
+            width = int(lens.max()) if n else 0
+            strings = di['rle_bytes'][:n, :width].cpu().numpy() if width else np.zeros((n, 0), np.uint8)
+            rles = [{'size': [ih, iw], 'counts': strings[j, :lens[j]].tobytes()} for j in range(n)]
+            if n and ovf.any():     # a device cap overflowed: dense paste + host RLE for those masks only
+                thr = self.cfg['test_cfg']['rcnn']['mask_thr_binary']
+                for j in np.flatnonzero(ovf):
+                    dense = ops.mask_paste(di['mask_prob'][j:j + 1].contiguous(),
+                                           di['det_bboxes'][j:j + 1].contiguous(), ih, iw, thr)
+                    rles[j] = rle.encode(dense[0].cpu().numpy())
             one = {'dt_scores': db[:, 4].reshape(-1).copy(),
                    'dt_bboxes': db[:, [1, 0, 3, 2]].reshape(-1, 4).copy(),
-                   'dt_cat_ids': dets[i]['det_labels'][:n].cpu().numpy().reshape(-1),
-                   'dt_isegmaps_rle': rle.encode_many(dets[i]['masks'][:n].cpu().numpy())}
+                   'dt_cat_ids': di['det_labels'][:n].cpu().numpy().reshape(-1),
+                   'dt_isegmaps_rle': rles}
             for key, val in passthrough.items():
                 v = val[i] if val is not None else None
                 one[key] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v

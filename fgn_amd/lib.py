@@ -35,6 +35,7 @@ SIGNATURES = {
     'fgn_det_post_f32': (_i, [_p] * 9 + [_i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f), _f, _f, _f, _i, _p]),
     'fgn_mask_logits_f32': (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
     'fgn_mask_paste_u8': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
+    'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
 }
 
 ABI_VERSION = 1
@@ -50,6 +51,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the process's HIP runtime (it owns
+    # the device memory and streams we are handed), so import torch BEFORE dlopen: our
+    # NEEDED libamdhip64.so.7 then resolves to the copy torch already loaded.  Loading ours
+    # first leaves two runtimes in the process and every launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise FgnHipError(
             f'{LIB_PATH} is missing: build it with `python -m fgn_amd.build` '

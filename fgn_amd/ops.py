@@ -18,6 +18,11 @@ import torch
 from . import lib as _lib
 
 
+# When set to a list, conv2d appends (start_event, end_event, flop_per_image, n_img,
+# n_img_dev) per launch: live HIP-event timing of the dominant kernel (bench.py roofline).
+PROFILE = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -124,11 +129,18 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
             raise _lib.FgnHipError(f'conv2d: in_scale must be [{n_img},{cin}], got {tuple(in_scale.shape)}')
     if n_img_dev is not None:
         _chk(n_img_dev, 'n_img_dev', torch.int32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.load().fgn_conv2d_nhwc_f32(
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
         layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * cin, n_img, n_img_dev))
     return out
 
 
@@ -367,3 +379,28 @@ def mask_paste(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, 
                                        img_w, m, float(thr), _stream())
     _lib.check(rc, 'fgn_mask_paste_u8')
     return out
+
+
+RLE_TRANS_CAP = 16384     # transitions per detection kept on device
+RLE_BYTE_CAP = 32768      # COCO string bytes per detection
+
+
+def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,
+             n_dev: Optional[torch.Tensor] = None):
+    """Fused paste + threshold + COCO RLE.  Returns (bytes [D,RLE_BYTE_CAP] u8, lens [D] i32,
+    overflow [D] i32), all on device."""
+    _chk(prob, 'prob')
+    _chk(boxes, 'boxes')
+    d, m, _ = prob.shape
+    if boxes.shape[0] != d or boxes.shape[1] < 4:
+        raise _lib.FgnHipError('mask_rle: boxes shape mismatch')
+    dev = prob.device
+    scratch = torch.empty((d, RLE_TRANS_CAP), device=dev, dtype=torch.int32)
+    out = torch.empty((d, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
+    lens = torch.zeros((d,), device=dev, dtype=torch.int32)
+    ovf = torch.zeros((d,), device=dev, dtype=torch.int32)
+    rc = _lib.load().fgn_mask_rle(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(scratch), _ptr(out), _ptr(lens),
+                                  _ptr(ovf), _ptr(n_dev), d, img_h, img_w, m, float(thr), RLE_TRANS_CAP,
+                                  RLE_BYTE_CAP, _stream())
+    _lib.check(rc, 'fgn_mask_rle')
+    return out, lens, ovf

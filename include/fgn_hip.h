@@ -120,6 +120,14 @@ int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logit
 int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uint8_t* out, const int32_t* n_dev,
                       int n_det, int img_h, int img_w, int mask_size, float thr, void* stream);
 
+/* Fused paste + threshold + COCO RLE (replaces get_seg_masks -> .cpu() -> pycocotools encode,
+ * fgn_roi_head.py:668-671 + fgn.py:267,281): out_bytes [D,byte_cap] holds the COCO "counts"
+ * string of detection d in its first out_len[d] bytes.  trans_scratch uint32 [D,trans_cap].
+ * overflow[d] != 0: a cap was too small, use fgn_mask_paste_u8 + host RLE for that detection. */
+int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
+                 uint8_t* out_bytes, int32_t* out_len, int32_t* overflow, const int32_t* n_dev, int n_det,
+                 int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

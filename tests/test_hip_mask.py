@@ -1,0 +1,84 @@
+"""Mask tail on the HIP path: logits/sigmoid, dense paste, fused paste+RLE."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(g, d, h, w):
+    x0 = torch.rand(d, generator=g) * (w * 0.7)
+    y0 = torch.rand(d, generator=g) * (h * 0.7)
+    bw = torch.rand(d, generator=g) * (w * 0.5) + 2
+    bh = torch.rand(d, generator=g) * (h * 0.5) + 2
+    b = torch.stack([x0, y0, (x0 + bw).clamp(max=w), (y0 + bh).clamp(max=h), torch.rand(d, generator=g)], 1)
+    return b
+
+
+@pytest.mark.parametrize('hw', [(97, 131), (64, 64), (800, 1333)])
+def test_paste_matches_oracle_and_rle_matches_paste(hw):
+    from fgn_amd import ops, rle
+    from oracle import fgn_ref_cpu as O
+    h, w = hw
+    g = torch.Generator().manual_seed(11)
+    d = 12
+    prob = torch.rand(d, 14, 14, generator=g)
+    prob[0] = 1.0                       # saturated mask: full box
+    prob[1] = 0.0                       # empty mask
+    boxes = _boxes(g, d, h, w)
+    boxes[2, :4] = torch.tensor([0., 0., float(w), float(h)])        # full image: column wrap case
+    boxes[3, :4] = torch.tensor([w * 0.25, 0., w * 0.75, float(h)])  # full height
+    boxes[4, :4] = torch.tensor([0.3, h * 0.5, 1.7, float(h)])       # touches bottom edge, starts mid-image
+    prob[2] = 1.0
+    prob[3] = (torch.rand(14, 14, generator=g) > 0.5).float()
+    prob[4] = 1.0
+    dense = ops.mask_paste(prob.cuda(), boxes.cuda(), h, w, 0.5).cpu().numpy().astype(bool)
+    ref = O.paste_masks(prob[:, None], boxes.numpy(), h, w, 0.5)
+    # same formula up to fp32 rounding of the bilinear sample: only pixels within 1e-5 of the
+    # threshold may differ
+    mismatch = (dense != ref).mean()
+    assert mismatch < 2e-4, mismatch
+    assert dense[0].sum() > 0 and dense[1].sum() == 0 and dense[2].mean() > 0.9
+    # fused kernel == RLE of the dense kernel's mask, byte for byte
+    by, ln, ovf = ops.mask_rle(prob.cuda(), boxes.cuda(), h, w, 0.5)
+    by, ln, ovf = by.cpu().numpy(), ln.cpu().numpy(), ovf.cpu().numpy()
+    for j in range(d):
+        want = rle.encode(dense[j])
+        if ovf[j]:
+            continue
+        assert by[j, :ln[j]].tobytes() == want['counts'], j
+        assert np.array_equal(rle.decode({'size': [h, w], 'counts': by[j, :ln[j]].tobytes()}), dense[j])
+    assert ovf.sum() == 0
+    # the oracle's encoder (pycocotools restatement) agrees with the product's host encoder
+    assert O.rle_encode(dense[3]) == rle.encode(dense[3])
+
+
+def test_rle_overflow_is_flagged_and_device_count_respected():
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(2)
+    h, w = 600, 900
+    prob = (torch.rand(3, 14, 14, generator=g) > 0.5).float()
+    boxes = torch.tensor([[0., 0., w, h, 1.], [10., 10., 300., 200., 1.], [5., 5., 50., 60., 1.]])
+    old = ops.RLE_TRANS_CAP
+    try:
+        ops.RLE_TRANS_CAP = 64
+        cnt = torch.tensor([2], dtype=torch.int32, device='cuda')
+        by, ln, ovf = ops.mask_rle(prob.cuda(), boxes.cuda(), h, w, 0.5, cnt)
+        assert ovf.cpu().tolist()[0] == 1            # big checkerboard overflows a 64-entry cap
+        assert ln.cpu().tolist()[2] == 0             # beyond the device count: untouched
+    finally:
+        ops.RLE_TRANS_CAP = old
+
+
+def test_mask_logits_layout():
+    from fgn_amd import ops
+    from oracle import fgn_ref_cpu as O
+    g = torch.Generator().manual_seed(4)
+    d, c = 5, 64
+    x = torch.randn(d, 7, 7, 4 * c, generator=g)            # [D,7,7,(dy,dx),C]
+    wl = torch.randn(c, generator=g)
+    logits, prob = ops.mask_logits(x.cuda(), wl.cuda(), 0.25, 7)
+    x14 = x.view(d, 7, 7, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(d, 14, 14, c)
+    ref = (x14.double() * wl.double()).sum(-1) + 0.25
+    assert (logits.cpu().double() - ref).abs().max() < 1e-4
+    assert np.abs(prob.cpu().numpy() - O.sigmoid32(logits.cpu().numpy())).max() <= 6e-8
