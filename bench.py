@@ -143,7 +143,7 @@ def main():
     # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
     conv_ms = 0.0
     conv_flop = 0.0
-    for (e0, e1, flop_per_img, n_img, n_img_dev) in prof:
+    for (e0, e1, flop_per_img, n_img, n_img_dev, _shape) in prof:
         conv_ms += e0.elapsed_time(e1)
         n = n_img if n_img_dev is None else min(n_img, int(n_img_dev.item()))
         conv_flop += flop_per_img * n

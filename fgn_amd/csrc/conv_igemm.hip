@@ -46,8 +46,95 @@ struct ConvParams {
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats
 
-template <int BM, int BN, int WM, int WN, bool CIN4, bool IN_SCALE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+// Per-thread staging state: which rows of the A tile this thread loads (fixed for the whole
+// K loop) and where they start in the input image.
+template <int A_LD>
+struct AStage {
+    const float* base[A_LD];
+    const float* sbase[A_LD];
+    int iy0[A_LD], ix0[A_LD];
+};
+
+// Register staging buffers are ext_vector SSA values (not arrays): hipcc leaves float4 arrays
+// that cross a scheduling fence in scratch memory, which serialises every load.
+template <int N>
+struct Pack {
+    typedef float type __attribute__((ext_vector_type(N)));
+};
+#define PACK_SET4(pk, i, v)      \
+    do {                         \
+        (pk)[4 * (i) + 0] = (v).x; \
+        (pk)[4 * (i) + 1] = (v).y; \
+        (pk)[4 * (i) + 2] = (v).z; \
+        (pk)[4 * (i) + 3] = (v).w; \
+    } while (0)
+#define PACK_GET4(pk, i) make_float4((pk)[4 * (i)], (pk)[4 * (i) + 1], (pk)[4 * (i) + 2], (pk)[4 * (i) + 3])
+
+// Issue the global loads of one K-tile.  Nothing here consumes a loaded value: zero-fill of
+// out-of-image taps and the input-scale multiply happen in finish_tile(), after the MFMA block,
+// so the compiler places its s_waitcnt there and the loads fly under the MFMAs.
+template <int A_LD, int B_LD, bool CIN4, bool IN_SCALE>
+__device__ __forceinline__ unsigned load_tile(const ConvParams& p, const AStage<A_LD>& st, const float* b_base,
+                                              int kt, int cin_tiles, int col4,
+                                              typename Pack<4 * A_LD>::type& a_reg,
+                                              typename Pack<4 * A_LD>::type& s_reg,
+                                              typename Pack<4 * B_LD>::type& b_reg) {
+    unsigned ok_mask = 0;
+    if (CIN4) {
+        // Cin == 4: one float4 is one filter tap; 8 taps per K-tile.
+        const int tap = kt * 8 + col4;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const bool tap_ok = tap < p.KH * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = st.iy0[i] + ky, ix = st.ix0[i] + kx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = ok ? (iy * p.W + ix) * 4 : 0;   // invalid taps read a valid dummy address
+            const float4 v = *reinterpret_cast<const float4*>(st.base[i] + off);
+            PACK_SET4(a_reg, i, v);
+            ok_mask |= ok ? (1u << i) : 0u;
+        }
+    } else {
+        const int tap = kt / cin_tiles;
+        const int c0 = (kt - tap * cin_tiles) * BK + col4 * 4;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = st.iy0[i] + ky, ix = st.ix0[i] + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = ok ? (iy * p.W + ix) * p.Cin + c0 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(st.base[i] + off);
+            PACK_SET4(a_reg, i, v);
+            if (IN_SCALE) {
+                const float4 sv = *reinterpret_cast<const float4*>(st.sbase[i] + c0);
+                PACK_SET4(s_reg, i, sv);
+            }
+            ok_mask |= ok ? (1u << i) : 0u;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(b_base + (size_t)(32 * i) * p.K + kt * BK);
+        PACK_SET4(b_reg, i, v);
+    }
+    return ok_mask;
+}
+
+template <int A_LD, bool IN_SCALE>
+__device__ __forceinline__ void finish_tile(unsigned ok_mask, typename Pack<4 * A_LD>::type& a_reg,
+                                            const typename Pack<4 * A_LD>::type& s_reg) {
+    if (IN_SCALE) a_reg *= s_reg;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        if (!(ok_mask & (1u << i))) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            PACK_SET4(a_reg, i, z);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN4, bool IN_SCALE, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvParams p) {
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -85,9 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // ---- per-thread staging coordinates (fixed across the K loop) ---------------
     const int col4 = t & 7;    // which float4 of the 32-float K-tile row
     const int row0 = t >> 3;   // 0..31, rows row0 + 32*i
-    const float* a_base[A_LD];
-    const float* s_base[A_LD];
-    int iy0[A_LD], ix0[A_LD];
+    AStage<A_LD> st;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + row0 + 32 * i;
@@ -96,15 +181,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int rem = m - img * HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
-            iy0[i] = oy * p.stride - p.pad;
-            ix0[i] = ox * p.stride - p.pad;
-            a_base[i] = p.x + (size_t)(img / p.a_img_div) * p.H * p.W * p.Cin;
-            s_base[i] = IN_SCALE ? p.in_scale + (size_t)img * p.Cin : nullptr;
+            st.iy0[i] = oy * p.stride - p.pad;
+            st.ix0[i] = ox * p.stride - p.pad;
+            st.base[i] = p.x + (size_t)(img / p.a_img_div) * p.H * p.W * p.Cin;
+            st.sbase[i] = IN_SCALE ? p.in_scale + (size_t)img * p.Cin : p.x;
         } else {
-            iy0[i] = -(1 << 28);  // forces the bounds test to fail
-            ix0[i] = -(1 << 28);
-            a_base[i] = p.x;
-            s_base[i] = p.in_scale;
+            st.iy0[i] = -(1 << 28);  // forces the bounds test to fail
+            st.ix0[i] = -(1 << 28);
+            st.base[i] = p.x;
+            st.sbase[i] = IN_SCALE ? p.in_scale : p.x;
         }
     }
     const float* b_base = p.w + (size_t)(n0 + row0) * p.K + col4 * 4;
@@ -112,55 +197,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int KT = p.K / BK;
     const int cin_tiles = CIN4 ? 1 : p.Cin / BK;
 
-    float4 a_reg[A_LD], b_reg[B_LD];
-
-    auto load_tile = [&](int kt) {
-        if (CIN4) {
-            // Cin == 4: one float4 is one filter tap; 8 taps per K-tile.
-            const int tap = kt * 8 + col4;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const bool tap_ok = tap < p.KH * p.KW;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                a_reg[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)iy * p.W + ix) * 4)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            const int tap = kt / cin_tiles;
-            const int c0 = (kt - tap * cin_tiles) * BK + col4 * 4;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    v = *reinterpret_cast<const float4*>(a_base[i] + ((size_t)iy * p.W + ix) * p.Cin + c0);
-                    if (IN_SCALE) {
-                        const float4 s = *reinterpret_cast<const float4*>(s_base[i] + c0);
-                        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                    }
-                }
-                a_reg[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            b_reg[i] = *reinterpret_cast<const float4*>(b_base + (size_t)(32 * i) * p.K + kt * BK);
-    };
-
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * STAGE;
-        float* Bs = As + BM * LDS_STRIDE;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<float4*>(As + (row0 + 32 * i) * LDS_STRIDE + col4 * 4) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<float4*>(Bs + (row0 + 32 * i) * LDS_STRIDE + col4 * 4) = b_reg[i];
-    };
+    typename Pack<4 * A_LD>::type a_reg, s_reg;
+    typename Pack<4 * B_LD>::type b_reg;
+    s_reg = 0.f;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -172,18 +211,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
+    float* const st_a = smem + row0 * LDS_STRIDE + col4 * 4;
+    float* const st_b = st_a + BM * LDS_STRIDE;
+    const float* const rd_a = smem + (wm * WM + frag_row) * LDS_STRIDE + frag_k;
+    const float* const rd_b = smem + BM * LDS_STRIDE + (wn * WN + frag_row) * LDS_STRIDE + frag_k;
 
-    load_tile(0);
-    store_tile(0);
+    unsigned okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, 0, cin_tiles, col4, a_reg, s_reg, b_reg);
+    finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(st_a + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(st_b + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
     __syncthreads();
 
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
+        // prefetch the next K-tile into registers; the last iteration re-loads tile KT-1
+        // (in bounds, never stored) so the loop body has no divergent control flow
+        const int kn = min(kt + 1, KT - 1);
+        okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, kn, cin_tiles, col4, a_reg, s_reg, b_reg);
+        // keep the global loads ABOVE the MFMA block: without a fence hipcc sinks most of them
+        // next to the ds_writes and the whole memory latency is exposed every K-tile
+        asm volatile("" ::: "memory");
 
-        const float* As = smem + cur * STAGE + (wm * WM + frag_row) * LDS_STRIDE + frag_k;
-        const float* Bs = smem + cur * STAGE + BM * LDS_STRIDE + (wn * WN + frag_row) * LDS_STRIDE + frag_k;
+        const float* As = rd_a + cur * STAGE;
+        const float* Bs = rd_b + cur * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float4 af[TM], bf[TN];
@@ -196,14 +248,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
         }
-        if (more) store_tile(cur ^ 1);
+        // stage the prefetched tile into the other buffer (harmless after the last tile).
+        // The fence keeps every consumer of the loaded registers (and so the vmcnt waits) BELOW
+        // the MFMA block.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(okm));   // opaque here: the selects that use it cannot be hoisted
+        finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
+        float* sa = st_a + (cur ^ 1) * STAGE;
+        float* sb = st_b + (cur ^ 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(sa + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(sb + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
         __syncthreads();
         cur ^= 1;
     }
@@ -234,30 +308,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, BN);
     const int grid = cdiv(M_max, BM) * p.n_tiles_n;
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static const hipError_t attr_once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, false>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     if (attr_once != hipSuccess) return (int)attr_once;
     if (cin4)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), dim3(grid), dim3(256), lds, stream, p);
     else if (p.in_scale)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), dim3(grid), dim3(256), lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>), dim3(grid), dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
@@ -286,21 +360,19 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     const long long M = (long long)n_img * p.Ho * p.Wo;
     if (M * (long long)Cout >= (1ll << 31) * 4) return FGN_ERR_SHAPE;
 
-    // tile choice: the largest tile that still yields >= ~2 blocks per CU, else smaller.
+    // tile choice (measured on MI355X, tools_conv_bench.py): the 64x64 tile (4 blocks/CU,
+    // ~4 waves/SIMD) wins almost everywhere because it quantises best over 256 CUs; the
+    // 128x128 tile (2 blocks/CU) is ~10 % better only when its grid is one nearly full wave.
     int tile = tile_hint;
     if (tile == 0) {
         const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
-        const long long b64x128 = ((M + 63) / 64) * cdiv(Cout, 128);
-        if (Cout <= 64) tile = 3;
-        else if (b128 >= 384) tile = 1;
-        else if (b64x128 >= 384) tile = 2;
-        else tile = 4;
+        tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;
     }
     switch (tile) {
-        case 1: return launch_cfg<128, 128, 64, 64>(p, (int)M, cin4, stream);
-        case 2: return launch_cfg<64, 128, 32, 64>(p, (int)M, cin4, stream);
-        case 3: return launch_cfg<128, 64, 64, 32>(p, (int)M, cin4, stream);
-        case 4: return launch_cfg<64, 64, 32, 32>(p, (int)M, cin4, stream);
+        case 1: return launch_cfg<128, 128, 64, 64, 2>(p, (int)M, cin4, stream);
+        case 2: return launch_cfg<64, 128, 32, 64, 3>(p, (int)M, cin4, stream);
+        case 3: return launch_cfg<128, 64, 64, 32, 3>(p, (int)M, cin4, stream);
+        case 4: return launch_cfg<64, 64, 32, 32, 4>(p, (int)M, cin4, stream);
         default: return FGN_ERR_ARG;
     }
 }

@@ -140,7 +140,8 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * cin, n_img, n_img_dev))
+        prof.append((e0, e1, 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * cin, n_img, n_img_dev,
+                     (n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
     return out
 
 
