@@ -28,24 +28,72 @@ __device__ __forceinline__ uint32_t key_index(uint64_t k) { return (uint32_t)k; 
 __device__ __forceinline__ float sigmoid32(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
 __device__ __forceinline__ float exp32(float x) { return (float)exp((double)x); }
 
-// In-LDS bitonic sort of n_pow2 uint64 keys, ascending; all POST_THREADS threads call.
+// In-LDS bitonic sort of n_pow2 (>= 1024, power of two) uint64 keys, ascending; all
+// POST_THREADS threads call.  Each wave owns a contiguous segment of n_pow2/16 keys: every
+// compare-exchange with stride j < segment stays inside one wave's segment, and a wave's LDS
+// operations execute in order, so those stages need no workgroup barrier - only the strides
+// that cross segments do (10 of the 91 stages at n = 8192).
+__device__ __forceinline__ void bitonic_cmpx(uint64_t* keys, int i, int j, int k) {
+    const uint64_t a = keys[i], b = keys[i + j];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) {
+        keys[i] = b;
+        keys[i + j] = a;
+    }
+}
 __device__ inline void block_bitonic_sort(uint64_t* keys, int n_pow2) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int seg = n_pow2 / POST_WAVES;        // keys per wave segment (>= 64)
+    const int seg_half = seg >> 1;
+    const int half = n_pow2 >> 1;
+    bool need_block_sync = false;
     for (int k = 2; k <= n_pow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        keys[i] = b;
-                        keys[ixj] = a;
+        for (int lj = 31 - __builtin_clz(k >> 1); lj >= 0; --lj) {
+            const int j = 1 << lj;
+            if (j >= seg) {
+                // cross-segment stride: comparators spread over the whole workgroup
+                __syncthreads();
+                for (int c = t; c < half; c += POST_THREADS)
+                    bitonic_cmpx(keys, ((c >> lj) << (lj + 1)) + (c & (j - 1)), j, k);
+                need_block_sync = true;
+            } else {
+                if (need_block_sync) {
+                    __syncthreads();
+                    need_block_sync = false;
+                }
+                // wave-local stride: this wave's seg/2 comparators, in-order LDS within the wave.
+                // All reads of a stage are issued before any write (min/max stores, no
+                // divergence), so LDS latency is paid once per stage, not once per comparator.
+                const int base = wv * seg;
+                uint64_t lo[4], hi[4];
+                int idx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = lane + 64 * u;
+                    idx[u] = base + ((c >> lj) << (lj + 1)) + (c & (j - 1));
+                    if (c < seg_half) {
+                        lo[u] = keys[idx[u]];
+                        hi[u] = keys[idx[u] + j];
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < seg_half) {
+                        const bool up = (idx[u] & k) == 0;
+                        const uint64_t mn = lo[u] < hi[u] ? lo[u] : hi[u];
+                        const uint64_t mx = lo[u] < hi[u] ? hi[u] : lo[u];
+                        keys[idx[u]] = up ? mn : mx;
+                        keys[idx[u] + j] = up ? mx : mn;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 // IoU test of mmcv's nms (offset 0): inter / (area_a + area_b - inter) > thr
@@ -58,77 +106,121 @@ __device__ __forceinline__ NmsBox make_nms_box(float x1, float y1, float x2, flo
     b.area = (x2 - x1) * (y2 - y1);
     return b;
 }
+// Exactly `inter / ((area_a + area_b) - inter) > thr` (the oracle's fp32 expression), but the
+// IEEE division is only executed when a multiplication test cannot decide with a 4e-6 relative
+// margin (the quotient and the products are each within 1 ulp): the division is ~10x the cost
+// of everything else in the test and sits on the serial chain of the greedy loop.
 __device__ __forceinline__ bool iou_gt(const NmsBox& a, const NmsBox& b, float thr) {
     const float xx1 = fmaxf(a.x1, b.x1), yy1 = fmaxf(a.y1, b.y1);
     const float xx2 = fminf(a.x2, b.x2), yy2 = fminf(a.y2, b.y2);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
     const float inter = w * h;
-    const float ovr = inter / ((a.area + b.area) - inter);
+    const float uni = (a.area + b.area) - inter;
+    const float tu = thr * uni;
+    if (inter > tu * 1.000004f && uni > 0.f && tu < 3.0e38f) return true;
+    if (inter < tu * 0.999996f && uni > 0.f) return false;
+    const float ovr = inter / uni;
     return ovr > thr;
 }
 
 // Greedy NMS over boxes already sorted by (score desc, index asc).
-//   boxes   : global, n x float4 (x1,y1,x2,y2) in sorted order
-//   keep    : LDS/global int array [max_out] receiving sorted positions of kept boxes
-//   kept    : LDS scratch NmsBox[max_out]
-//   chunk_* : LDS scratch [POST_THREADS]
-// Exactly the sequential greedy result: a box is kept iff no previously kept box has
-// IoU > thr with it; stops after max_out kept boxes.  Returns the number kept (uniform).
-// Parallel structure: 1024 candidates per round are tested against the kept list by all
-// 16 waves (phase A); wave 0 then resolves the round 64 boxes at a time with ballot /
-// readlane only (phase B) -- no barriers inside the serial part.
+//   boxes : global, n x float4 (x1,y1,x2,y2) in sorted order
+//   keep  : LDS int [max_out]  sorted positions of the kept boxes (output)
+//   kept  : LDS NmsBox [max_out], cand : LDS NmsBox [NMS_ROUND], sup : LDS u64 [NMS_ROUND*4],
+//   flags : LDS int [NMS_ROUND + 1]  (alive flags, last = kept counter)
+// Exactly the sequential greedy result: a box is kept iff no previously kept box has IoU > thr
+// with it; stops after max_out kept boxes.  Returns the number kept (uniform).
+// Rounds of 256 candidates:
+//   A. all 1024 threads test the candidates against the boxes kept in earlier rounds
+//      (4 threads per candidate split the kept list),
+//   M. all threads build the 256x256 suppression bit matrix of the round (64 tests each),
+//   S. wave 0 walks the round in score order using only scalar bit operations and
+//      v_readlane on register-held matrix rows: ~50 cycles per kept box, no LDS, no barrier.
+constexpr int NMS_ROUND = 256;
+
 __device__ inline int nms_sorted_block(const float4* __restrict__ boxes, int n, float thr, int max_out,
-                                       int* keep, NmsBox* kept, NmsBox* chunk_box, int* chunk_alive,
-                                       int* kept_cnt_sh) {
+                                       int* keep, NmsBox* kept, NmsBox* cand, unsigned long long* sup,
+                                       int* flags) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int* kept_cnt_sh = flags + NMS_ROUND;
     if (t == 0) *kept_cnt_sh = 0;
     __syncthreads();
     int kept_cnt = 0;
-    for (int base = 0; base < n && kept_cnt < max_out; base += POST_THREADS) {
-        const int i = base + t;
-        bool alive = i < n;
-        NmsBox b = make_nms_box(0.f, 0.f, 0.f, 0.f);
-        if (alive) {
-            const float4 v = boxes[i];
-            b = make_nms_box(v.x, v.y, v.z, v.w);
+    for (int base = 0; base < n && kept_cnt < max_out; base += NMS_ROUND) {
+        const int nb = min(NMS_ROUND, n - base);
+        if (t < NMS_ROUND) {
+            NmsBox b = make_nms_box(0.f, 0.f, 0.f, 0.f);
+            if (t < nb) {
+                const float4 v = boxes[base + t];
+                b = make_nms_box(v.x, v.y, v.z, v.w);
+            }
+            cand[t] = b;
+            flags[t] = t < nb ? 1 : 0;
         }
-        const int K0 = kept_cnt;
-        for (int j = 0; j < K0 && alive; ++j)
-            if (iou_gt(kept[j], b, thr)) alive = false;
-        chunk_box[t] = b;
-        chunk_alive[t] = alive ? 1 : 0;
         __syncthreads();
+        const int c = t & (NMS_ROUND - 1), part = t >> 8;   // 4 threads per candidate
+        const NmsBox cb = cand[c];
+        // ---- A: against boxes kept in earlier rounds
+        {
+            bool dead = false;
+            for (int j = part; j < kept_cnt; j += 4)
+                if (iou_gt(kept[j], cb, thr)) dead = true;
+            if (dead) flags[c] = 0;    // benign race: every writer stores 0
+        }
+        // ---- M: bit (w*64+b) of row c  <=>  box c suppresses the later box w*64+b of this round
+        {
+            const int w = part;
+            unsigned long long bits = 0ull;
+            if (w * 64 + 63 > c && c < nb) {
+                for (int b2 = 0; b2 < 64; ++b2) {
+                    const int c2 = w * 64 + b2;
+                    if (c2 > c && c2 < nb && iou_gt(cb, cand[c2], thr)) bits |= 1ull << b2;
+                }
+            }
+            sup[c * 4 + w] = bits;
+        }
+        __syncthreads();
+        // ---- S: serial resolution by wave 0
         if (wv == 0) {
-            int kcur = K0;
-            for (int c = 0; c < POST_WAVES && kcur < max_out; ++c) {
-                const int ci = c * 64 + lane;
-                if (base + c * 64 >= n) break;
-                const NmsBox cb = chunk_box[ci];
-                bool und = chunk_alive[ci] != 0;
-                for (int j = K0; j < kcur && und; ++j)
-                    if (iou_gt(kept[j], cb, thr)) und = false;
-                while (kcur < max_out) {
-                    const unsigned long long m = __ballot(und);
-                    if (m == 0ull) break;
-                    const int f = __ffsll((long long)m) - 1;
-                    NmsBox fb;
-                    fb.x1 = __shfl(cb.x1, f, 64); fb.y1 = __shfl(cb.y1, f, 64);
-                    fb.x2 = __shfl(cb.x2, f, 64); fb.y2 = __shfl(cb.y2, f, 64);
-                    fb.area = __shfl(cb.area, f, 64);
-                    if (lane == f) {
-                        kept[kcur] = cb;
-                        keep[kcur] = base + ci;
-                        und = false;
-                    } else if (und && iou_gt(fb, cb, thr)) {
-                        und = false;
-                    }
+            int kcur = kept_cnt;
+            unsigned long long removed[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) removed[q] = ~__ballot(flags[q * 64 + lane] != 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q * 64 >= nb || kcur >= max_out) break;
+                // this chunk's matrix rows, one candidate per lane, in registers
+                unsigned rl[4], rh[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long r = sup[(q * 64 + lane) * 4 + w];
+                    rl[w] = (unsigned)r;
+                    rh[w] = (unsigned)(r >> 32);
+                }
+                unsigned long long avail = ~removed[q];
+                while (avail != 0ull && kcur < max_out) {
+                    const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)avail) - 1);
+                    if (lane == 0) keep[kcur] = base + q * 64 + f;
                     ++kcur;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned long long r =
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rh[w], f) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)rl[w], f);
+                        removed[w] |= r;
+                    }
+                    removed[q] |= 1ull << f;
+                    avail = ~removed[q];
                 }
             }
             if (lane == 0) *kept_cnt_sh = kcur;
         }
         __syncthreads();
-        kept_cnt = *kept_cnt_sh;
+        const int new_cnt = *kept_cnt_sh;
+        // publish the boxes kept in this round for phase A of the next rounds
+        for (int j = kept_cnt + t; j < new_cnt; j += POST_THREADS) kept[j] = cand[keep[j] - base];
+        kept_cnt = new_cnt;
+        __syncthreads();
     }
     return kept_cnt;
 }

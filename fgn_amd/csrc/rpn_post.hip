@@ -54,6 +54,8 @@ extern "C" int fgn_rpn_merge_f32(const float* head, float* logits, float* scores
 // ----------------------------------------------------------------------------------------------
 // proposals: one workgroup (1024 threads) per image.
 // ----------------------------------------------------------------------------------------------
+constexpr int RPN_EPT = 64;   // scores cached per thread: n_total <= 65536
+
 struct ProposalParams {
     const float* scores;     // [B][n_total]
     const float4* deltas;    // [B][n_total]
@@ -71,64 +73,167 @@ struct ProposalParams {
     int max_out;
 };
 
+// diagnostic phase stamps (100 MHz realtime counter) written behind the top-k debug buffer
+#define RPN_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        if (p.dbg_topk_idx && threadIdx.x == 0)                                                 \
+            p.dbg_topk_idx[(size_t)blockIdx.x * 8192 + 8192 - 16 + (slot)] =                    \
+                (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);                       \
+    } while (0)
+
 __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const ProposalParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS carve: keys [cap] u64 | hist[256] | misc ; after the sort the key area is dead
     // and the NMS scratch (kept boxes, chunk boxes) is carved after it.
     uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);
-    int* hist = reinterpret_cast<int*>(keys + p.cap);
-    int* misc = hist + 256;   // [0] compaction counter, [1] scan carry, [2] kept count, [3..] wave sums
-    NmsBox* kept = reinterpret_cast<NmsBox*>(misc + 64);
-    NmsBox* chunk_box = kept + p.max_out;
-    int* chunk_alive = reinterpret_cast<int*>(chunk_box + POST_THREADS);
-    int* keep = chunk_alive + POST_THREADS;
+    int* hist = reinterpret_cast<int*>(keys + p.cap);      // [POST_WAVES][256] per-wave histograms
+    int* misc = hist + POST_WAVES * 256;   // [0] counter/digit, [1] rank carry, [2] kept count, [3..] wave sums
+    unsigned long long* sup = reinterpret_cast<unsigned long long*>(misc + 64);   // 8-byte aligned
+    NmsBox* kept = reinterpret_cast<NmsBox*>(sup + NMS_ROUND * 4);
+    NmsBox* cand = kept + p.max_out;
+    int* flags = reinterpret_cast<int*>(cand + NMS_ROUND);
+    int* keep = flags + NMS_ROUND + 2;
 
     const int b = blockIdx.x, t = threadIdx.x;
     const float* scores = p.scores + (size_t)b * p.n_total;
     const float4* deltas = p.deltas + (size_t)b * p.n_total;
     const int n_sel = min(p.nms_pre, p.n_total);
+    RPN_STAMP(0);
 
     // ---- 1. exact k-th key by 8-bit radix select over the 64-bit composite key ------------
-    uint64_t kth = ~0ull;
+    // The scores are read from global memory ONCE into registers (<= 64 per thread); the eight
+    // digit passes then touch only registers and LDS.  Histograms are private per wave (16
+    // copies) so that the first pass, where most keys share the exponent byte, does not
+    // serialise 1024 threads on one LDS word.
+    // Cached per element: hk = high word of the composite key (= ~ordered(score)); the low word
+    // is the anchor index j*1024+t, recomputed on the fly.  All digit passes are 32-bit: passes
+    // 7..4 walk hk, passes 3..0 walk the index among elements whose hk equals the threshold.
+    uint32_t hk[RPN_EPT];
+#pragma unroll
+    for (int j = 0; j < RPN_EPT; ++j) {
+        const int i = j * POST_THREADS + t;
+        hk[j] = (i < p.n_total) ? ~f32_ordered(scores[i]) : 0xffffffffu;
+    }
+    const int lane = t & 63, wv = t >> 6;
+    RPN_STAMP(1);
+    uint32_t kth_hi = 0xffffffffu, kth_lo = 0xffffffffu, kth_mask_hi = 0xffffffffu, kth_mask_lo = 0xffffffffu;
     if (n_sel < p.n_total) {
-        uint64_t prefix = 0, mask = 0;
+        uint32_t pre_hi = 0, msk_hi = 0, pre_lo = 0, msk_lo = 0;
         int k = n_sel;   // 1-based rank wanted
         for (int pass = 7; pass >= 0; --pass) {
-            const int shift = pass * 8;
-            for (int i = t; i < 256; i += POST_THREADS) hist[i] = 0;
+            const int shift = (pass & 3) * 8;
+            const bool hi_pass = pass >= 4;
+            for (int i = t; i < POST_WAVES * 256; i += POST_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i = t; i < p.n_total; i += POST_THREADS) {
-                const uint64_t key = sort_key(scores[i], (uint32_t)i);
-                if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
-            }
-            __syncthreads();
-            if (t == 0) {
-                int d = 0, cum = 0;
-                while (cum + hist[d] < k) {
-                    cum += hist[d];
-                    ++d;
+            int* my_hist = hist + wv * 256;
+            // run-length aggregation per thread: consecutive equal digits (the common case in
+            // the exponent-byte pass) cost one LDS atomic per run instead of one per element
+            uint32_t run_d = 0xffffffffu;
+            int run_n = 0;
+#pragma unroll
+            for (int j = 0; j < RPN_EPT; ++j) {
+                const uint32_t i = (uint32_t)(j * POST_THREADS + t);
+                const uint32_t h = hk[j];
+                bool match;
+                uint32_t digit;
+                if (hi_pass) {
+                    match = (h & msk_hi) == pre_hi;
+                    digit = (h >> shift) & 0xffu;
+                } else {
+                    match = (h == pre_hi) && ((i & msk_lo) == pre_lo);
+                    digit = (i >> shift) & 0xffu;
                 }
-                misc[0] = d;
-                misc[1] = k - cum;
+                if (match && i < (uint32_t)p.n_total) {
+                    if (digit == run_d) {
+                        ++run_n;
+                    } else {
+                        if (run_n) atomicAdd(&my_hist[run_d], run_n);
+                        run_d = digit;
+                        run_n = 1;
+                    }
+                }
+            }
+            if (run_n) atomicAdd(&my_hist[run_d], run_n);
+            __syncthreads();
+            // bin totals over the 16 wave copies, then an inclusive scan over the 256 bins
+            int tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int w = 0; w < POST_WAVES; ++w) tot += hist[w * 256 + t];
+            }
+            int incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            if (t < 256 && lane == 63) misc[8 + wv] = incl;
+            __syncthreads();
+            if (t < 256) {
+                int base = 0;
+                for (int w = 0; w < wv; ++w) base += misc[8 + w];
+                incl += base;
+                const int excl = incl - tot;
+                if (excl < k && k <= incl) {   // exactly one bin holds rank k
+                    misc[0] = t;
+                    misc[1] = k - excl;
+                    misc[5] = (n_sel - k) + incl;   // #keys whose known prefix is <= the chosen one
+                }
             }
             __syncthreads();
-            prefix |= (uint64_t)misc[0] << shift;
-            mask |= 0xffull << shift;
+            const uint32_t d = (uint32_t)misc[0];
+            if (hi_pass) {
+                pre_hi |= d << shift;
+                msk_hi |= 0xffu << shift;
+            } else {
+                pre_lo |= d << shift;
+                msk_lo |= 0xffu << shift;
+            }
             k = misc[1];
-            __syncthreads();
+            // Early exit: once the keys with prefix <= chosen fit the sort buffer, select them all;
+            // the sort puts the wanted n_sel first.  Typically after 2 of the 8 passes.
+            if (misc[5] <= p.cap) break;
         }
-        kth = prefix;
+        kth_hi = pre_hi;
+        kth_lo = pre_lo;
+        kth_mask_hi = msk_hi;
+        kth_mask_lo = msk_lo;
     }
-    // ---- 2. compaction of the selected keys into LDS, pad, sort ----------------------------
-    if (t == 0) misc[0] = 0;
+    // ---- 2. compaction of the selected keys into LDS (wave-aggregated), pad, sort ----------
+    RPN_STAMP(2);
     for (int i = t; i < p.cap; i += POST_THREADS) keys[i] = ~0ull;
-    __syncthreads();
-    for (int i = t; i < p.n_total; i += POST_THREADS) {
-        const uint64_t key = sort_key(scores[i], (uint32_t)i);
-        if (key <= kth) keys[atomicAdd(&misc[0], 1)] = key;
+    {
+        // each thread owns a contiguous output range found by one block scan: no atomics
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < RPN_EPT; ++j) {
+            const uint32_t i = (uint32_t)(j * POST_THREADS + t);
+            const uint32_t hm = hk[j] & kth_mask_hi;
+            mine += (i < (uint32_t)p.n_total && (hm < kth_hi || (hm == kth_hi && (i & kth_mask_lo) <= kth_lo))) ? 1 : 0;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) misc[8 + wv] = incl;
+        __syncthreads();          // also orders the ~0 fill above before the writes below
+        int pos = incl - mine;
+        for (int w = 0; w < wv; ++w) pos += misc[8 + w];
+#pragma unroll
+        for (int j = 0; j < RPN_EPT; ++j) {
+            const uint32_t i = (uint32_t)(j * POST_THREADS + t);
+            const uint32_t h = hk[j];
+            const uint32_t hm = h & kth_mask_hi;
+            if (i < (uint32_t)p.n_total && (hm < kth_hi || (hm == kth_hi && (i & kth_mask_lo) <= kth_lo)))
+                keys[pos++] = ((uint64_t)h << 32) | i;
+        }
     }
     __syncthreads();
+    RPN_STAMP(3);
     block_bitonic_sort(keys, p.cap);
+    RPN_STAMP(4);
 
     // ---- 3. decode (delta2bbox), min-size filter, order-preserving compaction --------------
     float4* out_boxes = p.sorted_boxes + (size_t)b * p.cap;
@@ -144,7 +249,7 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         if (j >= per_thread || i >= n_sel || i >= p.cap) continue;
         const uint64_t key = keys[i];
         const uint32_t idx = key_index(key);
-        if (p.dbg_topk_idx) p.dbg_topk_idx[(size_t)b * p.cap + i] = (int32_t)idx;
+        if (p.dbg_topk_idx) p.dbg_topk_idx[(size_t)b * 8192 + i] = (int32_t)idx;
         const int a = idx % p.A;
         const int px = idx / p.A;
         const int gx = px % p.feat_w, gy = px / p.feat_w;
@@ -177,7 +282,6 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         }
     }
     // block exclusive scan of cnt
-    const int lane = t & 63, wv = t >> 6;
     int incl = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -203,9 +307,9 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
     }
     __syncthreads();   // global writes of this workgroup are visible to it after the barrier
 
+    RPN_STAMP(5);
     // ---- 4. greedy NMS, keep the first max_out -------------------------------------------------
-    const int n_keep = nms_sorted_block(out_boxes, total_valid, p.iou_thr, p.max_out, keep, kept, chunk_box,
-                                        chunk_alive, &misc[2]);
+    const int n_keep = nms_sorted_block(out_boxes, total_valid, p.iou_thr, p.max_out, keep, kept, cand, sup, flags);
     float* props = p.proposals + (size_t)b * p.max_out * 5;
     for (int i = t; i < p.max_out; i += POST_THREADS) {
         if (i < n_keep) {
@@ -219,6 +323,7 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         }
     }
     if (t == 0) p.n_props[b] = n_keep;
+    RPN_STAMP(6);
 }
 
 extern "C" size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre) {
@@ -243,6 +348,7 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     int cap = POST_THREADS;
     while (cap < n_sel) cap <<= 1;
     if (cap > 8192 || max_per_img > 1024 || max_per_img < 1) return FGN_ERR_SHAPE;
+    if (p.n_total > RPN_EPT * POST_THREADS) return FGN_ERR_SHAPE;   // scores are cached in registers
     p.scores = scores; p.deltas = reinterpret_cast<const float4*>(deltas);
     p.base_anchors = reinterpret_cast<const float4*>(base_anchors);
     p.sorted_boxes = reinterpret_cast<float4*>(scratch);
@@ -253,8 +359,8 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     p.img_h = img_h; p.img_w = img_w;
     for (int i = 0; i < 4; ++i) { p.mean[i] = means4[i]; p.stdv[i] = stds4[i]; }
     p.max_ratio = max_ratio; p.min_size = min_bbox_size; p.iou_thr = iou_thr; p.max_out = max_per_img;
-    const size_t lds = (size_t)cap * 8 + 256 * 4 + 64 * 4 + (size_t)max_per_img * sizeof(NmsBox) +
-                       POST_THREADS * sizeof(NmsBox) + POST_THREADS * 4 + (size_t)max_per_img * 4;
+    const size_t lds = (size_t)cap * 8 + POST_WAVES * 256 * 4 + 64 * 4 + (size_t)max_per_img * sizeof(NmsBox) +
+                       NMS_ROUND * sizeof(NmsBox) + NMS_ROUND * 4 * 8 + (NMS_ROUND + 2) * 4 + (size_t)max_per_img * 4;
     static const hipError_t attr_once = hipFuncSetAttribute(
         reinterpret_cast<const void*>(rpn_proposals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_once != hipSuccess) return (int)attr_once;

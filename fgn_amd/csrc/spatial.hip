@@ -175,11 +175,15 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     }
 }
 
-// single-channel variant for the support masks (uint8/bool input [B,H,W]); one thread per bin
-__global__ void roi_align_mask_kernel(const uint8_t* __restrict__ mask, const float* __restrict__ rois,
-                                      float* __restrict__ out, int n_rois, int H, int W, int P,
-                                      float spatial_scale, int sampling_ratio, int aligned) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// single-channel variant for the support masks (uint8/bool input [B,H,W]); one wavefront per bin,
+// lanes stride over the (adaptive, up to ~37x37) sampling grid and combine with a shuffle reduction
+__global__ __launch_bounds__(256) void roi_align_mask_kernel(const uint8_t* __restrict__ mask,
+                                                             const float* __restrict__ rois,
+                                                             float* __restrict__ out, int n_rois, int H, int W,
+                                                             int P, float spatial_scale, int sampling_ratio,
+                                                             int aligned) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= n_rois * P * P) return;
     const int r = i / (P * P);
     const int pb = i - r * P * P;
@@ -202,21 +206,21 @@ __global__ void roi_align_mask_kernel(const uint8_t* __restrict__ mask, const fl
     const float count = (float)max(gh * gw, 1);
     const uint8_t* base = mask + (size_t)b * H * W;
     float acc = 0.f;
-    for (int iy = 0; iy < gh; ++iy) {
+    for (int s = lane; s < gh * gw; s += 64) {
+        const int iy = s / gw, ix = s - iy * gw;
         const float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+        const float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
         const AxisSample sy = axis_sample(y, H);
-        for (int ix = 0; ix < gw; ++ix) {
-            const float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
-            const AxisSample sx = axis_sample(x, W);
-            if (!(sy.valid && sx.valid)) continue;
-            const float v1 = base[(size_t)sy.lo * W + sx.lo] ? 1.f : 0.f;
-            const float v2 = base[(size_t)sy.lo * W + sx.hi] ? 1.f : 0.f;
-            const float v3 = base[(size_t)sy.hi * W + sx.lo] ? 1.f : 0.f;
-            const float v4 = base[(size_t)sy.hi * W + sx.hi] ? 1.f : 0.f;
-            acc += sy.h * sx.h * v1 + sy.h * sx.l * v2 + sy.l * sx.h * v3 + sy.l * sx.l * v4;
-        }
+        const AxisSample sx = axis_sample(x, W);
+        if (!(sy.valid && sx.valid)) continue;
+        const float v1 = base[(size_t)sy.lo * W + sx.lo] ? 1.f : 0.f;
+        const float v2 = base[(size_t)sy.lo * W + sx.hi] ? 1.f : 0.f;
+        const float v3 = base[(size_t)sy.hi * W + sx.lo] ? 1.f : 0.f;
+        const float v4 = base[(size_t)sy.hi * W + sx.hi] ? 1.f : 0.f;
+        acc += sy.h * sx.h * v1 + sy.h * sx.l * v2 + sy.l * sx.h * v3 + sy.l * sx.l * v4;
     }
-    out[i] = acc / count;
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) out[i] = acc / count;
 }
 
 extern "C" int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, float* out,
@@ -242,7 +246,7 @@ extern "C" int fgn_roi_align_mask_u8(const uint8_t* mask, const float* rois, flo
     (void)n_img;
     if (n_rois == 0) return FGN_OK;
     const int total = n_rois * out_size * out_size;
-    hipLaunchKernelGGL(roi_align_mask_kernel, dim3(cdiv(total, 64)), dim3(64), 0, stream, mask, rois, out,
+    hipLaunchKernelGGL(roi_align_mask_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, mask, rois, out,
                        n_rois, H, W, out_size, spatial_scale, sampling_ratio, aligned);
     FGN_LAUNCH_CHECK();
     return FGN_OK;

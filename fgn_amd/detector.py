@@ -135,6 +135,11 @@ class FGN(torch.nn.Module):
                                (state_dict if state_dict is not None else init_state_dict(self.cfg, seed)).items())
         self._packed_device = None
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
+        self.use_side_stream = True               # support branch on a second HIP stream
+        self._side_stream = None
+        self._copy_stream = None
+        self._pinned_ring: list = []
+        self._pinned_next = 0
 
     @classmethod
     def from_config(cls, model_cfg: dict, **kw) -> 'FGN':
@@ -280,14 +285,44 @@ class FGN(torch.nn.Module):
         spp_xyxy = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)[:, [1, 0, 3, 2]]
         spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
 
+        # Two HIP streams: the support branch (9 small crops: low-occupancy launches) runs beside
+        # the query branch, and its RoI/shared-head/reduction tail runs beside the single-workgroup
+        # proposal kernel.  Joined by events; no host synchronisation.
+        main = torch.cuda.current_stream()
+        if self.use_side_stream:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+        else:
+            side = main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            spp_fmaps = self.extract_feat(spp)                  # [B*N*K,s,s,C]
+            vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
+            vec_ready = side.record_event()
+            # ---- count_spp (fgn_roi_head.py:419-449) --------------------------------------
+            bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
+            spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
+            masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
+            # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
+            sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
+            sfeat = self._shared_head(sfeat)
+            cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
+            cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
+            S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
+            spp_ready = side.record_event()
+        for tns in (spp, spp_xyxy, spp_masks):              # allocated on main, consumed on side
+            tns.record_stream(side)
+        for tns in (spp_fmaps, vec, S, cat_mean, cat_mean_mp, masks7):   # produced on side, consumed on main
+            tns.record_stream(main)
+
         qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
-        spp_fmaps = self.extract_feat(spp)                      # [B*N*K,s,s,C]
         fh, fw, C = qry_fmap.shape[1:]
         if tr is not None:
             tr['qry_fmap'], tr['spp_fmaps'] = qry_fmap, spp_fmaps
 
         # ---- AG-RPN (fgn_ag_rpn_head.py:26-118) -------------------------------------------
-        vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
+        main.wait_event(vec_ready)
         x = ops.conv2d(qry_fmap, P['rpn_conv'], in_scale=vec, a_img_div=N)      # guidance fused
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
@@ -299,22 +334,10 @@ class FGN(torch.nn.Module):
                                            rp['target_means'], rp['target_stds'], tc['rpn']['nms_pre'],
                                            tc['rpn']['min_bbox_size'], tc['rpn']['nms_iou_threshold'],
                                            tc['rpn']['max_per_img'])
+        main.wait_event(spp_ready)
         if tr is not None:
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
-                      n_props=n_props)
-
-        # ---- count_spp (fgn_roi_head.py:419-449) ------------------------------------------
-        bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
-        spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
-        masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
-        # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
-        sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
-        sfeat = self._shared_head(sfeat)
-        cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
-        cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
-        S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
-        if tr is not None:
-            tr.update(spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
+                      n_props=n_props, spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
 
         # ---- per image: box head, detections, mask head -----------------------------------
         outs = []
@@ -350,7 +373,52 @@ class FGN(torch.nn.Module):
                     n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
             outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mprob, rle_bytes=rle_bytes,
                              rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
+        self._start_download(outs, main)
         return outs
+
+    def _pinned_slot(self, batch: int, max_det: int) -> dict:
+        """Ring of pinned host buffers (pinned allocation is slow; 4 slots cover a pipeline of
+        several episodes in flight)."""
+        key = (batch, max_det, ops.RLE_BYTE_CAP)
+        if not self._pinned_ring or self._pinned_ring[0]['key'] != key:
+            pin = lambda *shape, dtype: torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._pinned_ring = [dict(key=key,
+                                      det=pin(batch, max_det, 5, dtype=torch.float32),
+                                      lab=pin(batch, max_det, dtype=torch.int64),
+                                      cnt=pin(batch, 1, dtype=torch.int32),
+                                      rle_len=pin(batch, max_det, dtype=torch.int32),
+                                      rle_ovf=pin(batch, max_det, dtype=torch.int32),
+                                      rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
+                                 for _ in range(4)]
+            self._pinned_next = 0
+        slot = self._pinned_ring[self._pinned_next % len(self._pinned_ring)]
+        self._pinned_next += 1
+        return slot
+
+    def _start_download(self, outs: list, main) -> None:
+        """Queue the device->host copies of one batch on a copy stream behind the compute work;
+        ``pack_results`` later waits on the event only, so the next batch's kernels are not
+        serialised behind a host round trip."""
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        cp = self._copy_stream
+        max_det = outs[0]['det_bboxes'].shape[0]
+        slot = self._pinned_slot(len(outs), max_det)
+        cp.wait_stream(main)
+        with torch.cuda.stream(cp):
+            for i, d in enumerate(outs):
+                slot['det'][i].copy_(d['det_bboxes'], non_blocking=True)
+                slot['lab'][i].copy_(d['det_labels'], non_blocking=True)
+                slot['cnt'][i].copy_(d['n_dets'], non_blocking=True)
+                slot['rle_len'][i].copy_(d['rle_len'], non_blocking=True)
+                slot['rle_ovf'][i].copy_(d['rle_overflow'], non_blocking=True)
+                slot['rle'][i].copy_(d['rle_bytes'], non_blocking=True)
+                for k in ('det_bboxes', 'det_labels', 'n_dets', 'rle_len', 'rle_overflow', 'rle_bytes'):
+                    d[k].record_stream(cp)
+            ev = cp.record_event()
+        for d in outs:
+            d['host'] = slot
+            d['host_ready'] = ev
 
     def pack_results(self, dets: list, batch: int, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None,
                      img_shape=None, qry_child_idx=None, cats_ids_to_sample_real=None, spp_insts_ids=None,
@@ -360,17 +428,17 @@ class FGN(torch.nn.Module):
         passthrough = {'idx': idx, 'qry_bboxes': qry_bboxes, 'qry_img_shape': img_shape,
                        'qry_cat_ids': qry_cat_ids, 'qry_child_idx': qry_child_idx,
                        'cats_ids_to_sample_real': cats_ids_to_sample_real, 'spp_insts_ids': spp_insts_ids}
-        counts = torch.cat([d['n_dets'] for d in dets]).cpu().numpy()   # the one host sync
+        dets[0]['host_ready'].synchronize()        # the one host wait: the batch's D2H copies
+        host = dets[0]['host']
         results = []
         for i in range(batch):
-            n = int(counts[i])
             di = dets[i]
-            db = di['det_bboxes'][:n].cpu().numpy()
-            lens = di['rle_len'][:n].cpu().numpy()
-            ovf = di['rle_overflow'][:n].cpu().numpy()
+            n = int(host['cnt'][i, 0])
+            db = host['det'][i, :n].numpy()
+            lens = host['rle_len'][i, :n].numpy()
+            ovf = host['rle_ovf'][i, :n].numpy()
             ih, iw = di['img_hw']
-            width = int(lens.max()) if n else 0
-            strings = di['rle_bytes'][:n, :width].cpu().numpy() if width else np.zeros((n, 0), np.uint8)
+            strings = host['rle'][i].numpy()
             rles = [{'size': [ih, iw], 'counts': strings[j, :lens[j]].tobytes()} for j in range(n)]
             if n and ovf.any():     # a device cap overflowed: dense paste + host RLE for those masks only
                 thr = self.cfg['test_cfg']['rcnn']['mask_thr_binary']
@@ -380,7 +448,7 @@ class FGN(torch.nn.Module):
                     rles[j] = rle.encode(dense[0].cpu().numpy())
             one = {'dt_scores': db[:, 4].reshape(-1).copy(),
                    'dt_bboxes': db[:, [1, 0, 3, 2]].reshape(-1, 4).copy(),
-                   'dt_cat_ids': di['det_labels'][:n].cpu().numpy().reshape(-1),
+                   'dt_cat_ids': host['lab'][i, :n].numpy().copy().reshape(-1),
                    'dt_isegmaps_rle': rles}
             for key, val in passthrough.items():
                 v = val[i] if val is not None else None

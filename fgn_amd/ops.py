@@ -383,7 +383,7 @@ def mask_paste(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, 
 
 
 RLE_TRANS_CAP = 16384     # transitions per detection kept on device
-RLE_BYTE_CAP = 32768      # COCO string bytes per detection
+RLE_BYTE_CAP = 16384      # COCO string bytes per detection
 
 
 def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,

@@ -17,6 +17,6 @@ for it in range(4):
     dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'])
     t1 = time.perf_counter()
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    res = model.pack_results(dets, 1, img_shape=e['img_shape'])
+    res = model.pack_results(dets, 1, img_shape=e["img_shape"])
     t3 = time.perf_counter()
     print(f'iter {it}: launch {1e3*(t1-t0):.1f} ms, gpu-done {1e3*(t2-t0):.1f} ms, pack {1e3*(t3-t2):.2f} ms, n={len(res[0]["dt_scores"])}')
