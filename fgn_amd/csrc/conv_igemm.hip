@@ -41,6 +41,11 @@ struct ConvParams {
     int relu;
     int K;          // padded reduction length (multiple of 32)
     int n_tiles_n;  // Cout tiles
+    // split-K: blockIdx.y owns K-tiles [y*kt_per_split, (y+1)*kt_per_split) and writes its raw
+    // partial tile to slab y of `ws` ([splits][n_img*Ho*Wo][Cout]); splitk_epilogue_kernel sums
+    // the slabs in a fixed order (deterministic) and applies the epilogue.
+    float* ws;
+    int splits, kt_per_split;
 };
 
 constexpr int BK = 32;
@@ -194,7 +199,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     }
     const float* b_base = p.w + (size_t)(n0 + row0) * p.K + col4 * 4;
 
-    const int KT = p.K / BK;
+    const int KT_all = p.K / BK;
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int KT = min(KT_all, kt0 + p.kt_per_split);     // this block's K-tiles: [kt0, KT)
     const int cin_tiles = CIN4 ? 1 : p.Cin / BK;
 
     typename Pack<4 * A_LD>::type a_reg, s_reg;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     const float* const rd_a = smem + (wm * WM + frag_row) * LDS_STRIDE + frag_k;
     const float* const rd_b = smem + BM * LDS_STRIDE + (wn * WN + frag_row) * LDS_STRIDE + frag_k;
 
-    unsigned okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, 0, cin_tiles, col4, a_reg, s_reg, b_reg);
+    unsigned okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, kt0, cin_tiles, col4, a_reg, s_reg, b_reg);
     finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(st_a + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kt0; kt < KT; ++kt) {
         // prefetch the next K-tile into registers; the last iteration re-loads tile KT-1
         // (in bounds, never stored) so the loop body has no divergent control flow
         const int kn = min(kt + 1, KT - 1);
@@ -284,6 +291,23 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
 
     // ---- epilogue: C/D layout col = lane&31 (-> n), row = (r&3)+8*(r>>2)+4*(lane>>5) (-> m)
     const int half = lane >> 5;
+    if (p.splits > 1) {
+        float* slab = p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + frag_row;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * WM + i * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (n < p.Cout && m < M) slab[(size_t)m * p.Cout + n] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + frag_row;
@@ -308,11 +332,45 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     }
 }
 
+__global__ void splitk_epilogue_kernel(const ConvParams p) {
+    const int HoWo = p.Ho * p.Wo;
+    int n_img = p.n_img;
+    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
+    const size_t total4 = (size_t)n_img * HoWo * p.Cout / 4;
+    const size_t slab4 = (size_t)p.n_img * HoWo * p.Cout / 4;
+    const int c4n = p.Cout / 4;
+    const float4* ws = reinterpret_cast<const float4*>(p.ws);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ws[i];
+        for (int z = 1; z < p.splits; ++z) {
+            const float4 b = ws[i + (size_t)z * slab4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int c = (int)(i % c4n) * 4;
+        if (p.scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+            a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w;
+        }
+        if (p.shift) {
+            const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+            a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w;
+        }
+        if (p.residual) {
+            const float4 r = reinterpret_cast<const float4*>(p.residual)[i];
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        if (p.relu) {
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        }
+        reinterpret_cast<float4*>(p.y)[i] = a;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, BN);
-    const int grid = cdiv(M_max, BM) * p.n_tiles_n;
+    const dim3 grid(cdiv(M_max, BM) * p.n_tiles_n, p.splits);
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static const hipError_t attr_once = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>),
@@ -327,20 +385,52 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     }();
     if (attr_once != hipSuccess) return (int)attr_once;
     if (cin4)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), grid, dim3(256), lds, stream, p);
     else if (p.in_scale)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), grid, dim3(256), lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>), dim3(grid), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>), grid, dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const size_t total4 = (size_t)M_max * p.Cout / 4;
+        const int eg = (int)std::min<size_t>((total4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(eg), dim3(256), 0, stream, p);
+        FGN_LAUNCH_CHECK();
+    }
     return FGN_OK;
+}
+
+// split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
+static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
+    if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
+    if (Cout % 4) return 1;
+    const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
+    if (blocks >= 512 || KT < 8) return 1;
+    int s = (int)((1024 + blocks - 1) / blocks);
+    s = std::min(s, KT / 4);
+    s = std::min(s, 16);
+    return s < 2 ? 1 : s;
+}
+
+extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                                             int stride, int pad, int tile_hint) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || n_img <= 0) return 0;
+    const long long M = (long long)n_img * Ho * Wo;
+    const int KT = cdiv(KH * KW * Cin, BK);
+    if (tile_hint > 0 && tile_hint != 4) return 0;
+    const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
+    if (tile_hint == 0 && b128 >= 400 && b128 <= 512) return 0;
+    const int s = plan_splits(M, Cout, KT, tile_hint);
+    return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
 extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                                    const float* shift, const float* residual, const float* in_scale,
                                    const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                                    int cout_pad, int KH, int KW, int stride, int pad, int a_img_div,
-                                   int relu, int tile_hint, hipStream_t stream) {
+                                   int relu, int tile_hint, float* splitk_ws, size_t splitk_ws_bytes,
+                                   hipStream_t stream) {
     if (!x || !w_packed || !y) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const bool cin4 = (Cin == 4);
@@ -363,10 +453,20 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     // tile choice (measured on MI355X, tools_conv_bench.py): the 64x64 tile (4 blocks/CU,
     // ~4 waves/SIMD) wins almost everywhere because it quantises best over 256 CUs; the
     // 128x128 tile (2 blocks/CU) is ~10 % better only when its grid is one nearly full wave.
-    int tile = tile_hint;
+    int tile = tile_hint < 0 ? -tile_hint : tile_hint;
+    p.ws = nullptr; p.splits = 1; p.kt_per_split = p.K / BK;
     if (tile == 0) {
         const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
         tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;
+    }
+    if (tile == 4 && splitk_ws) {
+        const int KT = p.K / BK;
+        const int sp = plan_splits(M, Cout, KT, tile_hint);
+        if (sp > 1 && splitk_ws_bytes >= (size_t)sp * M * Cout * sizeof(float)) {
+            p.ws = splitk_ws;
+            p.kt_per_split = cdiv(KT, sp);
+            p.splits = cdiv(KT, p.kt_per_split);
+        }
     }
     switch (tile) {
         case 1: return launch_cfg<128, 128, 64, 64, 2>(p, (int)M, cin4, stream);

@@ -18,7 +18,8 @@ _f = C.c_float
 # name -> (restype, argtypes); mirrors include/fgn_hip.h one to one
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
-    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p]),
+    'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
+    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
     'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
@@ -38,7 +39,7 @@ SIGNATURES = {
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -133,10 +133,14 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib.load().fgn_conv2d_nhwc_f32(
+    L = _lib.load()
+    ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
+                                            layer.pad, tile_hint)
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
+    rc = L.fgn_conv2d_nhwc_f32(
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
-        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _stream())
+        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         e1.record()

@@ -44,12 +44,17 @@ int fgn_abi_version(void);
  *   cout_pad multiple of 128, zero rows)   y [n_img, Ho, Wo, Cout]
  *   scale/shift [Cout] or NULL; residual like y or NULL; in_scale [n_img, Cin] or NULL
  *   Cin must be a multiple of 32, or exactly 4 (stem, NHWC4 input)
- *   tile_hint 0 = auto, 1..4 = force a tile configuration (tests) */
+ *   tile_hint 0 = auto, 1..4 = force a tile configuration, negative = same without split-K (tests)
+ *   splitk_ws: optional workspace of fgn_conv2d_workspace_bytes() bytes; when given and the plain
+ *   grid would under-fill the GPU, K is split over blockIdx.y into slabs that a second kernel
+ *   sums in a fixed order (bit-reproducible) before the epilogue.  NULL = never split. */
+size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                  int pad, int tile_hint);
 int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                         const float* shift, const float* residual, const float* in_scale,
                         const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                         int cout_pad, int KH, int KW, int stride, int pad, int a_img_div, int relu,
-                        int tile_hint, void* stream);
+                        int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* NCHW [n,3,H,W] -> NHWC4 [n,H,W,4] (input side of fgn.py:212,215) */
 int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, void* stream);

@@ -41,7 +41,7 @@ CASES = [
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, -4])
 def test_conv_matches_torch(case, tile):
     from fgn_amd import ops
     n, cin, h, w, cout, k, stride, pad, use_bn, use_bias, use_res, relu = case
