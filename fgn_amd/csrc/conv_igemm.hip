@@ -48,16 +48,22 @@ struct ConvParams {
     int splits, kt_per_split;
 };
 
+#ifndef CONV_DBG
+#define CONV_DBG 0   // diagnostic ablations (tools only): 1 no global loads, 2 no ds_write, 4 no ds_read, 8 no barrier, 16 loads always hit the first tile
+#endif
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats
 
-// Per-thread staging state: which rows of the A tile this thread loads (fixed for the whole
-// K loop) and where they start in the input image.
+// Per-thread staging state, fixed for the whole K loop: for each A row this thread loads, the
+// element offset of the (ky=0,kx=0) tap and a bit mask of the filter taps that fall inside the
+// image.  Per K-tile the address is then `off + uniform tap offset` (one VALU add) and the
+// bounds test is one bit test - the im2col index arithmetic is out of the hot loop.
 template <int A_LD>
 struct AStage {
-    const float* base[A_LD];
-    const float* sbase[A_LD];
-    int iy0[A_LD], ix0[A_LD];
+    int off[A_LD];                    // ((img*H + iy0)*W + ix0)*Cin  (+ col4*4 for Cin>=32)
+    unsigned long long taps[A_LD];    // bit (ky*KW+kx): tap inside the image and row < M
+    int soff[A_LD];                   // in_scale row offset (img*Cin + col4*4)
+    int iy0[A_LD], ix0[A_LD];         // CIN4 path only
 };
 
 // Register staging buffers are ext_vector SSA values (not arrays): hipcc leaves float4 arrays
@@ -86,32 +92,31 @@ __device__ __forceinline__ unsigned load_tile(const ConvParams& p, const AStage<
                                               typename Pack<4 * B_LD>::type& b_reg) {
     unsigned ok_mask = 0;
     if (CIN4) {
-        // Cin == 4: one float4 is one filter tap; 8 taps per K-tile.
+        // Cin == 4: one float4 is one filter tap; 8 taps per K-tile, tap differs per lane.
         const int tap = kt * 8 + col4;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const bool tap_ok = tap < p.KH * p.KW;
+        const int tap_off = (ky * p.W + kx) * 4;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int iy = st.iy0[i] + ky, ix = st.ix0[i] + kx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int off = ok ? (iy * p.W + ix) * 4 : 0;   // invalid taps read a valid dummy address
-            const float4 v = *reinterpret_cast<const float4*>(st.base[i] + off);
+            const bool ok = tap < p.KH * p.KW && ((st.taps[i] >> tap) & 1ull);
+            const int off = ok ? st.off[i] + tap_off : 0;   // invalid taps read a valid dummy address
+            const float4 v = *reinterpret_cast<const float4*>(p.x + off);
             PACK_SET4(a_reg, i, v);
             ok_mask |= ok ? (1u << i) : 0u;
         }
     } else {
-        const int tap = kt / cin_tiles;
-        const int c0 = (kt - tap * cin_tiles) * BK + col4 * 4;
+        const int tap = kt / cin_tiles;                       // wave-uniform (scalar unit)
+        const int c0 = (kt - tap * cin_tiles) * BK;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int tap_off = (ky * p.W + kx) * p.Cin + c0;     // uniform
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int iy = st.iy0[i] + ky, ix = st.ix0[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int off = ok ? (iy * p.W + ix) * p.Cin + c0 : 0;
-            const float4 v = *reinterpret_cast<const float4*>(st.base[i] + off);
+            const bool ok = (st.taps[i] >> tap) & 1ull;
+            const int off = ok ? st.off[i] + tap_off : 0;
+            const float4 v = *reinterpret_cast<const float4*>(p.x + off);
             PACK_SET4(a_reg, i, v);
             if (IN_SCALE) {
-                const float4 sv = *reinterpret_cast<const float4*>(st.sbase[i] + c0);
+                const float4 sv = *reinterpret_cast<const float4*>(p.in_scale + st.soff[i] + c0);
                 PACK_SET4(s_reg, i, sv);
             }
             ok_mask |= ok ? (1u << i) : 0u;
@@ -181,20 +186,23 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + row0 + 32 * i;
+        st.off[i] = 0; st.taps[i] = 0ull; st.soff[i] = 0; st.iy0[i] = 0; st.ix0[i] = 0;
         if (m < M) {
             const int img = m / HoWo;
             const int rem = m - img * HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
-            st.iy0[i] = oy * p.stride - p.pad;
-            st.ix0[i] = ox * p.stride - p.pad;
-            st.base[i] = p.x + (size_t)(img / p.a_img_div) * p.H * p.W * p.Cin;
-            st.sbase[i] = IN_SCALE ? p.in_scale + (size_t)img * p.Cin : p.x;
-        } else {
-            st.iy0[i] = -(1 << 28);  // forces the bounds test to fail
-            st.ix0[i] = -(1 << 28);
-            st.base[i] = p.x;
-            st.sbase[i] = IN_SCALE ? p.in_scale : p.x;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            st.off[i] = (((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + (CIN4 ? 0 : col4 * 4);
+            st.soff[i] = img * p.Cin + col4 * 4;
+            unsigned long long tm = 0ull;
+            int tp = 0;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
+                for (int kx = 0; kx < p.KW; ++kx, ++tp)
+                    if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
+            }
+            st.taps[i] = tm;
         }
     }
     const float* b_base = p.w + (size_t)(n0 + row0) * p.K + col4 * 4;
@@ -223,24 +231,25 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     const float* const rd_a = smem + (wm * WM + frag_row) * LDS_STRIDE + frag_k;
     const float* const rd_b = smem + BM * LDS_STRIDE + (wn * WN + frag_row) * LDS_STRIDE + frag_k;
 
+    // ---- prologue: tile kt0 -> LDS[0]; tile kt0+1 -> registers -------------------------------
     unsigned okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, kt0, cin_tiles, col4, a_reg, s_reg, b_reg);
     finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(st_a + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(st_b + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
+    okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, min(kt0 + 1, KT - 1), cin_tiles, col4, a_reg, s_reg,
+                                                b_reg);
     __syncthreads();
 
+    // ---- main loop, three-stage software pipeline ------------------------------------------
+    //   registers hold tile t+1 (loaded one iteration ago), LDS[cur] holds tile t.
+    //   [MFMAs of k-slice 0] -> [regs(t+1) -> LDS[cur^1]; issue global loads of tile t+2]
+    //   -> [MFMAs of k-slices 1..3] -> barrier.
+    // The LDS stores and the global loads sit in the shadow of 3/4 of the tile's MFMAs, so the
+    // only pipe bubble per K-tile is the barrier plus the first ds_read of the next tile.
     int cur = 0;
     for (int kt = kt0; kt < KT; ++kt) {
-        // prefetch the next K-tile into registers; the last iteration re-loads tile KT-1
-        // (in bounds, never stored) so the loop body has no divergent control flow
-        const int kn = min(kt + 1, KT - 1);
-        okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, kn, cin_tiles, col4, a_reg, s_reg, b_reg);
-        // keep the global loads ABOVE the MFMA block: without a fence hipcc sinks most of them
-        // next to the ds_writes and the whole memory latency is exposed every K-tile
-        asm volatile("" ::: "memory");
-
         const float* As = rd_a + cur * STAGE;
         const float* Bs = rd_b + cur * STAGE;
 #pragma unroll
@@ -248,10 +257,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_STRIDE + kk * 8);
+                af[i] = (CONV_DBG & 4) ? make_float4(acc[i][0][0], acc[i][0][1], 1.f, 2.f)
+                                       : *reinterpret_cast<const float4*>(As + i * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_STRIDE + kk * 8);
+                bf[j] = (CONV_DBG & 4) ? make_float4(acc[0][j][2], acc[0][j][3], 1.f, 2.f)
+                                       : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -272,20 +283,32 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            if (kk == 0) {
+                // stage tile t+1 (in registers since the previous iteration) into the other buffer,
+                // then issue the loads of tile t+2.  Fences pin this block between k-slice 0 and 1.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+v"(okm));   // consumers of the loaded registers stay below
+                finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
+                float* sa = st_a + (cur ^ 1) * STAGE;
+                float* sb = st_b + (cur ^ 1) * STAGE;
+                if (!(CONV_DBG & 2)) {
+#pragma unroll
+                    for (int i = 0; i < A_LD; ++i)
+                        *reinterpret_cast<float4*>(sa + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
+#pragma unroll
+                    for (int i = 0; i < B_LD; ++i)
+                        *reinterpret_cast<float4*>(sb + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
+                }
+                asm volatile("" ::: "memory");
+                if (!(CONV_DBG & 1))
+                    okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base,
+                                                                (CONV_DBG & 16) ? kt0 : min(kt + 2, KT - 1), cin_tiles,
+                                                                col4, a_reg, s_reg, b_reg);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        // stage the prefetched tile into the other buffer (harmless after the last tile).
-        // The fence keeps every consumer of the loaded registers (and so the vmcnt waits) BELOW
-        // the MFMA block.
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(okm));   // opaque here: the selects that use it cannot be hoisted
-        finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
-        float* sa = st_a + (cur ^ 1) * STAGE;
-        float* sb = st_b + (cur ^ 1) * STAGE;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(sa + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(sb + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
-        __syncthreads();
+        if (!(CONV_DBG & 8)) __syncthreads();
         cur ^= 1;
     }
 
@@ -445,8 +468,11 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return FGN_ERR_SHAPE;
+    if (KH * KW > 64) return FGN_ERR_SHAPE;                   // tap validity is a 64-bit mask
     const int k_raw = KH * KW * Cin;
     p.K = cdiv(k_raw, BK) * BK;
+    // offsets are 32-bit element indices
+    if ((long long)(n_img / a_img_div + 1) * H * W * Cin >= (1ll << 31)) return FGN_ERR_SHAPE;
     const long long M = (long long)n_img * p.Ho * p.Wo;
     if (M * (long long)Cout >= (1ll << 31) * 4) return FGN_ERR_SHAPE;
 
