@@ -46,8 +46,12 @@ struct ConvParams {
     // the slabs in a fixed order (deterministic) and applies the epilogue.
     float* ws;
     int splits, kt_per_split;
+    unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
 };
 
+#ifndef CONV_DMA_STAGES
+#define CONV_DMA_STAGES 2
+#endif
 #ifndef CONV_DBG
 #define CONV_DBG 0   // diagnostic ablations (tools only): 1 no global loads, 2 no ds_write, 4 no ds_read, 8 no barrier, 16 loads always hit the first tile
 #endif
@@ -355,6 +359,255 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (no input scale, Cin >= 32): the K-tiles go global -> LDS directly with
+// `buffer_load_dwordx4 ... lds` (16 B per lane, 1 KiB per wave-instruction), no VGPR staging,
+// no ds_write, no zero-fill selects:
+//   * out-of-image filter taps use an out-of-range buffer offset, for which the hardware
+//     writes zeros into LDS (probed on gfx950: tools_scratch/t_ldsdma.hip);
+//   * an LDS-DMA destination is lane-linear (wave base + lane*16), so tile rows are the
+//     unpadded 128 bytes and bank conflicts are removed by an XOR swizzle applied to the
+//     SOURCE chunk index and to the ds_read address alike: chunk c of row r lives at
+//     c ^ ((r>>1)&7); 16 consecutive rows at one logical chunk then cover all 16 four-bank
+//     groups of the 64-bank LDS;
+//   * NSTAGE LDS buffers: the DMA of tile t+NSTAGE-1 is in flight while tile t is multiplied;
+//     completion is tracked with a counted s_waitcnt vmcnt and a raw s_barrier.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from buffer `rs` at per-lane byte offset `voff`
+// to LDS bytes [lds_base, lds_base + 1024).  Issued through inline asm on purpose: for the
+// builtin form hipcc conservatively emits `s_waitcnt vmcnt(0)` before the next ds_read of the
+// same __shared__ array (it cannot prove the buffers distinct), which would serialise the
+// pipeline; asm loads are invisible to its counters, so completion is waited for by hand
+// (counted s_waitcnt vmcnt before the barrier).  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const i32x4& rs, unsigned lds_base, unsigned voff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_base), "s"(rs)
+        : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));   // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM * 8 / 256;
+    constexpr int B_LD = BN * 8 / 256;
+    constexpr int STAGE = (BM + BN) * BK;          // floats per stage, rows are 32 floats (128 B)
+    constexpr int LOADS = A_LD + B_LD;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;
+    const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.n_tiles_n;
+    const int tile_n = bid - tile_m * p.n_tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int HoWo = p.Ho * p.Wo;
+    int n_img = p.n_img;
+    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
+    const int M = n_img * HoWo;
+    if (m0 >= M) return;
+
+    const int col4 = t & 7;
+    const int row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);      // swizzle on the source chunk (rows row0+32i share it)
+    int a_off[A_LD];
+    unsigned long long a_taps[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        a_off[i] = 0; a_taps[i] = 0ull;
+        if (m < M) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_off[i] = ((((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + src_c4 * 4) * 4;   // bytes
+            unsigned long long tm = 0ull;
+            int tp = 0;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
+                for (int kx = 0; kx < p.KW; ++kx, ++tp)
+                    if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
+            }
+            a_taps[i] = tm;
+        }
+    }
+    const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;   // bytes; rows +32i add 32*K*4
+
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+
+    const int KT_all = p.K / BK;
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int KT = min(KT_all, kt0 + p.kt_per_split);
+    const int cin_tiles = p.Cin / BK;
+
+    // wave-uniform LDS destinations: this wave writes rows [32i + 8*wv, +8) of the A / B tile
+    // LDS byte offset of the dynamic segment = low 32 bits of its generic address
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+
+    auto issue_tile = [&](int kt, int stage) {
+        const int tap = kt / cin_tiles;
+        const int c0 = (kt - tap * cin_tiles) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;           // bytes, wave-uniform
+        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const bool ok = (a_taps[i] >> tap) & 1ull;
+            const unsigned voff = ok ? (unsigned)(a_off[i] + tap_off) : OOB;   // OOB lanes are zero-filled
+            lds_dma16(x_rs, sa + i * 32 * 128, voff);
+        }
+        const unsigned sb = sa + BM * 128;
+        const unsigned bko = (unsigned)(kt * BK * 4);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int half = lane >> 5;
+    const int rswz = (frag_row >> 1) & 7;
+    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+
+    // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue_tile(min(kt0 + s, KT - 1), s);
+    if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    for (int kt = kt0; kt < KT; ++kt) {
+        int nxt = cur + NSTAGE - 1;
+        if (nxt >= NSTAGE) nxt -= NSTAGE;
+        issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
+        asm volatile("" ::: "memory");
+
+        const float* As = rd_a + cur * STAGE;
+        const float* Bs = rd_b + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int pc = ((kk * 2 + half) ^ rswz) * 4;
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+        // tile t+1 must have landed (own DMAs counted; the barrier covers the other waves');
+        // with NSTAGE == 3 the DMAs of tile t+2 stay in flight across the barrier.
+        if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches
+
+    // ---- epilogue (same as the register-staged kernel)
+    if (p.splits > 1) {
+        float* slab = p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + frag_row;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * WM + i * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (n < p.Cout && m < M) slab[(size_t)m * p.Cout + n] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + frag_row;
+        const bool n_ok = n < p.Cout;
+        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
+        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (n_ok && m < M) {
+                    const size_t o = (size_t)m * p.Cout + n;
+                    float v = acc[i][j][r] * sc + sh;
+                    if (p.residual) v += p.residual[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
     int n_img = p.n_img;
@@ -407,7 +660,15 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         return e;
     }();
     if (attr_once != hipSuccess) return (int)attr_once;
-    if (cin4)
+    if (!cin4 && !p.in_scale && p.x_bytes != 0) {
+        constexpr int NST = (BM + BN >= 256) ? 2 : CONV_DMA_STAGES;   // 128x128 keeps 2 blocks/CU
+        const size_t dlds = (size_t)NST * (BM + BN) * BK * sizeof(float);
+        static const hipError_t dma_attr = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (dma_attr != hipSuccess) return (int)dma_attr;
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW>), grid, dim3(256), dlds, stream, p);
+    } else if (cin4)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), grid, dim3(256), lds, stream, p);
     else if (p.in_scale)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), grid, dim3(256), lds, stream, p);
@@ -439,6 +700,7 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
                                              int stride, int pad, int tile_hint) {
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0 || n_img <= 0) return 0;
+    if (tile_hint >= 100) tile_hint -= 100;
     const long long M = (long long)n_img * Ho * Wo;
     const int KT = cdiv(KH * KW * Cin, BK);
     if (tile_hint > 0 && tile_hint != 4) return 0;
@@ -481,6 +743,16 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     // 128x128 tile (2 blocks/CU) is ~10 % better only when its grid is one nearly full wave.
     int tile = tile_hint < 0 ? -tile_hint : tile_hint;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = p.K / BK;
+    {
+        // descriptor extents (< 4 GiB checked below); tile_hint >= 100 forces the register-staged kernel
+        const long long xb = (long long)((n_img + a_img_div - 1) / a_img_div) * H * W * Cin * 4;
+        const long long wb = (long long)cout_pad * p.K * 4;
+        const bool use_dma = tile_hint < 100 && xb < 0x7fffff00ll && wb < 0x7fffff00ll;
+        p.x_bytes = use_dma ? (unsigned)xb : 0u;
+        p.w_bytes = use_dma ? (unsigned)wb : 0u;
+        if (tile_hint >= 100) tile_hint -= 100;
+    }
+    tile = tile_hint < 0 ? -tile_hint : tile_hint;
     if (tile == 0) {
         const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
         tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;
