@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--workload', default='cfg3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=3)
+    ap.add_argument('--inflight', type=int, default=2, help='independent episodes in flight per GPU')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -105,6 +106,11 @@ def main():
     max_det = cfg['test_cfg']['rcnn']['max_per_img']
     from fgn_amd import dist as fdist
 
+    # Independent episodes alternate between two HIP streams, so the low-occupancy phases of
+    # one episode (proposal selection, 100-RoI mask head, small support layers) overlap with
+    # the dense phases of the next.
+    ep_streams = [torch.cuda.Stream() for _ in range(args.inflight)]
+
     def launch(i, profile=None):
         """Queue one episode's device work (asynchronous)."""
         e = episodes[i % n_distinct]
@@ -112,7 +118,13 @@ def main():
         # profiled steps run single-stream so the per-launch HIP-event durations are not
         # inflated by a concurrent kernel of the other branch
         model.use_side_stream = profile is None
-        dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'])
+        if profile is not None:
+            torch.cuda.synchronize()          # nothing else on the GPU while launches are timed
+        with torch.cuda.stream(ep_streams[i % len(ep_streams)]):
+            dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
+                                       e['img_shape'])
+        if profile is not None:
+            torch.cuda.synchronize()
         ops.PROFILE = None
         if world > 1:
             recs, cnts = fdist.pack_detections(dets, max_det)
@@ -128,13 +140,13 @@ def main():
         """Software-pipelined: episode i+1 is queued before the results of episode i are packed,
         so host-side result packing overlaps device work.  Every result is still delivered."""
         n_det = 0
-        pending = None
+        pending = []
         for i in range(n_steps):
-            cur = launch(i, prof if (prof is not None and i % prof_every == 0) else None)
-            if pending is not None:
-                n_det += len(finish(pending)[0]['dt_scores'])
-            pending = cur
-        n_det += len(finish(pending)[0]['dt_scores'])
+            pending.append(launch(i, prof if (prof is not None and i % prof_every == 0) else None))
+            if len(pending) > args.inflight:
+                n_det += len(finish(pending.pop(0))[0]['dt_scores'])
+        while pending:
+            n_det += len(finish(pending.pop(0))[0]['dt_scores'])
         return n_det
 
     run(args.warmup)
@@ -147,14 +159,14 @@ def main():
     prof = []
     barrier()
     t0 = time.perf_counter()
-    n_d = run(args.steps, prof)
+    n_d = run(args.steps, prof, prof_every=8)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_prof_steps = (args.steps + 3) // 4
+    n_prof_steps = (args.steps + 7) // 8
 
     # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
     conv_ms = 0.0
@@ -189,7 +201,7 @@ def main():
                        'avg_detections': n_d / args.steps,
                        'algorithmic_gflop_per_episode': round(gflop, 1),
                        'algorithmic_tflops': round(gflop * world * args.steps / dt / 1e3, 2)},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all instances)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel + conv_igemm_kernel (all conv launches)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                          'launches_per_step': n_launch / n_prof_steps, 'profiled_steps': n_prof_steps,
@@ -202,9 +214,31 @@ def main():
             cpu_eps = [make_batch(j, 1, **shape) for j in range(args.cpu_episodes)]
             O.simple_test(sd, cfg, **cpu_eps[0])          # warm-up
             t0 = time.perf_counter()
+            cpu_res = []
             for b in cpu_eps:
-                O.simple_test(sd, cfg, **b)
+                cpu_res.extend(O.simple_test(sd, cfg, **b))
             cdt = time.perf_counter() - t0
+            # accuracy half of the metric: AP50 (FSISEGEval protocol) of the HIP path vs the CPU path
+            # on the same episodes (seeded random weights: the absolute value is meaningless, the
+            # difference is the criterion, |dAP| <= 0.1)
+            from fgn_amd.fsiseg_eval import evaluate_results
+            model.use_side_stream = True
+            hip_res = []
+            for b in cpu_eps:
+                hip_res.extend(model.simple_test(**b, rescale=True))
+            ap_cpu, ap_hip = evaluate_results(cpu_res, cfg['n_ways']), evaluate_results(hip_res, cfg['n_ways'])
+            out['ap50_vs_cpu_ref'] = {k: {'hip': round(ap_hip[k], 4), 'cpu_ref': round(ap_cpu[k], 4)}
+                                      for k in ('bbox_mAP50', 'segm_mAP50')}
+            # and directly: AP50 of the HIP detections scored against the CPU path's detections as
+            # ground truth (1.0 = every CPU detection reproduced with IoU >= 0.5 and the same label)
+            as_gt = []
+            for c, h in zip(cpu_res, hip_res):
+                r = dict(h)
+                r['qry_bboxes'], r['qry_cat_ids'] = c['dt_bboxes'], c['dt_cat_ids']
+                r['qry_isegmaps_rle'] = c['dt_isegmaps_rle']
+                as_gt.append(r)
+            agree = evaluate_results(as_gt, cfg['n_ways'])
+            out['ap50_hip_scored_against_cpu_detections'] = {k: round(agree[k], 4) for k in ('bbox_mAP50', 'segm_mAP50')}
             out['cpu_baseline'] = {'value': args.cpu_episodes / cdt, 'unit': 'img/s',
                                    'cores': torch.get_num_threads(), 'kind': 'port',
                                    'sample': f'{args.cpu_episodes} {args.workload} episodes (after 1 warm-up) through '

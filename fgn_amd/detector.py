@@ -291,8 +291,10 @@ class FGN(torch.nn.Module):
         main = torch.cuda.current_stream()
         if self.use_side_stream:
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-            side = self._side_stream
+                self._side_stream = {}
+            side = self._side_stream.get(main.cuda_stream)     # one side stream per caller stream
+            if side is None:
+                side = self._side_stream[main.cuda_stream] = torch.cuda.Stream()
         else:
             side = main
         side.wait_stream(main)
@@ -389,7 +391,7 @@ class FGN(torch.nn.Module):
                                       rle_len=pin(batch, max_det, dtype=torch.int32),
                                       rle_ovf=pin(batch, max_det, dtype=torch.int32),
                                       rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
-                                 for _ in range(4)]
+                                 for _ in range(6)]
             self._pinned_next = 0
         slot = self._pinned_ring[self._pinned_next % len(self._pinned_ring)]
         self._pinned_next += 1
@@ -400,8 +402,10 @@ class FGN(torch.nn.Module):
         ``pack_results`` later waits on the event only, so the next batch's kernels are not
         serialised behind a host round trip."""
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream()
-        cp = self._copy_stream
+            self._copy_stream = {}
+        cp = self._copy_stream.get(main.cuda_stream)
+        if cp is None:
+            cp = self._copy_stream[main.cuda_stream] = torch.cuda.Stream()
         max_det = outs[0]['det_bboxes'].shape[0]
         slot = self._pinned_slot(len(outs), max_det)
         cp.wait_stream(main)

@@ -63,3 +63,8 @@ def test_e2e_half_width(n_ways, k_shots, hw):
             assert np.array_equal(np.asarray(ref[i][key]), np.asarray(got[i][key])), key
         assert len(got[i]['dt_isegmaps_rle']) == len(gb)
         assert got[i]['qry_isegmaps_rle'] == ref[i]['qry_isegmaps_rle']
+    # accuracy criterion of BASELINE.json: box / mask AP50 (FSISEGEval protocol) within 0.1 of the CPU path
+    from fgn_amd.fsiseg_eval import evaluate_results
+    ap_ref, ap_got = evaluate_results(ref, n_ways), evaluate_results(got, n_ways)
+    for k in ap_ref:
+        assert abs(ap_ref[k] - ap_got[k]) <= 0.1, (k, ap_ref[k], ap_got[k])

@@ -169,3 +169,40 @@ def test_episode_sharding_and_gather_world2_gloo():
     for r in out:
         assert r[2] == [0.0, 1.0, 2.0, 3.0, 4.0, 99.0]
         assert r[3] == [0, 1, 2, 3, 0, 3]
+
+
+def _res(h, w, gt_boxes, gt_cats, dt_boxes, dt_cats, dt_scores):
+    """Result dict with rectangular masks; boxes are YXYX."""
+    from fgn_amd import rle
+
+    def m(b):
+        a = np.zeros((h, w), bool)
+        a[int(b[0]):int(b[2]), int(b[1]):int(b[3])] = True
+        return rle.encode(a)
+    return {'qry_img_shape': np.array([h, w, 3]), 'qry_bboxes': np.array(gt_boxes, np.float32).reshape(-1, 4),
+            'qry_cat_ids': np.array(gt_cats, np.int64), 'qry_isegmaps_rle': [m(b) for b in gt_boxes],
+            'dt_bboxes': np.array(dt_boxes, np.float32).reshape(-1, 4), 'dt_cat_ids': np.array(dt_cats, np.int64),
+            'dt_scores': np.array(dt_scores, np.float32), 'dt_isegmaps_rle': [m(b) for b in dt_boxes]}
+
+
+def test_fsiseg_eval_known_answers():
+    from fgn_amd.fsiseg_eval import FSISEGEval, evaluate_results
+    # perfect detections -> AP = AR = 1 for both IoU types
+    r = _res(40, 50, [[2, 3, 20, 25], [10, 30, 30, 45]], [0, 1], [[2, 3, 20, 25], [10, 30, 30, 45]], [0, 1], [.9, .8])
+    out = evaluate_results([r], 2)
+    assert all(abs(out[k] - 1.0) < 1e-12 for k in ('bbox_mAP50', 'bbox_mAR', 'segm_mAP50', 'segm_mAR'))
+    # one class, 2 GT; detections by score: TP, FP, TP  -> precision envelope [1, 2/3, 2/3], recall [.5,.5,1]
+    r = _res(40, 50, [[0, 0, 10, 10], [20, 20, 30, 30]], [0, 0],
+             [[0, 0, 10, 10], [30, 0, 39, 9], [20, 20, 30, 31]], [0, 0, 0], [.9, .8, .7])
+    ev = FSISEGEval(results=[r], n_ways=1, iou_type='segm')
+    got = ev.run()
+    # recall thresholds 0..0.5 -> p=1 (6 points), 0.6..1.0 -> p=2/3 (5 points)
+    assert abs(got['mAP'] - (6 * 1.0 + 5 * 2 / 3) / 11) < 1e-9 and got['mAR'] == 1.0
+    # wrong class is a miss; category without GT and without detections is skipped (-1)
+    r = _res(40, 50, [[0, 0, 10, 10]], [1], [[0, 0, 10, 10]], [0], [.9])
+    got = FSISEGEval(results=[r], n_ways=3, iou_type='bbox').run()
+    assert got['mAP'] == 0.0 and got['mAR'] == 0.0
+    # a duplicate detection of an already matched GT is a false positive
+    r = _res(40, 50, [[0, 0, 10, 10]], [0], [[0, 0, 10, 10], [0, 0, 10, 10]], [0, 0], [.9, .8])
+    got = FSISEGEval(results=[r], n_ways=1).run()
+    assert abs(got['mAP'] - 1.0) < 1e-12       # the TP comes first, precision 1 at every recall level

@@ -12,6 +12,8 @@ SHAPES = [
     ('C sh1x1 R300 1024>512', 300, 7, 7, 1024, 512, 1, 1, 0, False),
     ('C2 sh1x1 R300 512>1024', 300, 7, 7, 512, 1024, 1, 1, 0, True),
     ('D l1 1x1 64>256', 1, 200, 334, 64, 256, 1, 1, 0, True),
+    ('Dn l1 1x1 64>256 nores', 1, 200, 334, 64, 256, 1, 1, 0, False),
+    ('Jn l2 1x1 128>512 nores', 1, 100, 167, 128, 512, 1, 1, 0, False),
     ('D2 l1 3x3 64>64', 1, 200, 334, 64, 64, 3, 1, 0, False),
     ('E sh3x3 R9', 9, 7, 7, 512, 512, 3, 1, 0, False),
     ('F l3 3x3 256', 1, 50, 84, 256, 256, 3, 1, 0, False),
