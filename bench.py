@@ -178,6 +178,16 @@ def main():
     n_launch = max(len(prof), 1)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
+    # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    # same command (tools/profile_round.sh), corrected per MI355X_MICROARCH.md; PMC collection
+    # serialises kernels, so it is read from the committed profile, not collected inside the timed run
+    traffic = None
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('conv_traffic.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    if tfiles and args.workload == 'cfg3':
+        with open(os.path.join(ROOT, 'profiles', tfiles[-1])) as fh:
+            traffic = json.load(fh).get('hbm_bytes_per_launch')
+
     if rank == 0:
         R = cfg['test_cfg']['rpn']['max_per_img']
         gflop = algorithmic_gflop(cfg, shape['height'], shape['width'], shape['spp_size'], R, n_d / args.steps)
@@ -203,7 +213,8 @@ def main():
                        'algorithmic_tflops': round(gflop * world * args.steps / dt / 1e3, 2)},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel + conv_igemm_kernel (all conv launches)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per conv launch (PMC, profiles/*conv_traffic.json)',
                          'launches_per_step': n_launch / n_prof_steps, 'profiled_steps': n_prof_steps,
                          'avg_launch_us': round(conv_ms * 1e3 / n_launch, 2),
                          'conv_ms_per_step': round(conv_ms / n_prof_steps, 3),

@@ -1,7 +1,7 @@
 """Micro-benchmark of the conv kernel on the cfg3 layer shapes (diagnostic).
 usage: python tools_conv_bench.py [tiles e.g. 0,1,2,3,4] [reps]"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fgn_amd import ops
 tiles = [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else '0,1,2,3,4').split(',')]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -1,6 +1,6 @@
 """Run one conv shape/tile repeatedly (for rocprofv3 --pmc). usage: shape_letter tile reps"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fgn_amd import ops
 letter, tile, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 SH = {'A': (3, 50, 84, 1024, 1024, 3, 1, 3, False), 'B': (300, 7, 7, 512, 512, 3, 1, 0, False),

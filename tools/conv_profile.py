@@ -1,6 +1,6 @@
 """Per-launch conv timing of one cfg3 episode (diagnostic)."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fgn_amd import ops
 from fgn_amd.config import fgn_r50_c4_config
 from fgn_amd.detector import FGN

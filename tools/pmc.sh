@@ -4,9 +4,9 @@ L=$1; T=$2
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_${L}_${T}
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES -d $OUT/p1 --output-format csv -- python $GRAFT_REPO_ROOT/tools_conv_one.py $L $T 6 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -d $OUT/p2 --output-format csv -- python $GRAFT_REPO_ROOT/tools_conv_one.py $L $T 6 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_IFETCH SQ_ACTIVE_INST_MISC -d $OUT/p3 --output-format csv -- python $GRAFT_REPO_ROOT/tools_conv_one.py $L $T 6 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES -d $OUT/p1 --output-format csv -- python $GRAFT_REPO_ROOT/tools/conv_one.py $L $T 6 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -d $OUT/p2 --output-format csv -- python $GRAFT_REPO_ROOT/tools/conv_one.py $L $T 6 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_IFETCH SQ_ACTIVE_INST_MISC -d $OUT/p3 --output-format csv -- python $GRAFT_REPO_ROOT/tools/conv_one.py $L $T 6 > /dev/null 2>&1
 python - <<PY
 import csv, glob, collections
 for p in ('p1','p2','p3'):

@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fgn_amd import ops
 from fgn_amd.config import fgn_r50_c4_config
 g = torch.Generator().manual_seed(0)

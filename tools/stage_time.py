@@ -1,6 +1,6 @@
 """Stage timing of one cfg3 episode (diagnostic, not part of the product)."""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from fgn_amd.config import fgn_r50_c4_config
 from fgn_amd.detector import FGN
 from fgn_amd.episodes import CONFIGS, make_batch
