@@ -68,3 +68,64 @@ def test_e2e_half_width(n_ways, k_shots, hw):
     ap_ref, ap_got = evaluate_results(ref, n_ways), evaluate_results(got, n_ways)
     for k in ap_ref:
         assert abs(ap_ref[k] - ap_got[k]) <= 0.1, (k, ap_ref[k], ap_got[k])
+
+
+def test_empty_detections_and_empty_proposals():
+    """Edge cases of the reference (fgn_roi_head.py:558-566, 630-632): no proposal / no detection
+    in an image -> empty results, same as the oracle."""
+    import copy
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    base = tiny_config(3, 1, width_div=2)
+    batch = make_batch(5, 1, 3, 1, 128, 160, 64)
+    cfg = copy.deepcopy(base)
+    cfg['test_cfg']['rcnn']['score_thr'] = 2.0                 # softmax scores never exceed 1
+    ref, _, got, _ = _run(cfg, batch)
+    assert len(ref[0]['dt_scores']) == 0 and len(got[0]['dt_scores']) == 0
+    assert got[0]['dt_bboxes'].shape == (0, 4) and got[0]['dt_isegmaps_rle'] == []
+    cfg = copy.deepcopy(base)
+    cfg['test_cfg']['rpn']['min_bbox_size'] = 1e6              # every proposal is filtered out
+    ref, tr_ref, got, tr = _run(cfg, batch)
+    assert len(tr_ref['proposals'][0]) == 0 and int(tr['n_props'][0]) == 0
+    assert len(ref[0]['dt_scores']) == 0 and len(got[0]['dt_scores']) == 0
+
+
+def test_e2e_five_way_build_extension():
+    """N=5 (cfg5 of BASELINE.json) has no reference semantics (the reference asserts N in {1,3},
+    fgn_roi_head.py:303-308); oracle and HIP path share the natural generalisation (columns 1::2)."""
+    from fgn_amd.config import tiny_config, with_caps
+    from fgn_amd.episodes import make_batch
+    cfg = with_caps(tiny_config(5, 2, width_div=2), rpn_max=1000)
+    batch = make_batch(3, 1, 5, 2, 160, 160, 64)
+    ref, tr_ref, got, tr = _run(cfg, batch)
+    assert abs(len(ref[0]['dt_scores']) - len(got[0]['dt_scores'])) <= 3
+    n = min(len(ref[0]['dt_scores']), len(got[0]['dt_scores']), 10)
+    assert np.allclose(ref[0]['dt_scores'][:n], got[0]['dt_scores'][:n], atol=2e-3)
+    assert set(np.unique(got[0]['dt_cat_ids'])) <= set(range(5))
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2'])
+def test_e2e_full_width_reference_configs(name):
+    """cfg1 (MNISTISEG 1-way 1-shot 128x128) and cfg2 (OMNIISEG 3-way 1-shot 256x256) of BASELINE.json
+    with the full ResNet-50-C4 widths."""
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.episodes import CONFIGS, make_batch
+    from fgn_amd.fsiseg_eval import evaluate_results
+    shape = CONFIGS[name]
+    cfg = fgn_r50_c4_config(shape['n_ways'], shape['k_shots'])
+    batch = make_batch(11, 1, **shape)
+    ref, tr_ref, got, tr = _run(cfg, batch)
+    r = tr_ref['qry_fmap']
+    assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
+    rb, gb = ref[0]['dt_bboxes'], got[0]['dt_bboxes']
+    assert abs(len(rb) - len(gb)) <= max(2, len(rb) // 20)
+    if len(rb):
+        iou = _iou(rb[:, [1, 0, 3, 2]], gb[:, [1, 0, 3, 2]])
+        ok = (iou.max(1) > 0.98) & (ref[0]['dt_cat_ids'] == got[0]['dt_cat_ids'][iou.argmax(1)])
+        assert ok.mean() >= 0.9, ok.mean()
+    # HIP detections scored against the CPU path's detections as ground truth
+    as_gt = dict(got[0])
+    as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
+    as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
+    agree = evaluate_results([as_gt], shape['n_ways'])
+    assert agree['bbox_mAP50'] >= 0.9 and agree['segm_mAP50'] >= 0.9, agree
