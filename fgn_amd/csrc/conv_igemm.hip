@@ -608,6 +608,274 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stream-K variant of the LDS-DMA kernel (128x128 tile, 4 waves of 64x64, 2 LDS stages).
+// A fixed grid of SK_BLOCKS = 2 x 256 CUs persistent workgroups splits the launch's total
+// work - (output tiles) x (K-tiles) units - into equal contiguous ranges, so every CU
+// finishes at the same time whatever the tile count.  Measured motivation (tools/
+// conv_tail_probe.py): the same kernel runs 134 TF/s at 768 tiles and 104 TF/s at 792,
+// because a data-parallel grid leaves most CUs idle during its last partial wave.
+// A range covers part of one tile, then whole tiles, then part of a last tile.  Whole tiles
+// take the fused epilogue; partial tiles store raw 128x128 accumulators to a per-(block, slot)
+// slab and streamk_fixup_kernel adds the 2-4 slabs of a split tile in ascending block order
+// (deterministic) before the same epilogue.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_BLOCKS = 512;
+constexpr int SK_TILE = 128;
+
+__device__ __forceinline__ int sk_units_per_block(int total_units) { return (total_units + SK_BLOCKS - 1) / SK_BLOCKS; }
+
+__global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p) {
+    constexpr int BM = SK_TILE, BN = SK_TILE, WM = 64, WN = 64;
+    constexpr int TM = 2, TN = 2, A_LD = 4, B_LD = 4;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    int bid = blockIdx.x;      // XCD-contiguous logical ids (SK_BLOCKS is a multiple of 8)
+    bid = (bid & 7) * (SK_BLOCKS / 8) + (bid >> 3);
+
+    const int HoWo = p.Ho * p.Wo;
+    int n_img = p.n_img;
+    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
+    const int M = n_img * HoWo;
+    const int KT = p.K / BK;
+    const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
+    const int total = tiles * KT;
+    const int per = sk_units_per_block(total);
+    int u = bid * per;
+    const int u_end = min(u + per, total);
+    if (u >= u_end) return;
+
+    const int col4 = t & 7;
+    const int row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const int cin_tiles = p.Cin / BK;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    const int frag_row = lane & 31;
+    const int half = lane >> 5;
+    const int rswz = (frag_row >> 1) & 7;
+    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+    float* const my_slabs = p.ws + (size_t)bid * 2 * (SK_TILE * SK_TILE);
+
+    while (u < u_end) {
+        const int tile = u / KT;
+        const int kb = u - tile * KT;
+        const int ke = min(KT, kb + (u_end - u));
+        const bool first_seg = (u == bid * per);
+        u += ke - kb;
+        const int tile_m = tile / p.n_tiles_n;
+        const int tile_n = tile - tile_m * p.n_tiles_n;
+        const int m0 = tile_m * BM;
+        const int n0 = tile_n * BN;
+
+        int a_off[A_LD];
+        unsigned long long a_taps[A_LD];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_off[i] = 0; a_taps[i] = 0ull;
+            if (m < M) {
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                a_off[i] = ((((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + src_c4 * 4) * 4;
+                unsigned long long tm = 0ull;
+                int tp = 0;
+                for (int ky = 0; ky < p.KH; ++ky) {
+                    const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
+                    for (int kx = 0; kx < p.KW; ++kx, ++tp)
+                        if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
+                }
+                a_taps[i] = tm;
+            }
+        }
+        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+
+        auto issue_tile = [&](int kt, int stage) {
+            const int tap = kt / cin_tiles;
+            const int c0 = (kt - tap * cin_tiles) * BK;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;
+            const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = (a_taps[i] >> tap) & 1ull;
+                lds_dma16(x_rs, sa + i * 32 * 128, ok ? (unsigned)(a_off[i] + tap_off) : OOB);
+            }
+            const unsigned sb = sa + BM * 128;
+            const unsigned bko = (unsigned)(kt * BK * 4);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // all waves are past the previous segment's LDS reads (barrier at the end of its loop)
+        issue_tile(kb, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            issue_tile(min(kt + 1, ke - 1), cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int pc = ((kk * 2 + half) ^ rswz) * 4;
+                float4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+
+        if (kb == 0 && ke == KT) {
+            // whole tile: fused epilogue
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 32 + frag_row;
+                const bool n_ok = n < p.Cout;
+                const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
+                const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + wm * WM + i * 32 + 4 * half;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (n_ok && m < M) {
+                            const size_t o = (size_t)m * p.Cout + n;
+                            float v = acc[i][j][r] * sc + sh;
+                            if (p.residual) v += p.residual[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.y[o] = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            // partial tile: raw accumulators to this block's slab (slot 0 = the block's first
+            // segment, slot 1 = a later one, which can only be its last)
+            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WN + j * 32 + frag_row;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rb = wm * WM + i * 32 + 4 * half;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[(rb + (r & 3) + 8 * (r >> 2)) * SK_TILE + col] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// one workgroup per output tile: sums the slabs of a split tile in ascending block order
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const ConvParams p) {
+    const int HoWo = p.Ho * p.Wo;
+    int n_img = p.n_img;
+    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
+    const int M = n_img * HoWo;
+    const int KT = p.K / BK;
+    const int tiles = ((M + SK_TILE - 1) / SK_TILE) * p.n_tiles_n;
+    const int tile = blockIdx.x;
+    if (tile >= tiles) return;
+    const int per = sk_units_per_block(tiles * KT);
+    const int b_lo = (tile * KT) / per, b_hi = ((tile + 1) * KT - 1) / per;
+    if (b_lo == b_hi) return;                          // produced whole by one block
+    const int tile_m = tile / p.n_tiles_n, tile_n = tile - tile_m * p.n_tiles_n;
+    const int m0 = tile_m * SK_TILE, n0 = tile_n * SK_TILE;
+    for (int e = threadIdx.x; e < SK_TILE * SK_TILE / 4; e += 256) {
+        const int row = e >> 5, c4 = (e & 31) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m >= M || n >= p.Cout) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = b_lo; b <= b_hi; ++b) {
+            const int slot = (max(tile * KT, b * per) == b * per) ? 0 : 1;
+            const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)b * 2 + slot) * (SK_TILE * SK_TILE) +
+                                                              row * SK_TILE + c4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (p.scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+            a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w;
+        }
+        if (p.shift) {
+            const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+            a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w;
+        }
+        const size_t o = (size_t)m * p.Cout + n;
+        if (p.residual) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        if (p.relu) {
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(p.y + o) = a;
+    }
+}
+
+static int launch_streamk(const ConvParams& p0, int M_max, hipStream_t stream) {
+    ConvParams p = p0;
+    p.n_tiles_n = cdiv(p.Cout, SK_TILE);
+    const size_t dlds = (size_t)2 * (SK_TILE + SK_TILE) * BK * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(conv_streamk_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
+    FGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(streamk_fixup_kernel, dim3(cdiv(M_max, SK_TILE) * p.n_tiles_n), dim3(256), 0, stream, p);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
     int n_img = p.n_img;
@@ -696,6 +964,16 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
     return s < 2 ? 1 : s;
 }
 
+// Stream-K pays for deep reductions (K >= 2048) with >= 24 K-tiles of work per persistent block
+// (measured, tools/conv_bench.py: 3x3 convs on >= 100 RoIs, the AG-RPN conv); tile_hint 5 forces it (tests), any other non-zero hint disables it.
+static bool use_streamk(long long M, int Cin, int Cout, int KT, int tile_hint) {
+    if (Cin == 4 || (Cout % 4) != 0) return false;
+    if (tile_hint == 5) return true;
+    if (tile_hint != 0) return false;
+    const long long tiles = ((M + SK_TILE - 1) / SK_TILE) * cdiv(Cout, SK_TILE);
+    return Cout >= 128 && KT >= 64 && tiles * KT >= (long long)SK_BLOCKS * 24;
+}
+
 extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
                                              int stride, int pad, int tile_hint) {
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -703,6 +981,7 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     if (tile_hint >= 100) tile_hint -= 100;
     const long long M = (long long)n_img * Ho * Wo;
     const int KT = cdiv(KH * KW * Cin, BK);
+    if (use_streamk(M, Cin, Cout, KT, tile_hint)) return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
     if (tile_hint > 0 && tile_hint != 4) return 0;
     const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
     if (tile_hint == 0 && b128 >= 400 && b128 <= 512) return 0;
@@ -753,6 +1032,13 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         if (tile_hint >= 100) tile_hint -= 100;
     }
     tile = tile_hint < 0 ? -tile_hint : tile_hint;
+    if (p.x_bytes && !in_scale && splitk_ws &&
+        splitk_ws_bytes >= (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float) &&
+        use_streamk(M, Cin, Cout, p.K / BK, tile_hint)) {
+        p.ws = splitk_ws;
+        return launch_streamk(p, (int)M, stream);
+    }
+    if (tile == 5) tile = 1;       // stream-K not applicable here
     if (tile == 0) {
         const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
         tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;

@@ -357,3 +357,30 @@ extern "C" int fgn_gather_support_vectors_f32(const float* table, const int64_t*
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
+
+// out[n][p][c] = x[n / div][p][c] * v[n][c]: the AG-RPN guidance multiply materialised
+// (fgn_ag_rpn_head.py:44-46) so that the 3x3 RPN conv can run on the LDS-DMA stream-K kernel,
+// which has no register stage to scale in.  HBM-bound: 1 read of x per class + 1 write.
+__global__ void scale_channels_kernel(const float4* __restrict__ x, const float4* __restrict__ v,
+                                      float4* __restrict__ out, int div, long long PC4, int C4, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / PC4, r = i - n * PC4;
+        const float4 a = x[(n / div) * PC4 + r];
+        const float4 s = v[n * C4 + (r % C4)];
+        out[i] = make_float4(a.x * s.x, a.y * s.y, a.z * s.z, a.w * s.w);
+    }
+}
+
+extern "C" int fgn_scale_channels_f32(const float* x, const float* v, float* out, int n_out, int div, int P, int C,
+                                      hipStream_t stream) {
+    if (!x || !v || !out) return FGN_ERR_ARG;
+    if (C % 4 || div < 1) return FGN_ERR_SHAPE;
+    const long long pc4 = (long long)P * C / 4, total = pc4 * n_out;
+    if (total == 0) return FGN_OK;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<const float4*>(v), reinterpret_cast<float4*>(out), div, pc4, C / 4, total);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}

@@ -325,7 +325,9 @@ class FGN(torch.nn.Module):
 
         # ---- AG-RPN (fgn_ag_rpn_head.py:26-118) -------------------------------------------
         main.wait_event(vec_ready)
-        x = ops.conv2d(qry_fmap, P['rpn_conv'], in_scale=vec, a_img_div=N)      # guidance fused
+        # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
+        # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
+        x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)

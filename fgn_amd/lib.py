@@ -25,6 +25,7 @@ SIGNATURES = {
     'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_roi_align_mask_u8': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_support_class_vectors_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'fgn_scale_channels_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_support_kmean_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_gather_support_vectors_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p]),

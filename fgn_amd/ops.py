@@ -222,6 +222,20 @@ def support_class_vectors(x: torch.Tensor, weights: Optional[torch.Tensor], n_gr
     return out
 
 
+def scale_channels(x: torch.Tensor, v: torch.Tensor, div: int) -> torch.Tensor:
+    """x [n_in, ..., C], v [n_in*div, C] -> [n_in*div, ..., C] = x[n // div] * v[n]."""
+    _chk(x, 'x')
+    _chk(v, 'v')
+    n_out, c = v.shape
+    if x.shape[0] * div != n_out or x.shape[-1] != c:
+        raise _lib.FgnHipError('scale_channels: operand shapes inconsistent')
+    out = torch.empty((n_out,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    p = x[0].numel() // c
+    _lib.check(_lib.load().fgn_scale_channels_f32(_ptr(x), _ptr(v), _ptr(out), n_out, div, p, c, _stream()),
+               'fgn_scale_channels_f32')
+    return out
+
+
 def support_kmean(x: torch.Tensor, n_groups: int, k: int) -> torch.Tensor:
     _chk(x, 'x')
     if x.shape[0] != n_groups * k:

@@ -44,7 +44,8 @@ int fgn_abi_version(void);
  *   cout_pad multiple of 128, zero rows)   y [n_img, Ho, Wo, Cout]
  *   scale/shift [Cout] or NULL; residual like y or NULL; in_scale [n_img, Cin] or NULL
  *   Cin must be a multiple of 32, or exactly 4 (stem, NHWC4 input)
- *   tile_hint 0 = auto, 1..4 = force a tile configuration, negative = same without split-K (tests)
+ *   tile_hint 0 = auto, 1..4 = force a tile configuration, 5 = stream-K, negative = no split-K,
+ *   +100 = register-staged loader instead of LDS-DMA (tests)
  *   splitk_ws: optional workspace of fgn_conv2d_workspace_bytes() bytes; when given and the plain
  *   grid would under-fill the GPU, K is split over blockIdx.y into slabs that a second kernel
  *   sums in a fixed order (bit-reproducible) before the epilogue.  NULL = never split. */
@@ -83,6 +84,11 @@ int fgn_support_kmean_f32(const float* x, float* out, int n_groups, int K, int P
 /* out[i][:] = table[labels[i] + n_ways*img(i)][:]  (fgn_roi_head.py:707-714); rois may be NULL (img 0) */
 int fgn_gather_support_vectors_f32(const float* table, const int64_t* labels, const float* rois, float* out,
                                    const int32_t* n_dev, int n, int n_ways, int C, void* stream);
+
+/* out[n][p][c] = x[n / div][p][c] * v[n][c]  (guidance multiply, fgn_ag_rpn_head.py:44-46, materialised
+ * for the stream-K conv kernel); x [n_out/div, P, C], v [n_out, C], out [n_out, P, C] */
+int fgn_scale_channels_f32(const float* x, const float* v, float* out, int n_out, int div, int P, int C,
+                           void* stream);
 
 /* Fused tail of count_one_roi_by_n_spp + BBoxHead.forward (fgn_roi_head.py:253-279,338):
  * x = Q[r] + S[img*N+n]; GroupNorm(32)+ReLU; 7x7 avg-pool; fc_cls/fc_reg.
