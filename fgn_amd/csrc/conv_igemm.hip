@@ -403,7 +403,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
     return r;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES>
+// PW = point-wise fast path (1x1, stride 1, no padding, a_img_div 1): im2col is the identity, so
+// the per-row index decode (integer divisions) and the tap masks are compiled out.  These layers
+// have K of 64..1024, i.e. 2..32 K-tiles, and are otherwise dominated by prologue instructions.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, bool PW>
 __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
@@ -447,7 +450,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + row0 + 32 * i;
         a_off[i] = 0; a_taps[i] = 0ull;
-        if (m < M) {
+        if (PW) {
+            a_off[i] = (m * p.Cin + src_c4 * 4) * 4;
+            a_taps[i] = m < M ? 1ull : 0ull;
+        } else if (m < M) {
             const int img = m / HoWo;
             const int rem = m - img * HoWo;
             const int oy = rem / p.Wo;
@@ -480,10 +486,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
 
     auto issue_tile = [&](int kt, int stage) {
-        const int tap = kt / cin_tiles;
-        const int c0 = (kt - tap * cin_tiles) * BK;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;           // bytes, wave-uniform
+        int tap = 0, tap_off = kt * BK * 4;
+        if (!PW) {
+            tap = kt / cin_tiles;
+            const int c0 = (kt - tap * cin_tiles) * BK;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;           // bytes, wave-uniform
+        }
         const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
@@ -931,11 +940,22 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     if (!cin4 && !p.in_scale && p.x_bytes != 0) {
         constexpr int NST = (BM + BN >= 256) ? 2 : CONV_DMA_STAGES;   // 128x128 keeps 2 blocks/CU
         const size_t dlds = (size_t)NST * (BM + BN) * BK * sizeof(float);
-        static const hipError_t dma_attr = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static const hipError_t dma_attr = [] {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, true>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return e;
+        }();
         if (dma_attr != hipSuccess) return (int)dma_attr;
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW>), grid, dim3(256), dlds, stream, p);
+        const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
+        if (pw)
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, true>), grid, dim3(256), dlds, stream, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, false>), grid, dim3(256), dlds, stream, p);
     } else if (cin4)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), grid, dim3(256), lds, stream, p);
     else if (p.in_scale)

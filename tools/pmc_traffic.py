@@ -9,7 +9,7 @@ def collect(d, counter):
     tot, n = 0.0, 0
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and 'conv_igemm' in r['Kernel_Name']:
+            if r['Counter_Name'] == counter and ('conv_igemm' in r['Kernel_Name'] or 'conv_streamk' in r['Kernel_Name']):
                 tot += float(r['Counter_Value'])
                 n += 1
     return tot, n
