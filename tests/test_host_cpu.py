@@ -206,3 +206,33 @@ def test_fsiseg_eval_known_answers():
     r = _res(40, 50, [[0, 0, 10, 10]], [0], [[0, 0, 10, 10], [0, 0, 10, 10]], [0, 0], [.9, .8])
     got = FSISEGEval(results=[r], n_ways=1).run()
     assert abs(got['mAP'] - 1.0) < 1e-12       # the TP comes first, precision 1 at every recall level
+
+
+def test_synthetic_dataset_contract_and_evaluate(tmp_path):
+    """BaseFewShotISEG surface used by the eval loop: len/getitem sample dict, chunked pickles, evaluate keys."""
+    from torch.utils.data import DataLoader
+    from fgn_amd.episodes import collate
+    from fgn_amd.fewshot_ds import SyntheticFewShotISEG, write_chunked
+    ds = SyntheticFewShotISEG(3, 2, length=5, height=70, width=90, spp_img_size=32, batch=2)
+    assert len(ds) == 5 and (ds.height, ds.width) == (64, 80)          # x16 rounding for batch > 1
+    s = ds[3]
+    for key in ('idx', 'qry_child_idx', 'qry_img', 'qry_cat_ids', 'qry_bboxes', 'qry_isegmaps', 'spp_imgs',
+                'spp_bboxes', 'spp_isegmaps', 'cats_ids_to_sample_real', 'spp_insts_ids', 'img_shape'):
+        assert key in s
+    batches = list(DataLoader(ds, batch_size=ds.batch, collate_fn=collate))
+    assert len(batches) == 3 and batches[0]['qry_img'].shape == (2, 3, 64, 80)
+    # fake "perfect" results: detections = ground truth
+    fake = []
+    for b in batches:
+        one = []
+        for i in range(b['qry_img'].shape[0]):
+            gt = b['qry_isegmaps'][i].numpy()
+            one.append(_res(64, 80, b['qry_bboxes'][i].numpy().tolist(), b['qry_cat_ids'][i].tolist(),
+                            b['qry_bboxes'][i].numpy().tolist(), b['qry_cat_ids'][i].tolist(),
+                            [0.9] * len(gt)))
+        fake.append(one)
+    write_chunked(iter(fake), str(tmp_path / 'ResultsChunked'), chunk=2)
+    assert sorted(os.listdir(tmp_path / 'ResultsChunked')) == ['00.pkl', '01.pkl', '02.pkl']
+    m = ds.evaluate(results_pkl_dir_fp=str(tmp_path / 'ResultsChunked'))
+    assert set(m) == {'isegm_mAP', 'isegm_mAR', 'bbox_mAP', 'bbox_mAR'}
+    assert m['bbox_mAP'] > 0.99 and m['isegm_mAP'] > 0.99
