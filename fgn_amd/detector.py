@@ -302,21 +302,8 @@ class FGN(torch.nn.Module):
             spp_fmaps = self.extract_feat(spp)                  # [B*N*K,s,s,C]
             vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
             vec_ready = side.record_event()
-            # ---- count_spp (fgn_roi_head.py:419-449) --------------------------------------
-            bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
-            spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
-            masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
-            # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
-            sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
-            sfeat = self._shared_head(sfeat)
-            cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
-            cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
-            S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
-            spp_ready = side.record_event()
         for tns in (spp, spp_xyxy, spp_masks):              # allocated on main, consumed on side
             tns.record_stream(side)
-        for tns in (spp_fmaps, vec, S, cat_mean, cat_mean_mp, masks7):   # produced on side, consumed on main
-            tns.record_stream(main)
 
         qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
         fh, fw, C = qry_fmap.shape[1:]
@@ -331,6 +318,26 @@ class FGN(torch.nn.Module):
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)
+        rpn_done = main.record_event()
+
+        # ---- count_spp (fgn_roi_head.py:419-449) on the side stream, released only now: its
+        # 9-RoI launches occupy a handful of CUs and so does the single-workgroup proposal
+        # kernel - they run beside each other instead of slowing the dense AG-RPN conv
+        with torch.cuda.stream(side):
+            side.wait_event(rpn_done)
+            bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
+            spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
+            masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
+            # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
+            sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
+            sfeat = self._shared_head(sfeat)
+            cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
+            cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
+            S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
+            spp_ready = side.record_event()
+        for tns in (spp_fmaps, vec, S, cat_mean, cat_mean_mp, masks7):   # produced on side, consumed on main
+            tns.record_stream(main)
+
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
         if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
             raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
