@@ -34,7 +34,7 @@ __global__ __launch_bounds__(POST_THREADS) void det_post_kernel(const DetParams 
     uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);
     int* misc = reinterpret_cast<int*>(keys + p.cap);   // [0] counter, [2] kept count, [4..20) wave scratch
     unsigned long long* sup = reinterpret_cast<unsigned long long*>(misc + 64);   // 8-byte aligned
-    NmsBox* kept = reinterpret_cast<NmsBox*>(sup + NMS_ROUND * 4);
+    NmsBox* kept = reinterpret_cast<NmsBox*>(sup + NMS_ROUND * NMS_WORDS);
     NmsBox* cand = kept + p.max_out;
     int* flags = reinterpret_cast<int*>(cand + NMS_ROUND);
     int* keep = flags + NMS_ROUND + 2;
@@ -187,7 +187,7 @@ extern "C" int fgn_det_post_f32(const float* rois, const float* cls_raw, const f
     for (int i = 0; i < 4; ++i) { p.mean[i] = means4[i]; p.stdv[i] = stds4[i]; }
     p.max_ratio = max_ratio; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_per_img;
     const size_t lds = (size_t)cap * 8 + 64 * 4 + (size_t)max_per_img * sizeof(NmsBox) +
-                       NMS_ROUND * sizeof(NmsBox) + NMS_ROUND * 4 * 8 + (NMS_ROUND + 2) * 4 + (size_t)max_per_img * 4 + (size_t)cap * 4;
+                       NMS_ROUND * sizeof(NmsBox) + NMS_ROUND * NMS_WORDS * 8 + (NMS_ROUND + 2) * 4 + (size_t)max_per_img * 4 + (size_t)cap * 4;
     static const hipError_t attr_once = hipFuncSetAttribute(
         reinterpret_cast<const void*>(det_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_once != hipSuccess) return (int)attr_once;

@@ -126,23 +126,28 @@ __device__ __forceinline__ bool iou_gt(const NmsBox& a, const NmsBox& b, float t
 // Greedy NMS over boxes already sorted by (score desc, index asc).
 //   boxes : global, n x float4 (x1,y1,x2,y2) in sorted order
 //   keep  : LDS int [max_out]  sorted positions of the kept boxes (output)
-//   kept  : LDS NmsBox [max_out], cand : LDS NmsBox [NMS_ROUND], sup : LDS u64 [NMS_ROUND*4],
+//   kept  : LDS NmsBox [max_out], cand : LDS NmsBox [NMS_ROUND], sup : LDS u64 [NMS_ROUND*NMS_WORDS],
 //   flags : LDS int [NMS_ROUND + 1]  (alive flags, last = kept counter)
 // Exactly the sequential greedy result: a box is kept iff no previously kept box has IoU > thr
 // with it; stops after max_out kept boxes.  Returns the number kept (uniform).
-// Rounds of 256 candidates:
+// Rounds of NMS_ROUND = 128 candidates (fewer IoU tests in total than 256-wide rounds):
 //   A. all 1024 threads test the candidates against the boxes kept in earlier rounds
-//      (4 threads per candidate split the kept list),
-//   M. all threads build the 256x256 suppression bit matrix of the round (64 tests each),
+//      (8 threads per candidate split the kept list),
+//   M. all threads build the 128x128 suppression bit matrix of the round (16 tests each),
 //   S. wave 0 walks the round in score order using only scalar bit operations and
 //      v_readlane on register-held matrix rows: ~50 cycles per kept box, no LDS, no barrier.
-constexpr int NMS_ROUND = 256;
+constexpr int NMS_ROUND = 128;                       // candidates per round
+constexpr int NMS_WORDS = NMS_ROUND / 64;            // u64 words per suppression row
+constexpr int NMS_PARTS = POST_THREADS / NMS_ROUND;  // threads per candidate
+constexpr int NMS_PART_BITS = NMS_ROUND / NMS_PARTS; // matrix bits each thread computes (16)
+static_assert(NMS_PART_BITS == 16, "suppression rows are stored as 16-bit pieces");
 
 __device__ inline int nms_sorted_block(const float4* __restrict__ boxes, int n, float thr, int max_out,
                                        int* keep, NmsBox* kept, NmsBox* cand, unsigned long long* sup,
                                        int* flags) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int* kept_cnt_sh = flags + NMS_ROUND;
+    unsigned short* sup16 = reinterpret_cast<unsigned short*>(sup);   // [NMS_ROUND][NMS_PARTS] == rows of NMS_WORDS u64
     if (t == 0) *kept_cnt_sh = 0;
     __syncthreads();
     int kept_cnt = 0;
@@ -158,42 +163,43 @@ __device__ inline int nms_sorted_block(const float4* __restrict__ boxes, int n, 
             flags[t] = t < nb ? 1 : 0;
         }
         __syncthreads();
-        const int c = t & (NMS_ROUND - 1), part = t >> 8;   // 4 threads per candidate
+        const int c = t & (NMS_ROUND - 1), part = t / NMS_ROUND;   // NMS_PARTS threads per candidate
         const NmsBox cb = cand[c];
         // ---- A: against boxes kept in earlier rounds
         {
             bool dead = false;
-            for (int j = part; j < kept_cnt; j += 4)
+            for (int j = part; j < kept_cnt; j += NMS_PARTS)
                 if (iou_gt(kept[j], cb, thr)) dead = true;
             if (dead) flags[c] = 0;    // benign race: every writer stores 0
         }
-        // ---- M: bit (w*64+b) of row c  <=>  box c suppresses the later box w*64+b of this round
+        // ---- M: bit c2 of row c  <=>  box c suppresses the later box c2 of this round
         {
-            const int w = part;
-            unsigned long long bits = 0ull;
-            if (w * 64 + 63 > c && c < nb) {
-                for (int b2 = 0; b2 < 64; ++b2) {
-                    const int c2 = w * 64 + b2;
-                    if (c2 > c && c2 < nb && iou_gt(cb, cand[c2], thr)) bits |= 1ull << b2;
+            unsigned bits = 0u;
+            const int c2_0 = part * NMS_PART_BITS;
+            if (c2_0 + NMS_PART_BITS - 1 > c && c < nb) {
+#pragma unroll 4
+                for (int b2 = 0; b2 < NMS_PART_BITS; ++b2) {
+                    const int c2 = c2_0 + b2;
+                    if (c2 > c && c2 < nb && iou_gt(cb, cand[c2], thr)) bits |= 1u << b2;
                 }
             }
-            sup[c * 4 + w] = bits;
+            sup16[c * NMS_PARTS + part] = (unsigned short)bits;
         }
         __syncthreads();
         // ---- S: serial resolution by wave 0
         if (wv == 0) {
             int kcur = kept_cnt;
-            unsigned long long removed[4];
+            unsigned long long removed[NMS_WORDS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) removed[q] = ~__ballot(flags[q * 64 + lane] != 0);
+            for (int q = 0; q < NMS_WORDS; ++q) removed[q] = ~__ballot(flags[q * 64 + lane] != 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NMS_WORDS; ++q) {
                 if (q * 64 >= nb || kcur >= max_out) break;
                 // this chunk's matrix rows, one candidate per lane, in registers
-                unsigned rl[4], rh[4];
+                unsigned rl[NMS_WORDS], rh[NMS_WORDS];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned long long r = sup[(q * 64 + lane) * 4 + w];
+                for (int w = 0; w < NMS_WORDS; ++w) {
+                    const unsigned long long r = sup[(q * 64 + lane) * NMS_WORDS + w];
                     rl[w] = (unsigned)r;
                     rh[w] = (unsigned)(r >> 32);
                 }
@@ -203,7 +209,7 @@ __device__ inline int nms_sorted_block(const float4* __restrict__ boxes, int n, 
                     if (lane == 0) keep[kcur] = base + q * 64 + f;
                     ++kcur;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
+                    for (int w = 0; w < NMS_WORDS; ++w) {
                         const unsigned long long r =
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rh[w], f) << 32) |
                             (unsigned)__builtin_amdgcn_readlane((int)rl[w], f);
