@@ -66,7 +66,7 @@ def main():
     ap.add_argument('--workload', default='cfg3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=3)
-    ap.add_argument('--inflight', type=int, default=2, help='independent episodes in flight per GPU')
+    ap.add_argument('--inflight', type=int, default=1, help='independent episodes in flight per GPU')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -123,12 +123,14 @@ def main():
         with torch.cuda.stream(ep_streams[i % len(ep_streams)]):
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
                                        e['img_shape'])
+            if world > 1:
+                # one RCCL all-gather of fixed-size padded records per step, queued on the episode's
+                # stream right behind its kernels (no host synchronisation)
+                recs, cnts = fdist.pack_detections(dets, max_det)
+                fdist.gather_detections(recs, cnts)
         if profile is not None:
             torch.cuda.synchronize()
         ops.PROFILE = None
-        if world > 1:
-            recs, cnts = fdist.pack_detections(dets, max_det)
-            fdist.gather_detections(recs, cnts)          # one RCCL all-gather of padded records
         return e, dets
 
     def finish(pending):

@@ -129,3 +129,28 @@ def test_e2e_full_width_reference_configs(name):
     as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
     agree = evaluate_results([as_gt], shape['n_ways'])
     assert agree['bbox_mAP50'] >= 0.9 and agree['segm_mAP50'] >= 0.9, agree
+
+
+def test_rccl_gather_single_rank():
+    """The collective of the multi-GPU path (one all_gather_into_tensor of padded detection records) on
+    the RCCL backend; one rank is all a 1-GPU box can host, the N>1 layout is covered by the gloo test."""
+    import os
+    import torch.distributed as dist
+    from fgn_amd import dist as fd
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        dets = [dict(det_bboxes=torch.rand(100, 5, device='cuda'), det_labels=torch.randint(0, 3, (100,), device='cuda'),
+                     n_dets=torch.tensor([37], dtype=torch.int32, device='cuda'))]
+        recs, cnts = fd.pack_detections(dets, 100)
+        # world size 1 short-circuits in gather_detections; call the collective directly as it does
+        msg = torch.cat([recs.reshape(1, -1), cnts.to(recs.dtype)[:, None]], 1).contiguous()
+        out = torch.empty_like(msg)
+        dist.all_gather_into_tensor(out, msg)
+        torch.cuda.synchronize()
+        assert torch.equal(out, msg)
+        g_recs, g_cnts = fd.gather_detections(recs, cnts)
+        assert g_recs.shape == (1, 1, 100, 6) and int(g_cnts[0, 0]) == 37
+    finally:
+        dist.destroy_process_group()
