@@ -21,10 +21,14 @@
 //   Epilogue  :  y = acc*scale[n] + shift[n] (+ residual) (ReLU)  -- folded
 //     eval-mode BN or conv bias -- written straight from the accumulators
 //     (each half-wave stores 128 contiguous bytes of one output pixel).
-//   Fusions   :  optional per-(image, cin) input scale applied while staging A:
-//     the AG-RPN guidance multiply (fgn_ag_rpn_head.py:44) and the mask-head
-//     support-vector multiply (fgn_roi_head.py:379) never materialise their
-//     [N*B,1024,H,W] product; `a_img_div` lets N guided passes share one query map.
+//   Fusions   :  optional per-(image, cin) input scale applied while staging A (register-staged
+//     kernel only): used for the mask-head support-vector multiply (fgn_roi_head.py:379);
+//     `a_img_div` lets several output images read one input image.  The AG-RPN guidance
+//     multiply (fgn_ag_rpn_head.py:44) is materialised instead (fgn_scale_channels_f32, 20 us)
+//     so that its 238 GFLOP conv can use the LDS-DMA stream-K kernel below.
+//   Kernels   :  conv_igemm_kernel (register-staged loader), conv_igemm_dma_kernel (LDS-DMA
+//     loader, optional split-K), conv_streamk_kernel (LDS-DMA, persistent stream-K); the
+//     dispatcher at the bottom of the file picks one per launch.
 #include "common.h"
 
 struct ConvParams {

@@ -87,13 +87,6 @@ extern "C" int fgn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n_img, in
 // bilinear_interpolate: outside [-1,size] -> 0, coordinates clamped at 0, the last
 // row/column snaps.
 // ----------------------------------------------------------------------------------
-template <typename T>
-struct PixVec;
-template <>
-struct PixVec<float> {
-    static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
-};
-
 struct AxisSample {
     int lo, hi;
     float l, h;
