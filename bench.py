@@ -26,6 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DATASET = {'cfg1': 'MNISTISEG', 'cfg2': 'OMNIISEG', 'cfg3': 'COCO2VOC', 'cfg4': 'COCO2VOC', 'cfg5': 'COCO2VOC'}
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -85,13 +86,14 @@ def main():
     from fgn_amd import ops
     from fgn_amd.config import fgn_r50_c4_config
     from fgn_amd.detector import FGN
-    from fgn_amd.episodes import CONFIGS, make_batch
+    from fgn_amd.config import with_caps
+    from fgn_amd.episodes import CONFIGS, RPN_MAX_PER_IMG, make_batch
     from fgn_amd.weights import init_state_dict
 
     shape = CONFIGS[args.workload]
-    cfg = fgn_r50_c4_config(shape['n_ways'], shape['k_shots'])
+    cfg = with_caps(fgn_r50_c4_config(shape['n_ways'], shape['k_shots']), rpn_max=RPN_MAX_PER_IMG.get(args.workload))
     sd = init_state_dict(cfg, 0)
-    model = FGN(cfg['n_ways'], cfg['k_shots'], state_dict=sd)
+    model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
 
     # distinct seeded episodes per rank, inputs resident in HBM before timing
     n_distinct = 4
@@ -206,7 +208,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': f'{args.workload}: COCO2VOC {shape["n_ways"]}-way {shape["k_shots"]}-shot, '
+            'config': {'workload': f'{args.workload}: {DATASET.get(args.workload, "synthetic")} {shape["n_ways"]}-way {shape["k_shots"]}-shot, '
                                    f'query 3x{shape["height"]}x{shape["width"]}, supports '
                                    f'{shape["n_ways"] * shape["k_shots"]}x3x{shape["spp_size"]}^2, ResNet-50-C4, '
                                    f'R<={R} proposals, D<={max_det} detections, 1 episode per GPU per step',

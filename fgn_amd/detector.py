@@ -312,19 +312,20 @@ class FGN(torch.nn.Module):
 
         # ---- AG-RPN (fgn_ag_rpn_head.py:26-118) -------------------------------------------
         main.wait_event(vec_ready)
+        rpn_start = main.record_event()
         # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
         # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
         x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)
-        rpn_done = main.record_event()
 
-        # ---- count_spp (fgn_roi_head.py:419-449) on the side stream, released only now: its
-        # 9-RoI launches occupy a handful of CUs and so does the single-workgroup proposal
-        # kernel - they run beside each other instead of slowing the dense AG-RPN conv
+        # ---- count_spp (fgn_roi_head.py:419-449) on the side stream, released when the AG-RPN conv
+        # starts: its ~30 tiny 9-RoI launches (0.3 ms end to end, a handful of CUs each) hide under
+        # the 2 ms stream-K conv and the single-workgroup proposal kernel instead of delaying the
+        # query backbone or the RoI head
         with torch.cuda.stream(side):
-            side.wait_event(rpn_done)
+            side.wait_event(rpn_start)
             bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
             spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
             masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)

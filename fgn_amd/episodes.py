@@ -109,4 +109,7 @@ CONFIGS = {
     'cfg2': dict(n_ways=3, k_shots=1, height=256, width=256, spp_size=128),
     'cfg3': dict(n_ways=3, k_shots=3, height=800, width=1333, spp_size=256),
     'cfg4': dict(n_ways=3, k_shots=3, height=800, width=1328, spp_size=256),
+    # 5-way 5-shot, 1000 proposals: a build extension, the reference asserts N in {1,3}
+    'cfg5': dict(n_ways=5, k_shots=5, height=1024, width=1024, spp_size=256),
 }
+RPN_MAX_PER_IMG = {'cfg5': 1000}
