@@ -154,3 +154,72 @@ def test_rccl_gather_single_rank():
         assert g_recs.shape == (1, 1, 100, 6) and int(g_cnts[0, 0]) == 37
     finally:
         dist.destroy_process_group()
+
+
+def test_cfg3_full_size_parity_and_invariants():
+    """The headline configuration itself (3-way 3-shot, 800x1333, full ResNet-50-C4, R<=300, D<=100):
+    parity against the oracle, plus size-independent properties of the output."""
+    from fgn_amd import rle
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import CONFIGS, make_batch
+    from fgn_amd.fsiseg_eval import evaluate_results
+    from fgn_amd.weights import init_state_dict
+    from oracle import fgn_ref_cpu as O
+    shape = CONFIGS['cfg3']
+    cfg = fgn_r50_c4_config(3, 3)
+    sd = init_state_dict(cfg, 0)
+    batch = make_batch(21, 1, **shape)
+    model = FGN(3, 3, state_dict=sd)
+    model.debug_trace = {}
+    got = model.simple_test(**batch, rescale=True)
+    tr = model.debug_trace
+    model.debug_trace = None
+    again = model.simple_test(**batch, rescale=True)
+    g = got[0]
+    # --- determinism: bit-identical results run to run (split-K / stream-K sums are order-fixed)
+    for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+        assert np.array_equal(g[key], again[0][key]), key
+    assert g['dt_isegmaps_rle'] == again[0]['dt_isegmaps_rle']
+    # --- invariants of proposals (device tensors of the trace)
+    n_props = int(tr['n_props'][0])
+    props = tr['proposals'][0, :n_props].cpu().numpy()
+    assert 0 < n_props <= 300 and np.all(np.diff(props[:, 4]) <= 0)                 # score-sorted
+    assert props[:, [0, 2]].min() >= 0 and props[:, [0, 2]].max() <= 1333 and props[:, [1, 3]].max() <= 800
+    assert np.all(props[:, 2] > props[:, 0]) and np.all(props[:, 3] > props[:, 1])
+    iou = _iou(props[:, :4], props[:, :4])
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.7 + 1e-6                                                  # NMS post-condition
+    # --- invariants of detections
+    d = len(g['dt_scores'])
+    assert 0 < d <= 100 and np.all(np.diff(g['dt_scores']) <= 0) and g['dt_scores'].min() > 0.05
+    assert set(np.unique(g['dt_cat_ids'])) <= {0, 1, 2}
+    b = g['dt_bboxes'][:, [1, 0, 3, 2]]
+    for c in range(3):                                                              # class-aware NMS at 0.5
+        bc = b[g['dt_cat_ids'] == c]
+        if len(bc) > 1:
+            i2 = _iou(bc, bc)
+            np.fill_diagonal(i2, 0)
+            assert i2.max() <= 0.5 + 1e-6
+    for j in (0, d // 2, d - 1):                                                    # masks live inside their box (+1 px)
+        m = rle.decode(g['dt_isegmaps_rle'][j]).astype(bool)
+        assert m.shape == (800, 1333)
+        ys, xs = np.nonzero(m)
+        if len(ys):
+            assert xs.min() >= np.floor(b[j, 0]) - 1 and xs.max() <= np.ceil(b[j, 2]) + 1
+            assert ys.min() >= np.floor(b[j, 1]) - 1 and ys.max() <= np.ceil(b[j, 3]) + 1
+    # --- parity against the oracle on the same episode
+    tr_ref = {}
+    ref = O.simple_test(sd, cfg, **batch, trace=tr_ref)
+    r = tr_ref['qry_fmap']
+    assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
+    rb = ref[0]['dt_bboxes'][:, [1, 0, 3, 2]]
+    assert abs(len(rb) - d) <= 5
+    iou = _iou(rb, b)
+    ok = (iou.max(1) > 0.98) & (ref[0]['dt_cat_ids'] == g['dt_cat_ids'][iou.argmax(1)])
+    assert ok.mean() >= 0.9, ok.mean()
+    as_gt = dict(g)
+    as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
+    as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
+    agree = evaluate_results([as_gt], 3)
+    assert agree['bbox_mAP50'] >= 0.9 and agree['segm_mAP50'] >= 0.9, agree
