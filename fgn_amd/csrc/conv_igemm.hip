@@ -753,34 +753,46 @@ __global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p
             asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
+            // fragment double buffering: the ds_reads of K-slice kk+1 are issued before the 16 MFMAs
+            // of slice kk, so their LDS latency is covered instead of exposed once per slice
+            float4 af[2][TM], bf[2][TN];
+            {
+                const int pc = ((0 * 2 + half) ^ rswz) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int pc = ((kk * 2 + half) ^ rswz) * 4;
-                float4 af[TM], bf[TN];
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk < 3) {
+                    const int pc = (((kk + 1) * 2 + half) ^ rswz) * 4;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
+                    for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].x, bf[cb][j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].y, bf[cb][j].y, acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].z, bf[cb][j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
