@@ -841,6 +841,200 @@ __global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p
     }
 }
 
+// 16x16x4 MFMA variant of the stream-K kernel (same tiles, LDS image, partition and slabs):
+// experiment for the clock the chip holds per MFMA shape (MI355X_MICROARCH.md, DVFS item 7).
+__global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams p) {
+    constexpr int BM = SK_TILE, BN = SK_TILE, WM = 64, WN = 64;
+    constexpr int TM = 4, TN = 4, A_LD = 4, B_LD = 4;   // 4x4 MFMA tiles of 16x16 per wave
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    int bid = blockIdx.x;      // XCD-contiguous logical ids (SK_BLOCKS is a multiple of 8)
+    bid = (bid & 7) * (SK_BLOCKS / 8) + (bid >> 3);
+
+    const int HoWo = p.Ho * p.Wo;
+    int n_img = p.n_img;
+    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
+    const int M = n_img * HoWo;
+    const int KT = p.K / BK;
+    const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
+    const int total = tiles * KT;
+    const int per = sk_units_per_block(total);
+    int u = bid * per;
+    const int u_end = min(u + per, total);
+    if (u >= u_end) return;
+
+    const int col4 = t & 7;
+    const int row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const int cin_tiles = p.Cin / BK;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    const int frag_row = lane & 15;        // 16x16x4: lane l feeds A[row l&15][k = l>>4]
+    const int kgrp = lane >> 4;            // which float4 of a 16-wide K chunk this lane reads
+    const int rswz = (frag_row >> 1) & 7;
+    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+    float* const my_slabs = p.ws + (size_t)bid * 2 * (SK_TILE * SK_TILE);
+
+    while (u < u_end) {
+        const int tile = u / KT;
+        const int kb = u - tile * KT;
+        const int ke = min(KT, kb + (u_end - u));
+        const bool first_seg = (u == bid * per);
+        u += ke - kb;
+        const int tile_m = tile / p.n_tiles_n;
+        const int tile_n = tile - tile_m * p.n_tiles_n;
+        const int m0 = tile_m * BM;
+        const int n0 = tile_n * BN;
+
+        int a_off[A_LD];
+        unsigned long long a_taps[A_LD];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_off[i] = 0; a_taps[i] = 0ull;
+            if (m < M) {
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                a_off[i] = ((((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + src_c4 * 4) * 4;
+                unsigned long long tm = 0ull;
+                int tp = 0;
+                for (int ky = 0; ky < p.KH; ++ky) {
+                    const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
+                    for (int kx = 0; kx < p.KW; ++kx, ++tp)
+                        if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
+                }
+                a_taps[i] = tm;
+            }
+        }
+        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+
+        auto issue_tile = [&](int kt, int stage) {
+            const int tap = kt / cin_tiles;
+            const int c0 = (kt - tap * cin_tiles) * BK;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;
+            const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = (a_taps[i] >> tap) & 1ull;
+                lds_dma16(x_rs, sa + i * 32 * 128, ok ? (unsigned)(a_off[i] + tap_off) : OOB);
+            }
+            const unsigned sb = sa + BM * 128;
+            const unsigned bko = (unsigned)(kt * BK * 4);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
+        };
+
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+        // all waves are past the previous segment's LDS reads (barrier at the end of its loop)
+        issue_tile(kb, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            issue_tile(min(kt + 1, ke - 1), cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
+            // two 16-wide K chunks per K-tile; per chunk one ds_read_b128 per 16-row fragment feeds
+            // 4 MFMAs (element j of lane group g contracts k = 4g + j)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int pc = ((kc * 4 + kgrp) ^ rswz) * 4;
+                float4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 16 * BK + pc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 16 * BK + pc);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+
+        // C/D layout of 16x16x4: col = lane&15 (-> n), row = 4*(lane>>4) + r (-> m)
+        if (kb == 0 && ke == KT) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + frag_row;
+                const bool n_ok = n < p.Cout;
+                const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
+                const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mb = m0 + wm * WM + i * 16 + 4 * kgrp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb + r;
+                        if (n_ok && m < M) {
+                            const size_t o = (size_t)m * p.Cout + n;
+                            float v = acc[i][j][r] * sc + sh;
+                            if (p.residual) v += p.residual[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.y[o] = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WN + j * 16 + frag_row;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rb = wm * WM + i * 16 + 4 * kgrp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(rb + r) * SK_TILE + col] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+
 // one workgroup per output tile: sums the slabs of a split tile in ascending block order
 __global__ __launch_bounds__(256) void streamk_fixup_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
@@ -891,10 +1085,19 @@ static int launch_streamk(const ConvParams& p0, int M_max, hipStream_t stream) {
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, SK_TILE);
     const size_t dlds = (size_t)2 * (SK_TILE + SK_TILE) * BK * sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL(conv_streamk_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
+    if (p0.splits == 16)
+        hipLaunchKernelGGL(conv_streamk16_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
+    else
+        hipLaunchKernelGGL(conv_streamk_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
     FGN_LAUNCH_CHECK();
     hipLaunchKernelGGL(streamk_fixup_kernel, dim3(cdiv(M_max, SK_TILE) * p.n_tiles_n), dim3(256), 0, stream, p);
     FGN_LAUNCH_CHECK();
@@ -1004,7 +1207,7 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
 // (measured, tools/conv_bench.py: 3x3 convs on >= 100 RoIs, the AG-RPN conv); tile_hint 5 forces it (tests), any other non-zero hint disables it.
 static bool use_streamk(long long M, int Cin, int Cout, int KT, int tile_hint) {
     if (Cin == 4 || (Cout % 4) != 0) return false;
-    if (tile_hint == 5) return true;
+    if (tile_hint == 5 || tile_hint == 6) return true;     // 6 = the 16x16x4 MFMA variant
     if (tile_hint != 0) return false;
     const long long tiles = ((M + SK_TILE - 1) / SK_TILE) * cdiv(Cout, SK_TILE);
     return Cout >= 128 && KT >= 64 && tiles * KT >= (long long)SK_BLOCKS * 24;
@@ -1072,9 +1275,10 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         splitk_ws_bytes >= (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float) &&
         use_streamk(M, Cin, Cout, p.K / BK, tile_hint)) {
         p.ws = splitk_ws;
+        p.splits = (tile_hint == 5) ? 1 : 16;      // MFMA-shape selector of launch_streamk: 16x16x4 by default (+2..4 % measured), hint 5 = 32x32x2
         return launch_streamk(p, (int)M, stream);
     }
-    if (tile == 5) tile = 1;       // stream-K not applicable here
+    if (tile == 5 || tile == 6) tile = 1;       // stream-K not applicable here
     if (tile == 0) {
         const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
         tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;

@@ -24,13 +24,23 @@ def _rle_area(r: dict) -> int:
 
 
 def _mask_iou(dts: List[dict], gts: List[dict]) -> np.ndarray:
-    """pycocotools maskUtils.iou for non-crowd RLEs: |d & g| / |d | g|."""
+    """pycocotools maskUtils.iou for non-crowd RLEs: |d & g| / |d | g|.  Intersections are one
+    float32 matrix product over the pixels of the joint bounding box of all masks (exact: counts
+    stay far below 2^24), in column chunks to bound memory."""
     if not dts or not gts:
         return np.zeros((len(dts), len(gts)))
-    d = np.stack([_rle.decode(x).astype(bool).reshape(-1) for x in dts])
-    g = np.stack([_rle.decode(x).astype(bool).reshape(-1) for x in gts])
-    inter = (d[:, None, :] & g[None, :, :]).sum(-1).astype(np.float64)
-    union = d.sum(-1)[:, None] + g.sum(-1)[None, :] - inter
+    d = np.stack([_rle.decode(x).astype(bool) for x in dts])
+    g = np.stack([_rle.decode(x).astype(bool) for x in gts])
+    occ = d.any(0) | g.any(0)
+    if not occ.any():
+        return np.zeros((len(dts), len(gts)))
+    ys, xs = np.flatnonzero(occ.any(1)), np.flatnonzero(occ.any(0))
+    d = d[:, ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1].reshape(len(dts), -1)
+    g = g[:, ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1].reshape(len(gts), -1)
+    inter = np.zeros((len(dts), len(gts)), np.float64)
+    for c0 in range(0, d.shape[1], 1 << 18):
+        inter += d[:, c0:c0 + (1 << 18)].astype(np.float32) @ g[:, c0:c0 + (1 << 18)].astype(np.float32).T
+    union = d.sum(-1, dtype=np.float64)[:, None] + g.sum(-1, dtype=np.float64)[None, :] - inter
     with np.errstate(invalid='ignore', divide='ignore'):
         return np.where(union > 0, inter / union, 0.0)
 
