@@ -120,7 +120,7 @@ def main():
         # profiled steps run single-stream so the per-launch HIP-event durations are not
         # inflated by a concurrent kernel of the other branch
         model.use_side_stream = profile is None
-        if profile is not None:
+        if profile is not None and len(ep_streams) > 1:
             torch.cuda.synchronize()          # nothing else on the GPU while launches are timed
         with torch.cuda.stream(ep_streams[i % len(ep_streams)]):
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
@@ -130,7 +130,7 @@ def main():
                 # stream right behind its kernels (no host synchronisation)
                 recs, cnts = fdist.pack_detections(dets, max_det)
                 fdist.gather_detections(recs, cnts)
-        if profile is not None:
+        if profile is not None and len(ep_streams) > 1:
             torch.cuda.synchronize()
         ops.PROFILE = None
         return e, dets
@@ -140,19 +140,22 @@ def main():
         return model.pack_results(dets, 1, qry_bboxes=e['qry_bboxes'], qry_cat_ids=e['qry_cat_ids'],
                                   qry_isegmaps=None, img_shape=e['img_shape'], idx=e['idx'])
 
-    def run(n_steps, prof=None, prof_every=4):
+    def run(n_steps, prof=None, prof_steps=()):
         """Software-pipelined: episode i+1 is queued before the results of episode i are packed,
         so host-side result packing overlaps device work.  Every result is still delivered."""
         n_det = 0
         pending = []
         for i in range(n_steps):
-            pending.append(launch(i, prof if (prof is not None and i % prof_every == 0) else None))
+            pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None))
             if len(pending) > args.inflight:
                 n_det += len(finish(pending.pop(0))[0]['dt_scores'])
         while pending:
             n_det += len(finish(pending.pop(0))[0]['dt_scores'])
         return n_det
 
+    # setup (not a warm-up step): pack the weights for the device, fill the caching allocator's pools,
+    # pin the host ring and let every kernel set its LDS attribute once
+    run(2, prof=[], prof_steps=(1,))      # also creates the first timing events (a one-time ~40 ms in HIP)
     run(args.warmup)
 
     def barrier():
@@ -163,14 +166,18 @@ def main():
     prof = []
     barrier()
     t0 = time.perf_counter()
-    n_d = run(args.steps, prof, prof_every=8)
+    # two of the timed steps carry the HIP-event brackets (live roofline measurement); they run the
+    # support branch on the same stream, which costs ~1.5 ms each - kept to two so that the headline
+    # value is not dominated by instrumentation at small K
+    prof_steps = sorted({args.steps // 3, (2 * args.steps) // 3})
+    n_d = run(args.steps, prof, prof_steps=prof_steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_prof_steps = (args.steps + 7) // 8
+    n_prof_steps = len(prof_steps)
 
     # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
     conv_ms = 0.0
