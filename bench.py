@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=3)
     ap.add_argument('--inflight', type=int, default=1, help='independent episodes in flight per GPU')
+    ap.add_argument('--cache-supports', action='store_true',
+                    help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -104,6 +106,7 @@ def main():
                              [t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in b.items()})
     for e in episodes:
         e['img_shape'] = e['img_shape'].cpu()     # shape metadata is host data in the reference too
+        e['code'] = model.encode_supports(e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps']) if args.cache_supports else None
 
     max_det = cfg['test_cfg']['rcnn']['max_per_img']
     from fgn_amd import dist as fdist
@@ -124,7 +127,7 @@ def main():
             torch.cuda.synchronize()          # nothing else on the GPU while launches are timed
         with torch.cuda.stream(ep_streams[i % len(ep_streams)]):
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
-                                       e['img_shape'])
+                                       e['img_shape'], support_code=e['code'])
             if world > 1:
                 # one RCCL all-gather of fixed-size padded records per step, queued on the episode's
                 # stream right behind its kernels (no host synchronisation)
@@ -202,6 +205,8 @@ def main():
     if rank == 0:
         R = cfg['test_cfg']['rpn']['max_per_img']
         gflop = algorithmic_gflop(cfg, shape['height'], shape['width'], shape['spp_size'], R, n_d / args.steps)
+        if args.cache_supports:     # support backbone + support shared_head leave the timed step
+            gflop -= algorithmic_gflop(cfg, 0, 0, shape['spp_size'], 0, 0)
         out = {
             'metric': 'query-imgs/sec (3-way 3-shot, 800x1333 FGN simple_test)',
             'value': world * args.steps / dt,
@@ -219,6 +224,7 @@ def main():
                                    f'query 3x{shape["height"]}x{shape["width"]}, supports '
                                    f'{shape["n_ways"] * shape["k_shots"]}x3x{shape["spp_size"]}^2, ResNet-50-C4, '
                                    f'R<={R} proposals, D<={max_det} detections, 1 episode per GPU per step',
+                       'support_cache': bool(args.cache_supports),
                        'avg_detections': n_d / args.steps,
                        'algorithmic_gflop_per_episode': round(gflop, 1),
                        'algorithmic_tflops': round(gflop * world * args.steps / dt / 1e3, 2)},

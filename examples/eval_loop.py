@@ -4,6 +4,7 @@ DataLoader(ds, batch_size=ds.batch, collate_fn=collate_fn_new) -> model.simple_t
 -> chunked result pickles -> ds.evaluate(results_pkl_dir_fp=...).
 
     python examples/eval_loop.py --episodes 8 --batch 2 --height 320 --width 480
+    python examples/eval_loop.py --dataset OMNIISEG --episodes 16 --n-ways 3 --k-shots 1     (cfg2-shaped)
 """
 import argparse
 import os
@@ -17,7 +18,7 @@ from torch.utils.data import DataLoader
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fgn_amd.detector import FGN                          # noqa: E402
 from fgn_amd.episodes import collate                      # noqa: E402
-from fgn_amd.fewshot_ds import SyntheticFewShotISEG, write_chunked   # noqa: E402
+from fgn_amd.fewshot_ds import ClutteredCharsFewShotISEG, SyntheticFewShotISEG, write_chunked   # noqa: E402
 
 
 def main():
@@ -28,10 +29,15 @@ def main():
     ap.add_argument('--k-shots', type=int, default=3)
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1333)
+    ap.add_argument('--dataset', default='SYNTH', choices=['SYNTH', 'MNISTISEG', 'OMNIISEG'])
     ap.add_argument('--checkpoint', default=None, help='mmcv checkpoint of a trained reference FGN')
     args = ap.parse_args()
 
-    ds = SyntheticFewShotISEG(args.n_ways, args.k_shots, args.episodes, args.height, args.width, batch=args.batch)
+    if args.dataset == 'SYNTH':
+        ds = SyntheticFewShotISEG(args.n_ways, args.k_shots, args.episodes, args.height, args.width, batch=args.batch)
+    else:       # cluttered characters: 128^2 (MNISTISEG, cfg1) / 256^2 (OMNIISEG, cfg2) queries, 128^2 supports
+        ds = ClutteredCharsFewShotISEG(args.dataset, args.n_ways, args.k_shots, n_imgs=args.episodes,
+                                       img_size=128 if args.dataset == 'MNISTISEG' else 256, batch=args.batch)
     model = FGN(args.n_ways, args.k_shots)
     if args.checkpoint:
         model.load_state_dict(torch.load(args.checkpoint, map_location='cpu'))

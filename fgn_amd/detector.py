@@ -254,18 +254,64 @@ class FGN(torch.nn.Module):
     def simple_test(self, qry_img, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None, qry_bboxes_ignore=None,
                     spp_imgs=None, spp_bboxes=None, spp_isegmaps=None, qry_child_idx=None, img_shape=None,
                     rescale=False, cats_ids_to_sample_real=None, spp_insts_ids=None, idx=None,
-                    **kwargs) -> List[Dict]:
-        """Test without augmentation (fgn.py:187-303)."""
-        dets = self.detect_device(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape)
+                    support_code=None, **kwargs) -> List[Dict]:
+        """Test without augmentation (fgn.py:187-303).  ``support_code`` (optional, from
+        ``encode_supports``) replaces the three ``spp_*`` inputs."""
+        dets = self.detect_device(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
         return self.pack_results(dets, qry_img.shape[0], qry_bboxes=qry_bboxes, qry_cat_ids=qry_cat_ids,
                                  qry_isegmaps=qry_isegmaps, img_shape=img_shape, qry_child_idx=qry_child_idx,
                                  cats_ids_to_sample_real=cats_ids_to_sample_real, spp_insts_ids=spp_insts_ids,
                                  idx=idx)
 
+    # --- support branch (fgn.py:212-215 backbone pass; fgn_ag_rpn_head.py:38-41; fgn_roi_head.py:419-449) ---
+    def _support_front(self, spp_imgs, spp_bboxes, spp_isegmaps, B, dev, stream) -> dict:
+        """modify_input for the supports (fgn.py:79-108: H2D, YXYX -> XYXY on private copies), their
+        backbone pass and the AG-RPN class vectors."""
+        N, K = self.n_ways, self.k_shots
+        spp = spp_imgs.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, *spp_imgs.shape[-3:])
+        spp_xyxy = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)[:, [1, 0, 3, 2]]
+        spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
+        spp_fmaps = self.extract_feat(spp)                                      # [B*N*K,s,s,C]
+        vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
+        return dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp_fmaps=spp_fmaps, vec=vec)
+
+    def _support_back(self, sc: dict, B, dev) -> None:
+        """count_spp (fgn_roi_head.py:419-449) and the support half of the relation conv."""
+        P, rh = self._P, self.cfg['roi_head']
+        N, K, PS = self.n_ways, self.k_shots, rh['roi_out_size']
+        bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
+        spp_rois = torch.cat([bidx, sc['spp_xyxy']], 1).contiguous()
+        sc['masks7'] = ops.roi_align_mask(sc['spp_masks'], spp_rois, PS, 1.0, -1, False)
+        # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
+        sfeat = ops.roi_align(sc['spp_fmaps'], spp_rois, PS, 1.0 / rh['featmap_stride'], -1, False)
+        sfeat = self._shared_head(sfeat)
+        sc['cat_mean'] = ops.support_kmean(sfeat, B * N, K)                           # [B*N,7,7,C]
+        sc['cat_mean_mp'] = ops.support_class_vectors(sfeat, sc['masks7'], B * N, K)  # [B*N,C]
+        sc['S'] = ops.conv2d(sc['cat_mean'], P['rel_s'])                              # Ws*support + bias
+
     @torch.no_grad()
-    def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape) -> list:
+    def encode_supports(self, spp_imgs, spp_bboxes, spp_isegmaps) -> dict:
+        """Support-feature caching across queries: everything the path derives
+        from the support set alone - backbone pass, AG-RPN class vectors, count_spp, the support
+        half of the relation conv - computed once on the current stream.  The returned code is
+        passed as ``support_code=`` to ``simple_test`` / ``detect_device`` for every query that
+        shares the support set (the reference recomputes it per query, fgn.py:212-215; results
+        are identical)."""
+        if not torch.cuda.is_available():
+            raise ops._lib.FgnHipError('FGN.encode_supports needs a GPU: the HIP path has no CPU fallback')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if self._packed_device != dev:
+            self._pack(dev)
+        B = spp_imgs.shape[0] if spp_imgs.dim() == 5 else 1
+        sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, torch.cuda.current_stream())
+        self._support_back(sc, B, dev)
+        return sc
+
+    @torch.no_grad()
+    def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None) -> list:
         """Everything up to (not including) the device->host copy.  Returns, per image, a
-        dict of device tensors: det_bboxes [D,5], det_labels [D], n_dets [1], masks u8 [D,H,W]."""
+        dict of device tensors: det_bboxes [D,5], det_labels [D], n_dets [1], masks u8 [D,H,W].
+        With ``support_code`` (from ``encode_supports``) the support branch is skipped."""
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('FGN.simple_test needs a GPU: the HIP path has no CPU fallback')
         dev = torch.device('cuda', torch.cuda.current_device())
@@ -279,17 +325,18 @@ class FGN(torch.nn.Module):
         PS = rh['roi_out_size']
         inv_stride = 1.0 / rh['featmap_stride']
 
-        # modify_input (fgn.py:79-108): H2D, YXYX -> XYXY on private copies
         qry = qry_img.to(dev, torch.float32, non_blocking=True)
-        spp = spp_imgs.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, *spp_imgs.shape[-3:])
-        spp_xyxy = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)[:, [1, 0, 3, 2]]
-        spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
 
         # Two HIP streams: the support branch (9 small crops: low-occupancy launches) runs beside
         # the query branch, and its RoI/shared-head/reduction tail runs beside the single-workgroup
         # proposal kernel.  Joined by events; no host synchronisation.
         main = torch.cuda.current_stream()
-        if self.use_side_stream:
+        cached = support_code is not None
+        if cached:
+            if support_code['B'] != B or support_code['device'] != dev:
+                raise ValueError('support_code was encoded for another batch size or device')
+            side = main
+        elif self.use_side_stream:
             if self._side_stream is None:
                 self._side_stream = {}
             side = self._side_stream.get(main.cuda_stream)     # one side stream per caller stream
@@ -297,21 +344,23 @@ class FGN(torch.nn.Module):
                 side = self._side_stream[main.cuda_stream] = torch.cuda.Stream()
         else:
             side = main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            spp_fmaps = self.extract_feat(spp)                  # [B*N*K,s,s,C]
-            vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
-            vec_ready = side.record_event()
-        for tns in (spp, spp_xyxy, spp_masks):              # allocated on main, consumed on side
-            tns.record_stream(side)
+        if cached:
+            sc = support_code
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, side)
+                vec_ready = side.record_event()
+        vec = sc['vec']
 
         qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
         fh, fw, C = qry_fmap.shape[1:]
         if tr is not None:
-            tr['qry_fmap'], tr['spp_fmaps'] = qry_fmap, spp_fmaps
+            tr['qry_fmap'], tr['spp_fmaps'] = qry_fmap, sc.get('spp_fmaps')
 
         # ---- AG-RPN (fgn_ag_rpn_head.py:26-118) -------------------------------------------
-        main.wait_event(vec_ready)
+        if not cached:
+            main.wait_event(vec_ready)
         rpn_start = main.record_event()
         # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
         # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
@@ -324,20 +373,14 @@ class FGN(torch.nn.Module):
         # starts: its ~30 tiny 9-RoI launches (0.3 ms end to end, a handful of CUs each) hide under
         # the 2 ms stream-K conv and the single-workgroup proposal kernel instead of delaying the
         # query backbone or the RoI head
-        with torch.cuda.stream(side):
-            side.wait_event(rpn_start)
-            bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
-            spp_rois = torch.cat([bidx, spp_xyxy], 1).contiguous()
-            masks7 = ops.roi_align_mask(spp_masks, spp_rois, PS, 1.0, -1, False)
-            # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
-            sfeat = ops.roi_align(spp_fmaps, spp_rois, PS, inv_stride, -1, False)
-            sfeat = self._shared_head(sfeat)
-            cat_mean = ops.support_kmean(sfeat, B * N, K)                            # [B*N,7,7,C]
-            cat_mean_mp = ops.support_class_vectors(sfeat, masks7, B * N, K)         # [B*N,C]
-            S = ops.conv2d(cat_mean, P['rel_s'])                                     # Ws*support + bias
-            spp_ready = side.record_event()
-        for tns in (spp_fmaps, vec, S, cat_mean, cat_mean_mp, masks7):   # produced on side, consumed on main
-            tns.record_stream(main)
+        if not cached:
+            with torch.cuda.stream(side):
+                side.wait_event(rpn_start)
+                self._support_back(sc, B, dev)
+                spp_ready = side.record_event()
+            for key in ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):   # produced on side, consumed on main
+                sc[key].record_stream(main)
+        S, cat_mean, cat_mean_mp, masks7 = sc['S'], sc['cat_mean'], sc['cat_mean_mp'], sc['masks7']
 
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
         if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
@@ -346,7 +389,8 @@ class FGN(torch.nn.Module):
                                            rp['target_means'], rp['target_stds'], tc['rpn']['nms_pre'],
                                            tc['rpn']['min_bbox_size'], tc['rpn']['nms_iou_threshold'],
                                            tc['rpn']['max_per_img'])
-        main.wait_event(spp_ready)
+        if not cached:
+            main.wait_event(spp_ready)
         if tr is not None:
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
                       n_props=n_props, spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)

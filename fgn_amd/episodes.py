@@ -79,7 +79,7 @@ def make_episode(idx: int, n_ways: int, k_shots: int, height: int, width: int,
     }
 
 
-_LIST_KEYS = ('qry_cat_ids', 'qry_bboxes', 'qry_isegmaps')
+_LIST_KEYS = ('qry_cat_ids_real', 'qry_cat_ids', 'qry_bboxes', 'qry_isegmaps')
 
 
 def collate(samples: list) -> dict:

@@ -11,11 +11,61 @@ from __future__ import annotations
 
 import os
 import pickle
+import random
 
+import numpy as np
+import torch
 from torch.utils.data import Dataset
 
+from . import cluttered_chars as cc
 from . import episodes
 from .fsiseg_eval import FSISEGEval
+
+
+def get_new_shape(h, w, target_size=800, max_size=1333):
+    """Short side -> target_size, long side capped at max_size, aspect ratio kept
+    (cp_utils/create_img_from_chars.py:250-267; integer truncation as there)."""
+    old = np.array([h, w], dtype=np.float64)
+    new = np.array([h, w], dtype=np.int64)
+    long_i = int(np.argmax(old))
+    ar = old[long_i] / old[1 - long_i]
+    new[1 - long_i] = target_size
+    new[long_i] = int(target_size * ar)
+    if new[long_i] > max_size:
+        new[long_i] = max_size
+        new[1 - long_i] = int(max_size / ar)
+    return new
+
+
+def ar_grouped_order(aspect_ratios, batch, target_size=800, max_size=1333, sub_sample_ratio=16, shuffle=True,
+                     seed=0):
+    """Aspect-ratio-grouped batching (base_fst.py:626-727): round width/height to one decimal, one group
+    per value, pad each group to a multiple of ``batch`` by re-drawing its own members, cut into chunks
+    of ``batch``, shuffle the chunks.  Returns (order [n_chunks*batch], group index per entry,
+    per-group (h, w) rounded to multiples of ``sub_sample_ratio``)."""
+    rnd = random.Random(seed)
+    ars = np.around(np.asarray(aspect_ratios, np.float64), decimals=1)
+    uniq = sorted(np.unique(ars))
+    hws = []
+    for a in uniq:
+        hws.append(get_new_shape(100 / a, 100, target_size, max_size))
+    hws = (np.around(np.array(hws) / sub_sample_ratio) * sub_sample_ratio).astype(np.int32).reshape(-1, 2)
+    order, groups = [], []
+    for gi, a in enumerate(uniq):
+        members = np.flatnonzero(ars == a)
+        elems = list(range(len(members)))
+        if len(members) % batch:
+            elems += rnd.choices(elems, k=batch - len(members) % batch)
+        if shuffle:
+            rnd.shuffle(elems)
+        order.extend(members[elems].tolist())
+        groups.extend([gi] * len(elems))
+    order = np.asarray(order, np.int32).reshape(-1, batch)
+    groups = np.asarray(groups, np.int32).reshape(-1, batch)
+    chunks = list(range(len(order)))
+    if shuffle:
+        rnd.shuffle(chunks)
+    return order[chunks].reshape(-1), groups[chunks].reshape(-1), hws
 
 
 class SyntheticFewShotISEG(Dataset):
@@ -64,3 +114,91 @@ def write_chunked(results_iter, out_dir, chunk=1000):
     if buf:
         with open(os.path.join(out_dir, f'{counter:02}.pkl'), 'wb') as fh:
             pickle.dump(buf, fh)
+
+
+class ClutteredCharsFewShotISEG(Dataset):
+    """MNISTISEG / OMNIISEG-shaped episodes (cfg1 / cfg2 of BASELINE.json) over the numpy cluttered-
+    character generator: the sample dict of base_fst.py:1248-1266, class-major supports cropped around
+    one instance each (fill ratio 0.8), per-episode category ids 0..N-1, images normalised with the
+    dataset mean/std (datasets/mnistiseg/ParamsMNISTISEG.json:1-5, datasets/omniiseg/ParamsOMNIISEG.json:1-5).
+    Character datasets are batched without aspect-ratio grouping (base_fst.py:611-624)."""
+    PARAMS = {'MNISTISEG': dict(mean=(0.9531239867210388, 0.9524800777435303, 0.9531603455543518),
+                                std=(0.16827817261219025, 0.16883736848831177, 0.16667258739471436), n_cats=10),
+              'OMNIISEG': dict(mean=(0.9628916382789612, 0.9640044569969177, 0.9626953601837158),
+                               std=(0.16037128865718842, 0.15775758028030396, 0.15985246002674103), n_cats=26)}
+
+    def __init__(self, dataset='MNISTISEG', n_ways=1, k_shots=1, n_imgs=32, img_size=128, spp_img_size=128,
+                 spp_fill_ratio=0.8, batch=1, shuffle=False, seed=1234):
+        par = self.PARAMS[dataset]
+        self.n_ways, self.k_shots, self.batch, self.shuffle = n_ways, k_shots, batch, shuffle
+        self.img_size, self.spp_img_size, self.spp_fill_ratio = img_size, spp_img_size, spp_fill_ratio
+        self.sampling_origin_ds, self.sampling_origin_ds_subset = dataset, 'val'
+        self.sampling_cats, self.sampling_scenario, self.finetune = 'all', 'parents', 'None'
+        self.mean = np.asarray(par['mean'], np.float32)
+        self.std = np.asarray(par['std'], np.float32)
+        self.seed = seed
+        cats = np.arange(par['n_cats'])
+        self.images = [cc.make_image(seed + j, img_size, cats) for j in range(n_imgs)]
+        # instance table: (image, object) per class, instance id = position in this table
+        self.inst = [(j, o) for j, im in enumerate(self.images) for o in range(len(im['cat_ids']))]
+        self.inst_cat = np.array([self.images[j]['cat_ids'][o] for j, o in self.inst])
+        self.cats = cats
+        self.order_initial = np.arange(n_imgs, dtype=np.int32)
+        self.order = self.order_initial.copy()
+
+    def __len__(self):
+        return len(self.order)
+
+    def reshuffle(self, e=8):
+        """base_fst.py:605-624."""
+        order = list(self.order_initial)
+        if self.shuffle:
+            random.Random((2 ** e) % 1000).shuffle(order)
+        self.order = np.array(order, dtype=np.int32)
+
+    def _norm(self, img_u8):
+        return torch.from_numpy(((img_u8.astype(np.float32) / 255.0 - self.mean) / self.std).transpose(2, 0, 1).copy())
+
+    def __getitem__(self, idx):
+        child = int(self.order[int(idx)])
+        im = self.images[child]
+        rng = np.random.RandomState(self.seed * 31 + child)
+        # classes of the episode: the query's own classes first, then random others (novel classes of a
+        # query always get a support; base_fst.py samples the same way from the query's categories)
+        present = list(dict.fromkeys(im['cat_ids'].tolist()))
+        rng.shuffle(present)
+        others = [c for c in rng.permutation(self.cats).tolist() if c not in present]
+        real = np.array((present + others)[:self.n_ways], np.int64)
+        mapping = np.full(int(self.cats.max()) + 1, -1, np.int64)
+        mapping[real] = np.arange(len(real))
+        keep = mapping[im['cat_ids']] >= 0
+        spp_imgs, spp_boxes, spp_masks, spp_ids = [], [], [], []
+        for c in real:                                   # class-major (base_fst.py:1054-1080)
+            pool = np.flatnonzero(self.inst_cat == c)
+            foreign = np.array([p for p in pool if self.inst[p][0] != child], np.int64)
+            pool = foreign if len(foreign) >= 1 else pool
+            pick = rng.choice(pool, self.k_shots, replace=len(pool) < self.k_shots)
+            for p in pick:
+                j, o = self.inst[p]
+                src = self.images[j]
+                crop, nb, m = cc.crop_support(src['img'], src['bboxes'][o], src['isegmaps'][o],
+                                              self.spp_img_size, self.spp_fill_ratio)
+                spp_imgs.append(self._norm(crop)); spp_boxes.append(nb); spp_masks.append(m); spp_ids.append(p)
+        return {
+            'idx': int(idx),
+            'qry_child_idx': child,
+            'qry_img': self._norm(im['img']),
+            'qry_cat_ids_real': im['cat_ids'][keep].astype(np.int64),
+            'qry_cat_ids': mapping[im['cat_ids'][keep]].astype(np.int64),
+            'qry_bboxes': im['bboxes'][keep].astype(np.float32),
+            'qry_isegmaps': im['isegmaps'][keep].astype(bool),
+            'spp_imgs': torch.stack(spp_imgs),
+            'spp_bboxes': np.stack(spp_boxes).astype(np.float32),
+            'spp_isegmaps': np.stack(spp_masks).astype(bool),
+            'cats_ids_to_sample_real': real,
+            'cats_ids_to_sample': np.arange(len(real), dtype=np.int64),
+            'spp_insts_ids': np.asarray(spp_ids, np.int64),
+            'img_shape': np.array([self.img_size, self.img_size, 3], dtype=np.int32),
+        }
+
+    evaluate = SyntheticFewShotISEG.evaluate

@@ -223,3 +223,33 @@ def test_cfg3_full_size_parity_and_invariants():
     as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
     agree = evaluate_results([as_gt], 3)
     assert agree['bbox_mAP50'] >= 0.9 and agree['segm_mAP50'] >= 0.9, agree
+
+
+def test_support_code_cache_is_identical():
+    """queries that share a support set reuse ``encode_supports``; the results
+    are the same bytes as the per-query recomputation the reference does (fgn.py:212-215)."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+    first = make_batch(0, 1, 3, 2, 160, 224, 64)
+    code = model.encode_supports(first['spp_imgs'], first['spp_bboxes'], first['spp_isegmaps'])
+    for q in range(3):
+        other = make_batch(10 + q, 1, 3, 2, 160, 224, 64)
+        batch = dict(other, spp_imgs=first['spp_imgs'], spp_bboxes=first['spp_bboxes'],
+                     spp_isegmaps=first['spp_isegmaps'])
+        plain = model.simple_test(**batch, rescale=True)
+        no_spp = {k: v for k, v in batch.items() if not k.startswith('spp_i') and k != 'spp_bboxes'}
+        cached = model.simple_test(**no_spp, support_code=code, rescale=True)
+        for a, b in zip(plain, cached):
+            assert len(a['dt_scores']) > 0
+            for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+                assert np.array_equal(a[key], b[key]), key
+            assert a['dt_isegmaps_rle'] == b['dt_isegmaps_rle']
+    with pytest.raises(ValueError):
+        two = make_batch(0, 2, 3, 2, 160, 224, 64)
+        model.simple_test(**{k: v for k, v in two.items() if not k.startswith('spp_i') and k != 'spp_bboxes'},
+                          support_code=code)

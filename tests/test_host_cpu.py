@@ -236,3 +236,53 @@ def test_synthetic_dataset_contract_and_evaluate(tmp_path):
     m = ds.evaluate(results_pkl_dir_fp=str(tmp_path / 'ResultsChunked'))
     assert set(m) == {'isegm_mAP', 'isegm_mAR', 'bbox_mAP', 'bbox_mAR'}
     assert m['bbox_mAP'] > 0.99 and m['isegm_mAP'] > 0.99
+
+
+def test_cluttered_chars_dataset_contract():
+    """MNISTISEG/OMNIISEG-shaped episodes; sample dict of base_fst.py:1248-1266."""
+    from fgn_amd import cluttered_chars as cc
+    from fgn_amd.episodes import collate
+    from fgn_amd.fewshot_ds import ClutteredCharsFewShotISEG
+    im = cc.make_image(3, 256, np.arange(10))
+    n = len(im['cat_ids'])
+    assert 2 <= n <= 6 and im['img'].dtype == np.uint8 and im['isegmaps'].shape == (n, 256, 256)
+    for b, m in zip(im['bboxes'], im['isegmaps']):
+        ys, xs = np.nonzero(m)
+        assert m.sum() > 0 and ys.min() >= b[0] and ys.max() < b[2] and xs.min() >= b[1] and xs.max() < b[3]
+    boxes = im['bboxes']
+    for i in range(n):                          # placement rule: pairwise IoU below 0.2
+        for j in range(i):
+            assert cc._iou_one_to_many(boxes[i], boxes[j:j + 1])[0] < 0.2
+    ds = ClutteredCharsFewShotISEG('OMNIISEG', n_ways=3, k_shots=2, n_imgs=12, img_size=256, spp_img_size=128)
+    s = ds[4]
+    assert s['spp_imgs'].shape == (6, 3, 128, 128) and s['spp_isegmaps'].shape == (6, 128, 128)
+    assert s['qry_img'].shape == (3, 256, 256) and s['qry_img'].dtype == torch.float32
+    assert set(s['qry_cat_ids'].tolist()) <= {0, 1, 2} and len(s['qry_cat_ids']) >= 1
+    assert np.array_equal(s['cats_ids_to_sample_real'][s['qry_cat_ids']], s['qry_cat_ids_real'])
+    # class-major supports of the sampled real classes, taken from other images, box fills ~0.8 of the crop
+    for i, p in enumerate(s['spp_insts_ids']):
+        assert ds.inst_cat[p] == s['cats_ids_to_sample_real'][i // 2]
+        side = max(s['spp_bboxes'][i][2] - s['spp_bboxes'][i][0], s['spp_bboxes'][i][3] - s['spp_bboxes'][i][1])
+        assert abs(side / 128 - 0.8) < 1e-3 and s['spp_isegmaps'][i].sum() > 0
+    assert ds[4]['qry_img'].equal(s['qry_img'])                         # deterministic
+    b = collate([ds[0], ds[1], ds[2]])
+    assert b['qry_img'].shape == (3, 3, 256, 256) and isinstance(b['qry_cat_ids_real'], list)
+    ds.shuffle = True
+    ds.reshuffle(e=3)
+    assert sorted(ds.order.tolist()) == list(range(12))
+
+
+def test_ar_grouped_batching():
+    """base_fst.py:626-727 and create_img_from_chars.py:250-267."""
+    from fgn_amd.fewshot_ds import ar_grouped_order, get_new_shape
+    assert get_new_shape(480, 640).tolist() == [800, 1066]
+    assert get_new_shape(375, 500).tolist() == [800, 1066]
+    assert get_new_shape(333, 1000).tolist() == [443, 1333]         # long side capped
+    assert get_new_shape(640, 480).tolist() == [1066, 800]
+    ars = [1.33, 1.5, 0.75, 1.34, 1.49, 1.3, 0.66, 1.0, 1.31]
+    order, groups, hws = ar_grouped_order(ars, batch=2, seed=1)
+    assert len(order) % 2 == 0 and set(order.tolist()) == set(range(len(ars)))
+    rounded = np.around(ars, 1)
+    for c in range(0, len(order), 2):            # every chunk holds one aspect-ratio group
+        assert rounded[order[c]] == rounded[order[c + 1]] and groups[c] == groups[c + 1]
+    assert (hws % 16 == 0).all() and hws.min() >= 800 - 8 and hws.max() <= 1344
