@@ -16,6 +16,7 @@ SOURCES = [
     ('conv_igemm.hip', []),
     ('abi.hip', []),
     ('spatial.hip', ['-ffp-contract=off']),
+    ('norm.hip', []),
     ('relation.hip', []),
     ('rpn_post.hip', ['-ffp-contract=off']),
     ('det_post.hip', ['-ffp-contract=off']),

@@ -21,6 +21,7 @@ def fgn_r50_c4_config(n_ways: int = 3, k_shots: int = 3) -> dict:
             # layer4 is deleted at run time (main.py:403-405); out_indices=(2,)
             stage_blocks=(3, 4, 6), stage_planes=(64, 128, 256),
             strides=(1, 2, 2), stem_channels=64, style='pytorch',
+            deep_stem=False, avg_down=False, norm='BN', gn_groups=32,
             norm_eval=True, bn_eps=1e-5),
         rpn_head=dict(
             type='AGRPNHead', in_channels=1024, feat_channels=1024,
@@ -46,16 +47,26 @@ def fgn_r50_c4_config(n_ways: int = 3, k_shots: int = 3) -> dict:
     )
 
 
-def tiny_config(n_ways: int = 3, k_shots: int = 1, width_div: int = 8) -> dict:
+def fgn_r50_c4_scratch_config(n_ways: int = 3, k_shots: int = 3) -> dict:
+    """The from-scratch backbone variant (fgn_r50_c4_scratch.py:5-30): 3-conv deep stem, average-pool
+    shortcuts, GroupNorm(32) instead of frozen BatchNorm.  Heads and test_cfg are the same."""
+    cfg = fgn_r50_c4_config(n_ways, k_shots)
+    cfg['backbone'].update(deep_stem=True, avg_down=True, norm='GN', gn_groups=32)
+    return cfg
+
+
+def tiny_config(n_ways: int = 3, k_shots: int = 1, width_div: int = 8, scratch: bool = False) -> dict:
     """A narrow variant (all channel widths divided) for fast CPU tests.
 
     Not a reference configuration: same topology, smaller widths, so the
     oracle and the host logic can be exercised in seconds on CPU.
     """
-    cfg = fgn_r50_c4_config(n_ways, k_shots)
+    cfg = (fgn_r50_c4_scratch_config if scratch else fgn_r50_c4_config)(n_ways, k_shots)
     d = width_div
     cfg['backbone'].update(stage_planes=tuple(p // d for p in (64, 128, 256)),
                            stem_channels=64 // d)
+    if scratch:     # GroupNorm(32) needs >= 32 channels everywhere: keep the stem at full width
+        cfg['backbone'].update(stem_channels=64, gn_groups=min(32, 64 // d))
     c = 1024 // d
     cfg['rpn_head'].update(in_channels=c, feat_channels=c)
     cfg['roi_head']['shared_head'].update(inplanes=c, planes=c // 2)

@@ -44,12 +44,19 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
         if 'stage_blocks' in backbone:
             cfg['backbone'].update(backbone)
         else:   # mmdet ResNet dict (fgn_r50_c4_densecl.py:15-42); layer4 is dropped (main.py:403-405)
-            if backbone.get('depth', 50) != 50 or backbone.get('deep_stem') or backbone.get('avg_down'):
-                raise NotImplementedError('only the DenseCL ResNet-50-C4 backbone variant is built')
+            if backbone.get('depth', 50) != 50:
+                raise NotImplementedError('only ResNet-50-C4 backbones are built (both reference configs)')
             last = max(backbone.get('out_indices', (2,)))
+            norm = backbone.get('norm_cfg', dict(type='BN'))
+            if norm.get('type', 'BN') not in ('BN', 'GN'):
+                raise NotImplementedError(f"norm_cfg {norm.get('type')!r}")
             cfg['backbone'].update(stage_blocks=_R50_BLOCKS[:last + 1],
                                    stage_planes=(64, 128, 256, 512)[:last + 1],
-                                   strides=tuple(backbone.get('strides', (1, 2, 2, 2)))[:last + 1])
+                                   strides=tuple(backbone.get('strides', (1, 2, 2, 2)))[:last + 1],
+                                   # fgn_r50_c4_scratch.py:16-23
+                                   deep_stem=bool(backbone.get('deep_stem', False)),
+                                   avg_down=bool(backbone.get('avg_down', False)),
+                                   norm=norm.get('type', 'BN'), gn_groups=norm.get('num_groups', 32))
     if rpn_head:
         r = cfg['rpn_head']
         if 'anchor_generator' in rpn_head:
@@ -115,6 +122,49 @@ class _Bottleneck:
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
 
 
+class _BottleneckGN:
+    """Bottleneck of the from-scratch backbone (fgn_r50_c4_scratch.py:16-25): conv -> GroupNorm -> ReLU;
+    the norm cannot fold into the conv epilogue, so every conv is followed by the GN passes.  Shortcut
+    under avg_down: [2x2 average pool if strided] -> 1x1 conv (stride 1) -> GN."""
+
+    def __init__(self, sd, prefix, stride, groups, eps, avg_down):
+        self.groups, self.eps = groups, eps
+        self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'])
+        self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], stride=stride, pad=1)
+        self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'])
+        self.gn = [[sd[f'{prefix}.gn{i}.weight'].clone(), sd[f'{prefix}.gn{i}.bias'].clone()] for i in (1, 2, 3)]
+        self.pooled = bool(avg_down) and stride != 1
+        if self.pooled and stride != 2:
+            raise NotImplementedError('avg_down shortcut: only stride 2')
+        i = 1 if self.pooled else 0
+        self.down = None
+        if f'{prefix}.downsample.{i}.weight' in sd:
+            self.down = ops.pack_conv(sd[f'{prefix}.downsample.{i}.weight'], stride=1 if avg_down else stride)
+            self.gn.append([sd[f'{prefix}.downsample.{i + 1}.weight'].clone(),
+                            sd[f'{prefix}.downsample.{i + 1}.bias'].clone()])
+
+    def layers(self):
+        return [l for l in (self.conv1, self.conv2, self.conv3, self.down) if l is not None]
+
+    def to(self, device):
+        for l in self.layers():
+            l.to(device)
+        self.gn = [[t.float().contiguous().to(device) for t in pair] for pair in self.gn]
+        return self
+
+    def _norm(self, x, i, relu, residual=None):
+        return ops.group_norm(x, self.gn[i][0], self.gn[i][1], self.groups, self.eps, relu=relu, residual=residual,
+                              inplace=True)
+
+    def __call__(self, x, n_img_dev=None):
+        idt = x
+        if self.down is not None:
+            idt = self._norm(ops.conv2d(ops.avgpool2x2(x) if self.pooled else x, self.down), 3, False)
+        y = self._norm(ops.conv2d(x, self.conv1), 0, True)
+        y = self._norm(ops.conv2d(y, self.conv2), 1, True)
+        return self._norm(ops.conv2d(y, self.conv3), 2, True, residual=idt)   # relu(gn3(conv3) + identity)
+
+
 class FGN(torch.nn.Module):
     """Fully Guided Network, inference path, on MI355X HIP kernels."""
     fp16_enabled = False
@@ -170,13 +220,31 @@ class FGN(torch.nn.Module):
         sd, cfg = self._sd, self.cfg
         eps = cfg['backbone']['bn_eps']
         P = {}
-        bn1 = {k: sd[f'backbone.bn1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
-        P['stem'] = ops.pack_conv(sd['backbone.conv1.weight'], bn=bn1, stride=2, pad=3, relu=True, eps=eps,
-                                  pad_cin_to=4)
+        bb = cfg['backbone']
+        gn = bb.get('norm', 'BN') == 'GN'
+        bnp = lambda name: {k: sd[f'{name}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+        # stem: list of (conv, GroupNorm params or None); BatchNorm(eval) folds into the conv epilogue
+        if bb.get('deep_stem'):
+            P['stem'] = []
+            for i, stride in enumerate((2, 1, 1)):
+                w, nm = sd[f'backbone.stem.{3 * i}.weight'], f'backbone.stem.{3 * i + 1}'
+                kw = dict(stride=stride, pad=1, pad_cin_to=4 if i == 0 else None)
+                if gn:
+                    P['stem'].append((ops.pack_conv(w, **kw), [sd[nm + '.weight'].clone(), sd[nm + '.bias'].clone()]))
+                else:
+                    P['stem'].append((ops.pack_conv(w, bn=bnp(nm), relu=True, eps=eps, **kw), None))
+        elif gn:
+            P['stem'] = [(ops.pack_conv(sd['backbone.conv1.weight'], stride=2, pad=3, pad_cin_to=4),
+                          [sd['backbone.gn1.weight'].clone(), sd['backbone.gn1.bias'].clone()])]
+        else:
+            P['stem'] = [(ops.pack_conv(sd['backbone.conv1.weight'], bn=bnp('backbone.bn1'), stride=2, pad=3,
+                                        relu=True, eps=eps, pad_cin_to=4), None)]
         P['stages'] = []
-        for li, (nblk, stride) in enumerate(zip(cfg['backbone']['stage_blocks'], cfg['backbone']['strides'])):
-            P['stages'].append([_Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps)
-                                for b in range(nblk)])
+        for li, (nblk, stride) in enumerate(zip(bb['stage_blocks'], bb['strides'])):
+            P['stages'].append([
+                _BottleneckGN(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, bb.get('gn_groups', 32),
+                              eps, bb.get('avg_down', False)) if gn else
+                _Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps) for b in range(nblk)])
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
         # objectness and delta 1x1 convs fused into one launch: channels [0,A) | [A,5A)
@@ -218,7 +286,9 @@ class FGN(torch.nn.Module):
                 for l in o.layers():
                     l.to(device)
                 return o
-            if isinstance(o, list):
+            if isinstance(o, _BottleneckGN):
+                return o.to(device)
+            if isinstance(o, (list, tuple)):
                 return [mv(x) for x in o]
             return o
         self._P = {k: mv(v) for k, v in P.items()}
@@ -228,8 +298,12 @@ class FGN(torch.nn.Module):
     def extract_feat(self, img_nchw: torch.Tensor) -> torch.Tensor:
         """ResNet-50 stages 1-3 (fgn.py:67-77): NCHW fp32 in, NHWC [B,h,w,1024] out."""
         P = self._P
+        bb = self.cfg['backbone']
         x = ops.nchw3_to_nhwc4(img_nchw.contiguous())
-        x = ops.conv2d(x, P['stem'])
+        for conv, gn in P['stem']:
+            x = ops.conv2d(x, conv)
+            if gn is not None:
+                x = ops.group_norm(x, gn[0], gn[1], bb.get('gn_groups', 32), bb['bn_eps'], relu=True, inplace=True)
         x = ops.maxpool3x3s2(x)
         for stage in P['stages']:
             for blk in stage:

@@ -22,6 +22,9 @@ SIGNATURES = {
     'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
     'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'fgn_group_norm_workspace_bytes': (C.c_size_t, [_i] * 4),
+    'fgn_group_norm_nhwc_f32': (_i, [_p] * 6 + [C.c_size_t, _i, _i, _i, _i, _f, _i, _p]),
+    'fgn_avgpool2x2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_roi_align_mask_u8': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_support_class_vectors_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -40,7 +43,7 @@ SIGNATURES = {
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -172,6 +172,38 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-5,
+               relu: bool = False, residual: Optional[torch.Tensor] = None, inplace: bool = False) -> torch.Tensor:
+    """torch.nn.GroupNorm over NHWC x [n,H,W,C] (+ residual) (+ ReLU)."""
+    _chk(x, 'x')
+    _chk(gamma, 'gamma')
+    _chk(beta, 'beta')
+    n, h, w, c = x.shape
+    if gamma.numel() != c or beta.numel() != c or c % groups != 0:
+        raise _lib.FgnHipError('group_norm: bad gamma/beta/groups')
+    if residual is not None:
+        _chk(residual, 'residual')
+        if residual.shape != x.shape:
+            raise _lib.FgnHipError('group_norm: bad residual shape')
+    lib = _lib.load()
+    nbytes = lib.fgn_group_norm_workspace_bytes(n, h * w, c, groups)
+    ws = torch.empty(max(nbytes // 8, 1), device=x.device, dtype=torch.float64)
+    y = x if inplace else torch.empty_like(x)
+    _lib.check(lib.fgn_group_norm_nhwc_f32(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(ws), nbytes,
+                                           n, h * w, c, groups, float(eps), int(relu), _stream()),
+               'fgn_group_norm_nhwc_f32')
+    return y
+
+
+def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
+    """AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) over NHWC."""
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fgn_avgpool2x2_nhwc_f32(_ptr(x), _ptr(y), n, h, w, c, _stream()), 'fgn_avgpool2x2_nhwc_f32')
+    return y
+
+
 def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
               sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fmap [B,H,W,C], rois [R,5] -> [R,P,P,C]."""

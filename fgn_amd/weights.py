@@ -50,6 +50,26 @@ def _bn(sd, g, name, c, gamma_scale=1.0):
     sd[name + '.running_var'] = 0.75 + 0.5 * torch.rand(c, generator=g)
 
 
+def _gn(sd, g, name, c, gamma_scale=1.0):
+    sd[name + '.weight'] = (0.75 + 0.5 * torch.rand(c, generator=g)) * gamma_scale
+    sd[name + '.bias'] = 0.1 * torch.randn(c, generator=g)
+
+
+def _bottleneck_gn(sd, g, prefix, cin, planes, cout, downsample, pooled):
+    """mmdet Bottleneck with norm_cfg GN: norm layers are named gn1..gn3; under avg_down the shortcut
+    is [AvgPool2d (only when strided), conv1x1, norm] so the conv sits at index 1 (strided) or 0."""
+    sd[prefix + '.conv1.weight'] = _kaiming(g, planes, cin, 1, 1)
+    _gn(sd, g, prefix + '.gn1', planes)
+    sd[prefix + '.conv2.weight'] = _kaiming(g, planes, planes, 3, 3)
+    _gn(sd, g, prefix + '.gn2', planes)
+    sd[prefix + '.conv3.weight'] = _kaiming(g, cout, planes, 1, 1)
+    _gn(sd, g, prefix + '.gn3', cout, gamma_scale=0.35)
+    if downsample:
+        i = 1 if pooled else 0
+        sd[f'{prefix}.downsample.{i}.weight'] = _kaiming(g, cout, cin, 1, 1)
+        _gn(sd, g, f'{prefix}.downsample.{i + 1}', cout, gamma_scale=0.7)
+
+
 def _bottleneck(sd, g, prefix, cin, planes, cout, downsample):
     sd[prefix + '.conv1.weight'] = _kaiming(g, planes, cin, 1, 1)
     _bn(sd, g, prefix + '.bn1', planes)
@@ -68,14 +88,24 @@ def init_state_dict(cfg: dict, seed: int = 0) -> 'OrderedDict[str, torch.Tensor]
     sd: 'OrderedDict[str, torch.Tensor]' = OrderedDict()
     bb = cfg['backbone']
     stem = bb['stem_channels']
-    sd['backbone.conv1.weight'] = _kaiming(g, stem, 3, 7, 7)
-    _bn(sd, g, 'backbone.bn1', stem)
+    scratch = bb.get('norm', 'BN') == 'GN'
+    if bb.get('deep_stem'):       # mmdet ResNet deep stem: Sequential(conv, norm, relu) x 3 -> stem.{0,1,3,4,6,7}
+        for i, (ci, co) in enumerate(((3, stem // 2), (stem // 2, stem // 2), (stem // 2, stem))):
+            sd[f'backbone.stem.{3 * i}.weight'] = _kaiming(g, co, ci, 3, 3)
+            (_gn if scratch else _bn)(sd, g, f'backbone.stem.{3 * i + 1}', co)
+    else:
+        sd['backbone.conv1.weight'] = _kaiming(g, stem, 3, 7, 7)
+        (_gn if scratch else _bn)(sd, g, 'backbone.gn1' if scratch else 'backbone.bn1', stem)
     cin = stem
-    for li, (nblk, planes) in enumerate(zip(bb['stage_blocks'], bb['stage_planes'])):
+    for li, (nblk, planes, stride) in enumerate(zip(bb['stage_blocks'], bb['stage_planes'], bb['strides'])):
         cout = planes * 4
         for b in range(nblk):
-            _bottleneck(sd, g, f'backbone.layer{li + 1}.{b}', cin, planes, cout,
-                        downsample=(b == 0))
+            if scratch:
+                _bottleneck_gn(sd, g, f'backbone.layer{li + 1}.{b}', cin, planes, cout, downsample=(b == 0),
+                               pooled=bool(bb.get('avg_down')) and stride != 1)
+            else:
+                _bottleneck(sd, g, f'backbone.layer{li + 1}.{b}', cin, planes, cout,
+                            downsample=(b == 0))
             cin = cout
 
     rp = cfg['rpn_head']

@@ -63,6 +63,19 @@ int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, vo
 /* 3x3/2 pad 1 max-pool of the ResNet stem */
 int fgn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n_img, int H, int W, int C, void* stream);
 
+/* GroupNorm over NHWC (+ residual) (+ ReLU): the norm layers of the from-scratch backbone variant
+ * (fgn_r50_c4_scratch.py:16-23, norm_cfg GN(32); torch.nn.GroupNorm inside mmdet ResNet at
+ * fgn.py:71-73).  y = (x - mean_g) * rstd_g * gamma[c] + beta[c] per (image, group);
+ * ws from fgn_group_norm_workspace_bytes.  x == y (in place) is allowed. */
+size_t fgn_group_norm_workspace_bytes(int n_img, int HW, int C, int groups);
+int fgn_group_norm_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta,
+                            const float* residual, void* ws, size_t ws_bytes, int n_img, int HW, int C,
+                            int groups, float eps, int relu, void* stream);
+
+/* AvgPool2d(2, stride 2, ceil_mode, count_include_pad=False): shortcut of a strided bottleneck
+ * under avg_down (fgn_r50_c4_scratch.py:18-19); out [n, ceil(H/2), ceil(W/2), C] */
+int fgn_avgpool2x2_nhwc_f32(const float* x, float* y, int n_img, int H, int W, int C, void* stream);
+
 /* RoIAlign (avg), rois [R,5] = (batch_idx,x1,y1,x2,y2), out [R,P,P,C].
  * aligned=1,sampling_ratio=0 : mmcv.ops.RoIAlign (fgn_roi_head.py:331,366)
  * aligned=0,sampling_ratio=-1: torchvision.ops.roi_align (fgn_roi_head.py:429,432) */
