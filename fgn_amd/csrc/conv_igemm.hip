@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     for (int kt = kt0; kt < KT; ++kt) {
         int nxt = cur + NSTAGE - 1;
         if (nxt >= NSTAGE) nxt -= NSTAGE;
-        issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
+        if (!(CONV_DBG & 1)) issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
         asm volatile("" ::: "memory");
 
         const float* As = rd_a + cur * STAGE;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         // with NSTAGE == 3 the DMAs of tile t+2 stay in flight across the barrier.
         if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(CONV_DBG & 8)) __builtin_amdgcn_s_barrier();
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches

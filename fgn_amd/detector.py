@@ -165,6 +165,54 @@ class _BottleneckGN:
         return self._norm(ops.conv2d(y, self.conv3), 2, True, residual=idt)   # relu(gn3(conv3) + identity)
 
 
+class _GraphedEpisode:
+    """The launch sequence of ``FGN._detect_eager`` for one input geometry, captured once as a
+    hipGraph (both HIP streams of the path fork from and join the capture stream).  Inputs are copied
+    into static device buffers (this copy is the H2D step of fgn.py:79-108 when the batch arrives on
+    the host), outputs live in static buffers that the next replay overwrites - so the replay waits
+    for the previous download, and the two tensors the rare RLE-overflow fallback reads are cloned."""
+    CODE_KEYS = ('vec', 'S', 'cat_mean_mp')
+
+    def __init__(self, model, ins: dict, img_shape, support_code, dev):
+        self.static = {k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in ins.items()}
+        self.img_shape = torch.as_tensor(img_shape).cpu().clone()
+        self.code = None
+        if support_code is not None:
+            self.code = dict(support_code)
+            for k in self.CODE_KEYS:
+                self.code[k] = support_code[k].clone()
+        self.last_download = None
+        for k, v in ins.items():
+            self.static[k].copy_(v, non_blocking=True)
+        args = lambda: (self.static['qry_img'], self.static.get('spp_imgs'), self.static.get('spp_bboxes'),
+                        self.static.get('spp_isegmaps'), self.img_shape, self.code)
+        # eager pass first: packs the weights, sets kernel attributes, sizes the allocator pools
+        model._detect_eager(*args(), download=False)
+        torch.cuda.current_stream().synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outs = model._detect_eager(*args(), download=False)
+
+    def run(self, model, ins: dict, support_code, main) -> list:
+        for k, v in ins.items():
+            self.static[k].copy_(v, non_blocking=True)
+        if support_code is not None:
+            for k in self.CODE_KEYS:
+                if support_code[k].data_ptr() != self.code[k].data_ptr():
+                    self.code[k].copy_(support_code[k], non_blocking=True)
+        if self.last_download is not None:
+            main.wait_event(self.last_download)       # static outputs are still being read by the copy stream
+        self.graph.replay()
+        outs = []
+        for d in self.outs:
+            d = dict(d)
+            d['mask_prob'], d['det_bboxes_copy'] = d['mask_prob'].clone(), d['det_bboxes'].clone()
+            outs.append(d)
+        model._start_download(outs, main)
+        self.last_download = outs[0]['host_ready']
+        return outs
+
+
 class FGN(torch.nn.Module):
     """Fully Guided Network, inference path, on MI355X HIP kernels."""
     fp16_enabled = False
@@ -186,6 +234,8 @@ class FGN(torch.nn.Module):
         self._packed_device = None
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
         self.use_side_stream = True               # support branch on a second HIP stream
+        self.use_graphs = False                   # replay a captured hipGraph per input geometry
+        self._graphs: dict = {}
         self._side_stream = None
         self._copy_stream = None
         self._pinned_ring: list = []
@@ -214,6 +264,7 @@ class FGN(torch.nn.Module):
                     raise ValueError(f'shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._sd[k].shape)}')
                 self._sd[k] = sd[k].detach().float().cpu()
         self._packed_device = None
+        self._graphs = {}
 
     def _pack(self, device):
         """Fold BN, re-layout weights for the kernels and move them to ``device``."""
@@ -343,7 +394,8 @@ class FGN(torch.nn.Module):
         backbone pass and the AG-RPN class vectors."""
         N, K = self.n_ways, self.k_shots
         spp = spp_imgs.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, *spp_imgs.shape[-3:])
-        spp_xyxy = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)[:, [1, 0, 3, 2]]
+        b = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)
+        spp_xyxy = torch.stack((b[:, 1], b[:, 0], b[:, 3], b[:, 2]), 1)      # no host-built index tensor: graph-capturable
         spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
         spp_fmaps = self.extract_feat(spp)                                      # [B*N*K,s,s,C]
         vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
@@ -383,11 +435,34 @@ class FGN(torch.nn.Module):
 
     @torch.no_grad()
     def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None) -> list:
-        """Everything up to (not including) the device->host copy.  Returns, per image, a
-        dict of device tensors: det_bboxes [D,5], det_labels [D], n_dets [1], masks u8 [D,H,W].
-        With ``support_code`` (from ``encode_supports``) the support branch is skipped."""
+        """Everything up to the host wait: queues the whole path and the device->host copies of the
+        results.  Returns, per image, a dict of device tensors (det_bboxes [D,5], det_labels [D],
+        n_dets [1], mask_prob, RLE bytes) plus the pinned host slot ``pack_results`` reads.
+        With ``support_code`` (from ``encode_supports``) the support branch is skipped.  With
+        ``use_graphs`` the launch sequence of one input geometry is captured once into a hipGraph
+        and replayed (same kernels, same results; ~0.2 ms of host time instead of ~10 ms)."""
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('FGN.simple_test needs a GPU: the HIP path has no CPU fallback')
+        if self.use_graphs and self.debug_trace is None and ops.PROFILE is None:
+            return self._detect_graphed(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
+        return self._detect_eager(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
+
+    def _detect_graphed(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code) -> list:
+        main = torch.cuda.current_stream()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        ins = {'qry_img': qry_img}
+        if support_code is None:
+            ins.update(spp_imgs=spp_imgs, spp_bboxes=spp_bboxes, spp_isegmaps=spp_isegmaps)
+        hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
+        key = (main.cuda_stream, dev.index, hw, support_code is not None) + \
+            tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
+        ge = self._graphs.get(key)
+        if ge is None:
+            ge = self._graphs[key] = _GraphedEpisode(self, ins, img_shape, support_code, dev)
+        return ge.run(self, ins, support_code, main)
+
+    def _detect_eager(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None,
+                      download=True) -> list:
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._packed_device != dev:
             self._pack(dev)
@@ -452,8 +527,9 @@ class FGN(torch.nn.Module):
                 side.wait_event(rpn_start)
                 self._support_back(sc, B, dev)
                 spp_ready = side.record_event()
-            for key in ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):   # produced on side, consumed on main
-                sc[key].record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():
+                for key in ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):   # produced on side, consumed on main
+                    sc[key].record_stream(main)
         S, cat_mean, cat_mean_mp, masks7 = sc['S'], sc['cat_mean'], sc['cat_mean_mp'], sc['masks7']
 
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
@@ -503,7 +579,8 @@ class FGN(torch.nn.Module):
                     n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
             outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mprob, rle_bytes=rle_bytes,
                              rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
-        self._start_download(outs, main)
+        if download:
+            self._start_download(outs, main)
         return outs
 
     def _pinned_slot(self, batch: int, max_det: int) -> dict:
@@ -576,7 +653,8 @@ class FGN(torch.nn.Module):
                 thr = self.cfg['test_cfg']['rcnn']['mask_thr_binary']
                 for j in np.flatnonzero(ovf):
                     dense = ops.mask_paste(di['mask_prob'][j:j + 1].contiguous(),
-                                           di['det_bboxes'][j:j + 1].contiguous(), ih, iw, thr)
+                                           di.get('det_bboxes_copy', di['det_bboxes'])[j:j + 1].contiguous(),
+                                           ih, iw, thr)
                     rles[j] = rle.encode(dense[0].cpu().numpy())
             one = {'dt_scores': db[:, 4].reshape(-1).copy(),
                    'dt_bboxes': db[:, [1, 0, 3, 2]].reshape(-1, 4).copy(),

@@ -20,7 +20,27 @@ from . import lib as _lib
 
 # When set to a list, conv2d appends (start_event, end_event, flop_per_image, n_img,
 # n_img_dev) per launch: live HIP-event timing of the dominant kernel (bench.py roofline).
-PROFILE = None
+PROFILE = None          # a list (or ConvProfile): conv2d appends (e0, e1, flop_per_img, n_img, n_img_dev, shape)
+
+
+class ConvProfile(list):
+    """Record list for the ``PROFILE`` hook with a pool of pre-created timing events: creating HIP
+    timing events inside a timed region stalls now and then (tens of ms when the runtime grows its
+    event pool), so a benchmark creates them up front with ``reserve``."""
+
+    def __init__(self):
+        super().__init__()
+        self.pool = []
+
+    def reserve(self, n_pairs: int):
+        self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * n_pairs))
+        return self
+
+    def pair(self):
+        if len(self.pool) >= 2:
+            return self.pool.pop(), self.pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
 
 
 def _stream() -> int:
@@ -131,7 +151,8 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
         _chk(n_img_dev, 'n_img_dev', torch.int32)
     prof = PROFILE
     if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = prof.pair() if isinstance(prof, ConvProfile) else \
+            (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         e0.record()
     L = _lib.load()
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,

@@ -253,3 +253,49 @@ def test_support_code_cache_is_identical():
         two = make_batch(0, 2, 3, 2, 160, 224, 64)
         model.simple_test(**{k: v for k, v in two.items() if not k.startswith('spp_i') and k != 'spp_bboxes'},
                           support_code=code)
+
+
+def test_hip_graph_replay_is_identical():
+    """``use_graphs``: the captured hipGraph replays the same kernels - identical bytes to the eager
+    launch sequence, across different inputs, batch 2, and with a cached support code."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+
+    def same(a, b):
+        for x, y in zip(a, b):
+            assert len(x['dt_scores']) > 0
+            for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+                assert np.array_equal(x[key], y[key]), key
+            assert x['dt_isegmaps_rle'] == y['dt_isegmaps_rle']
+
+    batches = [make_batch(4 * q, 2, 3, 2, 160, 224, 64) for q in range(3)]
+    eager = [model.simple_test(**b, rescale=True) for b in batches]
+    model.use_graphs = True
+    for rep in range(2):                       # second round replays an existing graph
+        for b, e in zip(batches, eager):
+            same(e, model.simple_test(**b, rescale=True))
+    assert len(model._graphs) == 1
+    # pipelined use: queue two replays before reading the first result (static outputs are reused)
+    d0 = model.detect_device(batches[0]['qry_img'], batches[0]['spp_imgs'], batches[0]['spp_bboxes'],
+                             batches[0]['spp_isegmaps'], batches[0]['img_shape'])
+    d1 = model.detect_device(batches[1]['qry_img'], batches[1]['spp_imgs'], batches[1]['spp_bboxes'],
+                             batches[1]['spp_isegmaps'], batches[1]['img_shape'])
+    strip = lambda rs: [{k: r[k] for k in ('dt_scores', 'dt_bboxes', 'dt_cat_ids', 'dt_isegmaps_rle')} for r in rs]
+    same(eager[0], strip(model.pack_results(d0, 2)))
+    same(eager[1], strip(model.pack_results(d1, 2)))
+    # another geometry -> another graph; cached support code
+    one = make_batch(7, 1, 3, 2, 128, 160, 64)
+    model.use_graphs = False
+    code = model.encode_supports(one['spp_imgs'], one['spp_bboxes'], one['spp_isegmaps'])
+    ref = model.simple_test(**one, rescale=True)
+    model.use_graphs = True
+    q_only = {k: v for k, v in one.items() if not k.startswith('spp_i') and k != 'spp_bboxes'}
+    same(ref, model.simple_test(**q_only, support_code=code, rescale=True))
+    same(ref, model.simple_test(**q_only, support_code=code, rescale=True))
+    same(ref, model.simple_test(**one, rescale=True))
+    assert len(model._graphs) == 3
