@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--inflight', type=int, default=1, help='independent episodes in flight per GPU')
     ap.add_argument('--graphs', action='store_true', help='replay one captured hipGraph per step instead of launching from Python '
                     '(same GPU time; host enqueue 0.2-0.8 ms instead of 1.4-2.4 ms)')
+    ap.add_argument('--no-winograd', action='store_true', help='direct implicit-GEMM form for every 3x3 convolution')
     ap.add_argument('--cache-supports', action='store_true',
                     help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
     args = ap.parse_args()
@@ -99,6 +100,7 @@ def main():
     sd = init_state_dict(cfg, 0)
     model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
     model.use_graphs = args.graphs
+    model.use_winograd = not args.no_winograd
 
     # distinct seeded episodes per rank, inputs resident in HBM before timing
     n_distinct = 4
@@ -198,14 +200,22 @@ def main():
     n_prof_steps = len(prof_steps)
 
     # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
+    # conv_flop: FLOPs of the convolutions as the layers define them (direct form, 2*M*N*K: what the
+    # reference's formulation spends on these launches); mfma_flop: MFMA work actually issued, which is 16/36
+    # of that for the layers run in Winograd F(2x2,3x3) form (their event bracket spans transform + GEMM +
+    # transform).
     conv_ms = 0.0
     conv_flop = 0.0
-    for (e0, e1, flop_per_img, n_img, n_img_dev, _shape) in prof:
+    mfma_flop = 0.0
+    for rec in prof:
+        e0, e1, flop_per_img, n_img, n_img_dev = rec[:5]
         conv_ms += e0.elapsed_time(e1)
         n = n_img if n_img_dev is None else min(n_img, int(n_img_dev.item()))
         conv_flop += flop_per_img * n
+        mfma_flop += flop_per_img * n * (rec[6] if len(rec) > 6 else 1.0)
     n_launch = max(len(prof), 1)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    achieved_mfma = mfma_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
     # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
     # same command (tools/profile_round.sh), corrected per MI355X_MICROARCH.md; PMC collection
@@ -240,12 +250,21 @@ def main():
                                    f'{shape["n_ways"] * shape["k_shots"]}x3x{shape["spp_size"]}^2, ResNet-50-C4, '
                                    f'R<={R} proposals, D<={max_det} detections, 1 episode per GPU per step',
                        'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
+                       'winograd_3x3': bool(model.use_winograd),
                        'avg_detections': n_d / args.steps,
                        'algorithmic_gflop_per_episode': round(gflop, 1),
                        'algorithmic_tflops': round(gflop * world * args.steps / dt / 1e3, 2)},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel + conv_igemm_kernel (all conv launches)',
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'all convolution launches (conv_streamk16 / conv_igemm_dma / conv_igemm kernels; '
+                                   'Winograd layers: wg_input + grouped conv_streamk16 + wg_output)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'flop_convention': 'direct-convolution FLOPs of the launched layers (2*M*N*K) / HIP-event time; '
+                                            'achieved_mfma_issued counts the MFMA work actually issued '
+                                            '(Winograd layers issue 16/36 of their direct FLOPs)',
+                         'achieved_mfma_issued': round(achieved_mfma, 2),
+                         'frac_mfma_issued': round(achieved_mfma / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'traffic': traffic,
                          'traffic_unit': 'HBM bytes per conv launch (PMC, profiles/*conv_traffic.json)',
                          'launches_per_step': n_launch / n_prof_steps, 'profiled_steps': n_prof_steps,
                          'avg_launch_us': round(conv_ms * 1e3 / n_launch, 2),

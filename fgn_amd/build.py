@@ -17,6 +17,7 @@ SOURCES = [
     ('abi.hip', []),
     ('spatial.hip', ['-ffp-contract=off']),
     ('norm.hip', []),
+    ('winograd.hip', []),
     ('relation.hip', []),
     ('rpn_post.hip', ['-ffp-contract=off']),
     ('det_post.hip', ['-ffp-contract=off']),

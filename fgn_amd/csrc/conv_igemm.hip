@@ -51,6 +51,12 @@ struct ConvParams {
     float* ws;
     int splits, kt_per_split;
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
+    // grouped GEMM (Winograd, stream-K 16x16x4 kernel only): rows [g*grp_rows, (g+1)*grp_rows) use the weight
+    // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
+    // grp_valid, or min(grp_items, *grp_count_dev) * grp_rows_per_item when the item count lives on the
+    // device.  grp_rows == 0: plain convolution.
+    int grp_rows, grp_valid, grp_items, grp_rows_per_item, grp_w_stride;
+    const int32_t* grp_count_dev;
 };
 
 #ifndef CONV_DMA_STAGES
@@ -897,6 +903,15 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
         const int m0 = tile_m * BM;
         const int n0 = tile_n * BN;
 
+        int w_grp_off = 0;          // bytes
+        if (p.grp_rows) {
+            const int grp = m0 / p.grp_rows;
+            int valid = p.grp_valid;
+            if (p.grp_count_dev) valid = min(valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+            if (m0 - grp * p.grp_rows >= valid) continue;      // tile of rows nobody reads (wave-uniform)
+            w_grp_off = grp * p.grp_w_stride * 4;
+        }
+
         int a_off[A_LD];
         unsigned long long a_taps[A_LD];
 #pragma unroll
@@ -920,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
                 a_taps[i] = tm;
             }
         }
-        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4 + w_grp_off;
 
         auto issue_tile = [&](int kt, int stage) {
             const int tap = kt / cin_tiles;
@@ -1245,6 +1260,8 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     p.in_scale = in_scale; p.n_img_dev = n_img_dev;
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
+    p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
+    p.grp_count_dev = nullptr;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return FGN_ERR_SHAPE;
@@ -1299,4 +1316,39 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         case 4: return launch_cfg<64, 64, 32, 32, 4>(p, (int)M, cin4, stream);
         default: return FGN_ERR_ARG;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 16 batched GEMMs of a Winograd F(2x2,3x3) convolution (winograd.hip holds the transforms):
+//   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = 0..15 (position in the 4x4 transformed tile)
+// run as ONE stream-K launch over the stacked rows [16 * t_pad] with a per-group weight matrix.
+// t_pad is a multiple of the 128-row tile so no tile straddles two groups.
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t fgn_winograd_gemm_workspace_bytes(void) {
+    return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
+}
+
+extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
+                                     int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, float* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
+    if (!V || !U || !Mo || !ws) return FGN_ERR_ARG;
+    if (n_img <= 0) return FGN_OK;
+    if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % SK_TILE != 0 ||
+        (long long)n_img * tiles_per_img > t_pad)
+        return FGN_ERR_SHAPE;
+    if (ws_bytes < fgn_winograd_gemm_workspace_bytes()) return FGN_ERR_ARG;
+    const long long rows = 16ll * t_pad;
+    const long long xb = rows * Cin * 4, wb = 16ll * cout_pad * Cin * 4;
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
+    p.n_img_dev = nullptr;
+    p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
+    p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
+    p.ws = ws; p.splits = 16; p.kt_per_split = Cin / BK;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
+    p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
+    p.n_tiles_n = 0;
+    return launch_streamk(p, (int)rows, stream);
 }

@@ -101,11 +101,17 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
 
 # ------------------------------------------------------------------------------------------
 class _Bottleneck:
-    def __init__(self, sd, prefix, stride, eps):
+    WG_MIN_IMAGES = 64      # below this the 16 GEMMs are too small for the 512-workgroup stream-K launch
+
+    def __init__(self, sd, prefix, stride, eps, winograd=False):
         bn = lambda n: {k: sd[f'{prefix}.{n}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
         self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'], bn=bn('bn1'), relu=True, eps=eps)
         self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], bn=bn('bn2'), stride=stride, pad=1, relu=True,
                                    eps=eps)
+        # Winograd form of the 3x3 for large RoI batches (shared_head only; 2.25x fewer MFMA passes)
+        w2 = sd[prefix + '.conv2.weight']
+        self.conv2_wg = ops.pack_winograd(w2, bn=bn('bn2'), relu=True, eps=eps) \
+            if winograd and stride == 1 and w2.shape[1] % 32 == 0 and w2.shape[0] % 4 == 0 else None
         self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'], bn=bn('bn3'), relu=True, eps=eps)
         self.down = None
         if (prefix + '.downsample.0.weight') in sd:
@@ -113,12 +119,15 @@ class _Bottleneck:
             self.down = ops.pack_conv(sd[prefix + '.downsample.0.weight'], bn=dbn, stride=stride, eps=eps)
 
     def layers(self):
-        return [l for l in (self.conv1, self.conv2, self.conv3, self.down) if l is not None]
+        return [l for l in (self.conv1, self.conv2, self.conv3, self.down, self.conv2_wg) if l is not None]
 
     def __call__(self, x, n_img_dev=None):
         idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
         y = ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
-        y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
+        if self.conv2_wg is not None and y.shape[0] >= self.WG_MIN_IMAGES:
+            y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
+        else:
+            y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
 
 
@@ -235,6 +244,7 @@ class FGN(torch.nn.Module):
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
         self.use_side_stream = True               # support branch on a second HIP stream
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
+        self.use_winograd = True                  # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
         self._graphs: dict = {}
         self._side_stream = None
         self._copy_stream = None
@@ -298,11 +308,14 @@ class FGN(torch.nn.Module):
                 _Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps) for b in range(nblk)])
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
+        wr = sd['rpn_head.rpn_conv.weight']
+        P['rpn_conv_wg'] = ops.pack_winograd(wr, bias=sd['rpn_head.rpn_conv.bias'], relu=True) \
+            if self.use_winograd and wr.shape[1] % 32 == 0 and wr.shape[0] % 4 == 0 else None
         # objectness and delta 1x1 convs fused into one launch: channels [0,A) | [A,5A)
         P['rpn_head'] = ops.pack_conv(
             torch.cat([sd['rpn_head.rpn_cls.weight'], sd['rpn_head.rpn_reg.weight']], 0),
             bias=torch.cat([sd['rpn_head.rpn_cls.bias'], sd['rpn_head.rpn_reg.bias']], 0))
-        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps)
+        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
                        for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
         # relation conv split along its input channels: [Wq | Ws] (fgn_roi_head.py:270)
         wrel = sd['roi_head.cls_reg_shared_conv.weight']
@@ -331,7 +344,7 @@ class FGN(torch.nn.Module):
         def mv(o):
             if isinstance(o, torch.Tensor):
                 return o.float().contiguous().to(device)
-            if isinstance(o, ops.ConvLayer):
+            if isinstance(o, (ops.ConvLayer, ops.WinogradLayer)):
                 return o.to(device)
             if isinstance(o, _Bottleneck):
                 for l in o.layers():
@@ -513,7 +526,10 @@ class FGN(torch.nn.Module):
         rpn_start = main.record_event()
         # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
         # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
-        x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
+        if P['rpn_conv_wg'] is not None:      # Winograd F(2x2,3x3); the guidance multiply rides in its input transform
+            x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
+        else:
+            x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)

@@ -171,6 +171,95 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
 
 
 # --------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) form of 3x3 / stride 1 / pad 1 convolutions
+# --------------------------------------------------------------------------------------
+@dataclass
+class WinogradLayer:
+    """U [16, cout_pad, Cin] = G w G^T with the per-channel epilogue scale folded in; shift [Cout]."""
+    u: torch.Tensor
+    shift: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    cout_pad: int
+    relu: bool
+
+    def to(self, device):
+        self.u = self.u.to(device)
+        self.shift = None if self.shift is None else self.shift.to(device)
+        return self
+
+
+_WG_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
+                  relu: bool = False, eps: float = 1e-5) -> WinogradLayer:
+    """weight [Cout,Cin,3,3] -> WinogradLayer (transform in fp64, stored fp32)."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or cin % 32 != 0 or cout % 4 != 0:
+        raise _lib.FgnHipError('pack_winograd: needs a 3x3 kernel, Cin % 32 == 0, Cout % 4 == 0')
+    w = weight.detach().double()
+    scale = shift = None
+    if bn is not None:
+        scale = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + eps)
+        shift = bn['bias'].double() - bn['running_mean'].double() * scale
+        if bias is not None:
+            shift = shift + bias.double() * scale
+        w = w * scale[:, None, None, None]
+    elif bias is not None:
+        shift = bias.detach().double()
+    u = torch.einsum('ai,ocij,bj->aboc', _WG_G, w, _WG_G)                    # [4,4,Cout,Cin]
+    cout_pad = (cout + 127) // 128 * 128
+    up = torch.zeros(16, cout_pad, cin, dtype=torch.float32)
+    up[:, :cout] = u.reshape(16, cout, cin).float()
+    return WinogradLayer(up.contiguous(), None if shift is None else shift.float().contiguous(), cin, cout,
+                         cout_pad, relu)
+
+
+def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[torch.Tensor] = None,
+                     a_img_div: int = 1, n_img_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [n_in,H,W,Cin] -> relu?(conv3x3(x[i // a_img_div] * in_scale[i]) + shift) [n_in*a_img_div,H,W,Cout]."""
+    _chk(x, 'x')
+    n_in, H, W, cin = x.shape
+    if cin != layer.cin:
+        raise _lib.FgnHipError(f'conv3x3_winograd: Cin {cin} != layer Cin {layer.cin}')
+    n_img = n_in * a_img_div
+    if in_scale is not None:
+        _chk(in_scale, 'in_scale')
+        if tuple(in_scale.shape) != (n_img, cin):
+            raise _lib.FgnHipError('conv3x3_winograd: in_scale must be [n_img, Cin]')
+    if n_img_dev is not None:
+        _chk(n_img_dev, 'n_img_dev', torch.int32)
+    tiles = ((H + 1) // 2) * ((W + 1) // 2)
+    t_pad = (n_img * tiles + 127) // 128 * 128
+    L = _lib.load()
+    V = torch.empty((16, t_pad, cin), device=x.device, dtype=torch.float32)
+    Mo = torch.empty((16, t_pad, layer.cout), device=x.device, dtype=torch.float32)
+    y = torch.empty((n_img, H, W, layer.cout), device=x.device, dtype=torch.float32)
+    ws_bytes = L.fgn_winograd_gemm_workspace_bytes()
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = prof.pair() if isinstance(prof, ConvProfile) else \
+            (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        e0.record()
+    st = _stream()
+    _lib.check(L.fgn_winograd_input_f32(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W,
+                                        cin, t_pad, st), 'fgn_winograd_input_f32')
+    _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
+                                       layer.cout, layer.cout_pad, _ptr(ws), ws_bytes, st), 'fgn_winograd_gemm_f32')
+    _lib.check(L.fgn_winograd_output_f32(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W,
+                                         layer.cout, t_pad, int(layer.relu), st), 'fgn_winograd_output_f32')
+    if prof is not None:
+        e1.record()
+        # direct-convolution FLOPs of the layer (what the reference's formulation executes); the MFMA work
+        # actually issued is 16/36 of it
+        prof.append((e0, e1, 2.0 * H * W * layer.cout * 9 * cin, n_img, n_img_dev, (n_img, H, W, cin, layer.cout, 3, 1),
+                     16.0 / 36.0))
+    return y
+
+
+# --------------------------------------------------------------------------------------
 # spatial ops
 # --------------------------------------------------------------------------------------
 def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
