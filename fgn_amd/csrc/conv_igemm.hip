@@ -30,6 +30,7 @@
 //     loader, optional split-K), conv_streamk_kernel (LDS-DMA, persistent stream-K); the
 //     dispatcher at the bottom of the file picks one per launch.
 #include "common.h"
+#include <cstdlib>
 
 struct ConvParams {
     const float* x;
@@ -1211,6 +1212,8 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
     if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
     if (Cout % 4) return 1;
     const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
+    static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
+    if (forced > 0) return std::max(1, std::min(forced, KT / 2));
     if (blocks >= 512 || KT < 8) return 1;
     int s = (int)((1024 + blocks - 1) / blocks);
     s = std::min(s, KT / 4);

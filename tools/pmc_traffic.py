@@ -4,12 +4,15 @@ gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes 
 (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact; both are in KiB."""
 import csv, glob, json, sys
 
+# every kernel inside bench.py's per-layer HIP-event brackets
+CONV_FAMILY = ('conv_igemm', 'conv_streamk', 'streamk_fixup', 'splitk_epilogue', 'wg_input', 'wg_output')
+
 
 def collect(d, counter):
     tot, n = 0.0, 0
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and ('conv_igemm' in r['Kernel_Name'] or 'conv_streamk' in r['Kernel_Name']):
+            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in CONV_FAMILY):
                 tot += float(r['Counter_Value'])
                 n += 1
     return tot, n
@@ -17,7 +20,7 @@ def collect(d, counter):
 
 fetch, nf = collect(sys.argv[1], 'FETCH_SIZE')
 write, nw = collect(sys.argv[2], 'WRITE_SIZE')
-out = {'kernel': 'conv_igemm*_kernel', 'launches_fetch_pass': nf, 'launches_write_pass': nw,
+out = {'kernel': ' + '.join(CONV_FAMILY), 'launches_fetch_pass': nf, 'launches_write_pass': nw,
        'FETCH_SIZE_KiB_per_launch_raw': fetch / max(nf, 1), 'WRITE_SIZE_KiB_per_launch': write / max(nw, 1),
        'hbm_bytes_per_launch': (2.0 * fetch / max(nf, 1) + write / max(nw, 1)) * 1024.0,
        'note': 'FETCH_SIZE doubled (gfx950 wide-read correction); separate --pmc passes; same command as bench.py'}
