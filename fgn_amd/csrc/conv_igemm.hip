@@ -586,7 +586,52 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches
 
-    // ---- epilogue (same as the register-staged kernel)
+    // ---- epilogue.  64x64 tile: accumulators take a round trip through the (now idle) LDS stages so that
+    // every lane moves 16 B of one output row - 4x fewer, fully coalesced global instructions than storing
+    // the MFMA layout directly (each half-wave 128 B); this is what bounds the small-K 1x1 layers, whose
+    // epilogue (68 MB residual read + 68 MB store at layer1) outweighs their K loop.
+    if constexpr (TM == 1 && TN == 1) if ((p.Cout & 3) == 0) {
+        constexpr int PITCH = BN + 4;                 // floats; 272 B rows keep b128 alignment, shift banks by 4
+        static_assert(BM * PITCH <= NSTAGE * STAGE, "C tile fits in the stage buffers");
+        {
+            float* cw = smem + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[0][0][r];
+        }
+        __syncthreads();
+        const int c4 = t & 15, rr = t >> 4;
+        const int n = n0 + c4 * 4;
+        if (n < p.Cout) {
+            const bool raw = p.splits > 1;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!raw && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+            if (!raw && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+            float* dst = raw ? p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout : p.y;
+            float4 res[BM / 16];
+#pragma unroll
+            for (int k = 0; k < BM / 16; ++k) {       // residual loads first: their latency overlaps the LDS reads
+                const int m = m0 + rr + 16 * k;
+                res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!raw && p.residual && m < M)
+                    res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
+            }
+#pragma unroll
+            for (int k = 0; k < BM / 16; ++k) {
+                const int m = m0 + rr + 16 * k;
+                if (m >= M) continue;
+                float4 v = *reinterpret_cast<const float4*>(smem + (rr + 16 * k) * PITCH + c4 * 4);
+                if (!raw) {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                if (!(CONV_DBG & 32) || v.x == 12345.678f) *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n) = v;
+            }
+        }
+        return;
+    }
     if (p.splits > 1) {
         float* slab = p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout;
 #pragma unroll
