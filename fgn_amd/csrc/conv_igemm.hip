@@ -1055,43 +1055,58 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
             cur ^= 1;
         }
 
-        // C/D layout of 16x16x4: col = lane&15 (-> n), row = 4*(lane>>4) + r (-> m)
-        if (kb == 0 && ke == KT) {
+        // C/D layout of 16x16x4: col = lane&15 (-> n), row = 4*(lane>>4) + r (-> m).  Stored straight from
+        // registers that is 64 B per (row, 16-lane group); instead the 128x128 tile takes a round trip through
+        // the 64 KB of LDS (idle between segments): columns rotated by 16*((row>>2)&3) floats so the four
+        // row groups of a wave land in different banks, then every lane moves 16 B and a half-wave one
+        // 512 B row segment - to y with the fused epilogue, or raw to this block's slab.
+        {
+            const int g16 = 16 * kgrp;                     // (row >> 2) & 3 == kgrp for row = 16i + 4*kgrp + r
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + frag_row;
-                const bool n_ok = n < p.Cout;
-                const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
-                const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
+                const int col = (wn * WN + j * 16 + frag_row + g16) & (SK_TILE - 1);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int mb = m0 + wm * WM + i * 16 + 4 * kgrp;
+                    float* cw = smem + (wm * WM + i * 16 + 4 * kgrp) * SK_TILE + col;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mb + r;
-                        if (n_ok && m < M) {
-                            const size_t o = (size_t)m * p.Cout + n;
-                            float v = acc[i][j][r] * sc + sh;
-                            if (p.residual) v += p.residual[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            p.y[o] = v;
-                        }
-                    }
-                }
-            }
-        } else {
-            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * WN + j * 16 + frag_row;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int rb = wm * WM + i * 16 + 4 * kgrp;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) slab[(rb + r) * SK_TILE + col] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) cw[r * SK_TILE] = acc[i][j][r];
                 }
             }
         }
+        __syncthreads();
+        {
+            const bool whole = (kb == 0 && ke == KT);
+            const int c4 = t & 31, rr = t >> 5;            // 32 float4 per row, 8 rows per pass
+            const int n = n0 + c4 * 4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool n_ok = n < p.Cout;                  // Cout % 4 == 0 (dispatcher)
+            if (whole && n_ok && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+            if (whole && n_ok && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
+#pragma unroll 4
+            for (int k = 0; k < SK_TILE / 8; ++k) {
+                const int row = rr + 8 * k;
+                const int pc = (c4 * 4 + 16 * ((row >> 2) & 3)) & (SK_TILE - 1);
+                float4 v = *reinterpret_cast<const float4*>(smem + row * SK_TILE + pc);
+                if (!whole) {
+                    *reinterpret_cast<float4*>(slab + row * SK_TILE + c4 * 4) = v;
+                    continue;
+                }
+                const int m = m0 + row;
+                if (!n_ok || m >= M) continue;
+                const size_t o = (size_t)m * p.Cout + n;
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (p.residual) {
+                    const float4 rs = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                }
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+        }
+        __syncthreads();                                   // LDS is the DMA target of the next segment
     }
 }
 
@@ -1285,8 +1300,6 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     const int KT = cdiv(KH * KW * Cin, BK);
     if (use_streamk(M, Cin, Cout, KT, tile_hint)) return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
     if (tile_hint > 0 && tile_hint != 4) return 0;
-    const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
-    if (tile_hint == 0 && b128 >= 400 && b128 <= 512) return 0;
     const int s = plan_splits(M, Cout, KT, tile_hint);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
@@ -1344,10 +1357,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         return launch_streamk(p, (int)M, stream);
     }
     if (tile == 5 || tile == 6) tile = 1;       // stream-K not applicable here
-    if (tile == 0) {
-        const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
-        tile = (b128 >= 400 && b128 <= 512) ? 1 : 4;
-    }
+    if (tile == 0) tile = 4;     // with the float4 epilogue the 64x64 tile is at least as fast as 128x128 everywhere measured
     if (tile == 4 && splitk_ws) {
         const int KT = p.K / BK;
         const int sp = plan_splits(M, Cout, KT, tile_hint);

@@ -20,7 +20,8 @@ for it in range(3):
     torch.cuda.synchronize()
 tot = 0
 agg = {}
-for (e0, e1, fpi, n_img, nd, shp) in prof:
+for rec in prof:
+    e0, e1, fpi, n_img, nd, shp = rec[:6]
     ms = e0.elapsed_time(e1)
     n = n_img if nd is None else min(n_img, int(nd.item()))
     fl = fpi * n
