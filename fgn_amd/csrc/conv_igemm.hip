@@ -414,11 +414,16 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
     return r;
 }
 
-// PW = point-wise fast path (1x1, stride 1, no padding, a_img_div 1): im2col is the identity, so
+// MODE 1 = point-wise fast path (1x1, stride 1, no padding, a_img_div 1): im2col is the identity, so
 // the per-row index decode (integer divisions) and the tap masks are compiled out.  These layers
 // have K of 64..1024, i.e. 2..32 K-tiles, and are otherwise dominated by prologue instructions.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, bool PW>
+// MODE 2 = stem: Cin = 4 (NHWC4 image), KW <= 8.  A K-tile is one filter ROW: the 8 consecutive pixels
+// ix0..ix0+7 of input row iy0+ky are 128 contiguous bytes, i.e. exactly one LDS-DMA tile row; weights are packed
+// [Cout][KH][8][4] with zeros beyond KW (K = 32*KH).  Lane chunk = pixel: validity is per lane (x) and per
+// K-tile (y).
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, int MODE>
 __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
+    constexpr bool PW = MODE == 1, STEM = MODE == 2;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -464,6 +469,20 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         if (PW) {
             a_off[i] = (m * p.Cin + src_c4 * 4) * 4;
             a_taps[i] = m < M ? 1ull : 0ull;
+        } else if (STEM) {
+            if (m < M) {
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix = ox * p.stride - p.pad + src_c4;
+                a_off[i] = (((img / p.a_img_div) * p.H + iy0) * p.W + ix) * 16;      // bytes, 16 B per pixel
+                unsigned long long tm = 0ull;
+                if (src_c4 < p.KW && (unsigned)ix < (unsigned)p.W)
+                    for (int ky = 0; ky < p.KH; ++ky)
+                        if ((unsigned)(iy0 + ky) < (unsigned)p.H) tm |= 1ull << ky;
+                a_taps[i] = tm;
+            }
         } else if (m < M) {
             const int img = m / HoWo;
             const int rem = m - img * HoWo;
@@ -498,7 +517,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
 
     auto issue_tile = [&](int kt, int stage) {
         int tap = 0, tap_off = kt * BK * 4;
-        if (!PW) {
+        if (STEM) {
+            tap = kt;
+            tap_off = kt * p.W * 16;
+        } else if (!PW) {
             tap = kt / cin_tiles;
             const int c0 = (kt - tap * cin_tiles) * BK;
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -543,7 +565,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     for (int kt = kt0; kt < KT; ++kt) {
         int nxt = cur + NSTAGE - 1;
         if (nxt >= NSTAGE) nxt -= NSTAGE;
-        if (!(CONV_DBG & 1)) issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
+        // (with two stages the last iteration has nothing to prefetch; deeper pipelines keep the clamped
+        // re-load so that the counted s_waitcnt below stays exact)
+        if (!(CONV_DBG & 1) && (NSTAGE > 2 || kt + 1 < KT)) issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
         asm volatile("" ::: "memory");
 
         const float* As = rd_a + cur * STAGE;
@@ -579,8 +603,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         }
         // tile t+1 must have landed (own DMAs counted; the barrier covers the other waves');
         // with NSTAGE == 3 the DMAs of tile t+2 stay in flight across the barrier.
-        if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        // lgkmcnt(0): this wave's LDS reads of stage `cur` must have RETURNED before it signals the barrier -
+        // the waves released by the barrier DMA the next tile into this very stage.  (hipcc hoists the raw
+        // s_barrier above the last MFMAs and above the lgkmcnt wait it inserts for them; without the explicit
+        // wait a read still queued in the LDS pipe was overtaken by the next tile's data about once per 1e5
+        // tiles at 4-5 workgroups per CU: one wave's last k-slice of a K-tile wrong.)
+        if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
         if (!(CONV_DBG & 8)) __builtin_amdgcn_s_barrier();
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
@@ -590,11 +619,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     // every lane moves 16 B of one output row - 4x fewer, fully coalesced global instructions than storing
     // the MFMA layout directly (each half-wave 128 B); this is what bounds the small-K 1x1 layers, whose
     // epilogue (68 MB residual read + 68 MB store at layer1) outweighs their K loop.
-    if constexpr (TM == 1 && TN == 1) if ((p.Cout & 3) == 0) {
+    if constexpr (TM == 1 && TN == 1 && !(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
         constexpr int PITCH = BN + 4;                 // floats; 272 B rows keep b128 alignment, shift banks by 4
         static_assert(BM * PITCH <= NSTAGE * STAGE, "C tile fits in the stage buffers");
+        float* const cbase = smem;
         {
-            float* cw = smem + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
+            float* cw = cbase + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[0][0][r];
         }
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             for (int k = 0; k < BM / 16; ++k) {
                 const int m = m0 + rr + 16 * k;
                 if (m >= M) continue;
-                float4 v = *reinterpret_cast<const float4*>(smem + (rr + 16 * k) * PITCH + c4 * 4);
+                float4 v = *reinterpret_cast<const float4*>(cbase + (rr + 16 * k) * PITCH + c4 * 4);
                 if (!raw) {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
@@ -846,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own LDS reads returned (see conv_igemm_dma_kernel)
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
@@ -1050,7 +1080,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own LDS reads returned (see conv_igemm_dma_kernel)
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
@@ -1221,38 +1251,41 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     const dim3 grid(cdiv(M_max, BM) * p.n_tiles_n, p.splits);
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static const hipError_t attr_once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     if (attr_once != hipSuccess) return (int)attr_once;
-    if (!cin4 && !p.in_scale && p.x_bytes != 0) {
+    if (!p.in_scale && p.x_bytes != 0) {
         constexpr int NST = (BM + BN >= 256) ? 2 : CONV_DMA_STAGES;   // 128x128 keeps 2 blocks/CU
         const size_t dlds = (size_t)NST * (BM + BN) * BK * sizeof(float);
         static const hipError_t dma_attr = [] {
             hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, false>),
+                reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, true>),
+                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return e;
         }();
         if (dma_attr != hipSuccess) return (int)dma_attr;
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
-        if (pw)
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, true>), grid, dim3(256), dlds, stream, p);
+        if (cin4)
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
+        else if (pw)
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, false>), grid, dim3(256), dlds, stream, p);
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>), grid, dim3(256), dlds, stream, p);
     } else if (cin4)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, MW>), grid, dim3(256), lds, stream, p);
+        return FGN_ERR_SHAPE;      // the stem runs on the LDS-DMA kernel only (input < 2 GiB)
     else if (p.in_scale)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), grid, dim3(256), lds, stream, p);
     else
@@ -1329,6 +1362,10 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (KH * KW > 64) return FGN_ERR_SHAPE;                   // tap validity is a 64-bit mask
     const int k_raw = KH * KW * Cin;
     p.K = cdiv(k_raw, BK) * BK;
+    if (cin4) {                                   // stem layout: one K-tile per filter row, [KH][8 pixels][4]
+        if (KW > 8 || in_scale) return FGN_ERR_SHAPE;
+        p.K = KH * BK;
+    }
     // offsets are 32-bit element indices
     if ((long long)(n_img / a_img_div + 1) * H * W * Cin >= (1ll << 31)) return FGN_ERR_SHAPE;
     const long long M = (long long)n_img * p.Ho * p.Wo;
@@ -1343,7 +1380,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         // descriptor extents (< 4 GiB checked below); tile_hint >= 100 forces the register-staged kernel
         const long long xb = (long long)((n_img + a_img_div - 1) / a_img_div) * H * W * Cin * 4;
         const long long wb = (long long)cout_pad * p.K * 4;
-        const bool use_dma = tile_hint < 100 && xb < 0x7fffff00ll && wb < 0x7fffff00ll;
+        const bool use_dma = (tile_hint < 100 || cin4) && xb < 0x7fffff00ll && wb < 0x7fffff00ll;
         p.x_bytes = use_dma ? (unsigned)xb : 0u;
         p.w_bytes = use_dma ? (unsigned)wb : 0u;
         if (tile_hint >= 100) tile_hint -= 100;

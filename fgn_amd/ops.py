@@ -101,10 +101,19 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Opt
         weight = torch.cat([weight, weight.new_zeros(cout, pad_cin_to - cin, kh, kw)], dim=1)
         cin = pad_cin_to
     cout_pad = (cout + 127) // 128 * 128
-    k = kh * kw * cin
-    k_pad = (k + 31) // 32 * 32
-    w = weight.new_zeros(cout_pad, k_pad)
-    w[:cout, :k] = weight.permute(0, 2, 3, 1).reshape(cout, k)
+    if cin == 4:
+        # stem layout of the LDS-DMA kernel: one 32-float K-tile per filter row = 8 pixels x 4 channels
+        # (columns beyond kw are zero)
+        if kw > 8:
+            raise _lib.FgnHipError('pack_conv: a 4-channel (image) conv needs kw <= 8')
+        w = weight.new_zeros(cout_pad, kh, 8, 4)
+        w[:cout, :, :kw, :] = weight.permute(0, 2, 3, 1)
+        w = w.reshape(cout_pad, kh * 32)
+    else:
+        k = kh * kw * cin
+        k_pad = (k + 31) // 32 * 32
+        w = weight.new_zeros(cout_pad, k_pad)
+        w[:cout, :k] = weight.permute(0, 2, 3, 1).reshape(cout, k)
     scale = shift = None
     if bn is not None:
         scale = (bn['weight'].float() / torch.sqrt(bn['running_var'].float() + eps))

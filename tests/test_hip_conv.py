@@ -141,3 +141,22 @@ def test_streamk_split_tiles_and_device_count(shape, hint):
         got = out.cpu().permute(0, 3, 1, 2)
         assert (got[:n - 3] - ref[:n - 3]).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
         assert float((got[n - 3:] + 3.0).abs().max()) == 0.0
+
+
+def test_repeated_runs_are_bit_identical_at_full_occupancy():
+    """Regression: a 1x1 conv with 1840 workgroups of the 64x64 kernel (4-5 per CU) gave, about once in
+    40 launches, one wave a stale last k-slice of a K-tile: the loop barrier was signalled while that wave's
+    LDS reads were still queued and the next tile's LDS-DMA overtook them.  200 launches must agree bitwise,
+    and with a torch reference."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 7, 7, 1024, generator=g)
+    wt = torch.randn(512, 1024, 1, 1, generator=g) * 0.05
+    b = torch.randn(512, generator=g)
+    layer = ops.pack_conv(wt, bias=b, relu=True).to('cuda')
+    xc = x.cuda()
+    ref = torch.relu(x.reshape(-1, 1024).double() @ wt.reshape(512, 1024).double().T + b.double()).float()
+    first = ops.conv2d(xc, layer).clone()
+    assert (first.reshape(-1, 512).cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    for i in range(200):
+        assert torch.equal(ops.conv2d(xc, layer), first), f'launch {i} differs'
