@@ -225,7 +225,11 @@ def main():
         if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
     if tfiles and args.workload == 'cfg3':
         with open(os.path.join(ROOT, 'profiles', tfiles[-1])) as fh:
-            traffic = json.load(fh).get('hbm_bytes_per_launch')
+            tj = json.load(fh)
+        # bytes of all conv-family kernels of one episode / layer launches of one episode (the same unit
+        # `achieved` is computed over)
+        traffic = tj['hbm_bytes_per_episode'] / (n_launch / n_prof_steps) if 'hbm_bytes_per_episode' in tj \
+            else tj.get('hbm_bytes_per_launch')
 
     if rank == 0:
         R = cfg['test_cfg']['rpn']['max_per_img']
@@ -265,7 +269,8 @@ def main():
                          'achieved_mfma_issued': round(achieved_mfma, 2),
                          'frac_mfma_issued': round(achieved_mfma / PEAK_FP32_MFMA_TFLOPS, 4),
                          'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per conv launch (PMC, profiles/*conv_traffic.json)',
+                         'traffic_unit': 'HBM bytes per conv layer launch = bytes of all conv-family kernels of an episode / layer launches '
+                                         '(rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/*conv_traffic.json)',
                          'launches_per_step': n_launch / n_prof_steps, 'profiled_steps': n_prof_steps,
                          'avg_launch_us': round(conv_ms * 1e3 / n_launch, 2),
                          'conv_ms_per_step': round(conv_ms / n_prof_steps, 3),

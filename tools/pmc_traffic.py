@@ -9,20 +9,28 @@ CONV_FAMILY = ('conv_igemm', 'conv_streamk', 'streamk_fixup', 'splitk_epilogue',
 
 
 def collect(d, counter):
-    tot, n = 0.0, 0
+    """(sum of the counter over the conv-family kernels, their launches, episodes = mask_rle launches)"""
+    tot, n, eps = 0.0, 0, 0
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in CONV_FAMILY):
+            if r['Counter_Name'] != counter:
+                continue
+            if any(k in r['Kernel_Name'] for k in CONV_FAMILY):
                 tot += float(r['Counter_Value'])
                 n += 1
-    return tot, n
+            elif 'mask_rle_kernel' in r['Kernel_Name']:
+                eps += 1
+    return tot, n, eps
 
 
-fetch, nf = collect(sys.argv[1], 'FETCH_SIZE')
-write, nw = collect(sys.argv[2], 'WRITE_SIZE')
+fetch, nf, ef = collect(sys.argv[1], 'FETCH_SIZE')
+write, nw, ew = collect(sys.argv[2], 'WRITE_SIZE')
 out = {'kernel': ' + '.join(CONV_FAMILY), 'launches_fetch_pass': nf, 'launches_write_pass': nw,
        'FETCH_SIZE_KiB_per_launch_raw': fetch / max(nf, 1), 'WRITE_SIZE_KiB_per_launch': write / max(nw, 1),
        'hbm_bytes_per_launch': (2.0 * fetch / max(nf, 1) + write / max(nw, 1)) * 1024.0,
+       'episodes_fetch_pass': ef, 'episodes_write_pass': ew,
+       # all conv-family kernels of one episode (bench.py divides by its layer launches per step)
+       'hbm_bytes_per_episode': (2.0 * fetch / max(ef, 1) + write / max(ew, 1)) * 1024.0,
        'note': 'FETCH_SIZE doubled (gfx950 wide-read correction); separate --pmc passes; same command as bench.py'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out))
