@@ -515,11 +515,35 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
     const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
 
+    // K-tile -> (filter tap, byte offset of the tap's channel slice), wave-uniform.  Tiles are issued in
+    // ascending order, so the decode is incremental (two integer divisions per K-tile were ~60 scalar
+    // instructions against 16 MFMAs): consecutive channel tiles and consecutive kx are 128 B apart, a wrap
+    // of kx jumps to the next input row.
+    int nx_tap = 0, nx_c0t = 0, nx_kx = 0, nx_off = 0;
+    if (!PW && !STEM) {
+        nx_tap = kt0 / cin_tiles;
+        nx_c0t = kt0 - nx_tap * cin_tiles;
+        const int ky = nx_tap / p.KW;
+        nx_kx = nx_tap - ky * p.KW;
+        nx_off = ((ky * p.W + nx_kx) * p.Cin + nx_c0t * BK) * 4;
+    }
     auto issue_tile = [&](int kt, int stage) {
         int tap = 0, tap_off = kt * BK * 4;
         if (STEM) {
             tap = kt;
             tap_off = kt * p.W * 16;
+        } else if (!PW && NSTAGE == 2) {
+            tap = nx_tap;
+            tap_off = nx_off;
+            nx_off += BK * 4;
+            if (++nx_c0t == cin_tiles) {
+                nx_c0t = 0;
+                ++nx_tap;
+                if (++nx_kx == p.KW) {
+                    nx_kx = 0;
+                    nx_off += (p.W - p.KW) * p.Cin * 4;
+                }
+            }
         } else if (!PW) {
             tap = kt / cin_tiles;
             const int c0 = (kt - tap * cin_tiles) * BK;
@@ -1013,11 +1037,27 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
         }
         const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4 + w_grp_off;
 
+        // incremental K-tile -> (tap, byte offset) decode (see conv_igemm_dma_kernel)
+        int nx_tap = kb / cin_tiles;
+        int nx_c0t = kb - nx_tap * cin_tiles;
+        int nx_kx, nx_off;
+        {
+            const int ky = nx_tap / p.KW;
+            nx_kx = nx_tap - ky * p.KW;
+            nx_off = ((ky * p.W + nx_kx) * p.Cin + nx_c0t * BK) * 4;
+        }
         auto issue_tile = [&](int kt, int stage) {
-            const int tap = kt / cin_tiles;
-            const int c0 = (kt - tap * cin_tiles) * BK;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;
+            const int tap = nx_tap;
+            const int tap_off = nx_off;
+            nx_off += BK * 4;
+            if (++nx_c0t == cin_tiles) {
+                nx_c0t = 0;
+                ++nx_tap;
+                if (++nx_kx == p.KW) {
+                    nx_kx = 0;
+                    nx_off += (p.W - p.KW) * p.Cin * 4;
+                }
+            }
             const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
@@ -1045,7 +1085,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int kt = kb; kt < ke; ++kt) {
-            issue_tile(min(kt + 1, ke - 1), cur ^ 1);
+            if (kt + 1 < ke) issue_tile(kt + 1, cur ^ 1);      // nothing to prefetch behind the segment's last tile
             asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
