@@ -58,6 +58,9 @@ struct ConvParams {
     // device.  grp_rows == 0: plain convolution.
     int grp_rows, grp_valid, grp_items, grp_rows_per_item, grp_w_stride;
     const int32_t* grp_count_dev;
+    // stream-K: round the units per workgroup up to whole tiles (no split tiles, no slabs, no fix-up launch);
+    // chosen by the host when that idles < 7 % of the workgroups
+    int sk_align;
 };
 
 #ifndef CONV_DMA_STAGES
@@ -742,7 +745,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
 constexpr int SK_BLOCKS = 512;
 constexpr int SK_TILE = 128;
 
-__device__ __forceinline__ int sk_units_per_block(int total_units) { return (total_units + SK_BLOCKS - 1) / SK_BLOCKS; }
+__host__ __device__ __forceinline__ int sk_units_per_block(int total_units, int KT, int align) {
+    const int per = (total_units + SK_BLOCKS - 1) / SK_BLOCKS;
+    return align ? (per + KT - 1) / KT * KT : per;
+}
 
 __global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p) {
     constexpr int BM = SK_TILE, BN = SK_TILE, WM = 64, WN = 64;
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p
     const int KT = p.K / BK;
     const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
     const int total = tiles * KT;
-    const int per = sk_units_per_block(total);
+    const int per = sk_units_per_block(total, KT, p.sk_align);
     int u = bid * per;
     const int u_end = min(u + per, total);
     if (u >= u_end) return;
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
     const int KT = p.K / BK;
     const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
     const int total = tiles * KT;
-    const int per = sk_units_per_block(total);
+    const int per = sk_units_per_block(total, KT, p.sk_align);
     int u = bid * per;
     const int u_end = min(u + per, total);
     if (u >= u_end) return;
@@ -1191,7 +1197,7 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(const ConvParams p) 
     const int tiles = ((M + SK_TILE - 1) / SK_TILE) * p.n_tiles_n;
     const int tile = blockIdx.x;
     if (tile >= tiles) return;
-    const int per = sk_units_per_block(tiles * KT);
+    const int per = sk_units_per_block(tiles * KT, KT, p.sk_align);
     const int b_lo = (tile * KT) / per, b_hi = ((tile + 1) * KT - 1) / per;
     if (b_lo == b_hi) return;                          // produced whole by one block
     const int tile_m = tile / p.n_tiles_n, tile_n = tile - tile_m * p.n_tiles_n;
@@ -1240,13 +1246,21 @@ static int launch_streamk(const ConvParams& p0, int M_max, hipStream_t stream) {
         return e;
     }();
     if (attr != hipSuccess) return (int)attr;
+    {
+        const int KT = p.K / BK;
+        const long long total = (long long)cdiv(M_max, SK_TILE) * p.n_tiles_n * KT;
+        const int per = sk_units_per_block((int)total, KT, 0), per_al = sk_units_per_block((int)total, KT, 1);
+        p.sk_align = (per_al * 100 <= per * 107) ? 1 : 0;
+    }
     if (p0.splits == 16)
         hipLaunchKernelGGL(conv_streamk16_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
     else
         hipLaunchKernelGGL(conv_streamk_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
     FGN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(streamk_fixup_kernel, dim3(cdiv(M_max, SK_TILE) * p.n_tiles_n), dim3(256), 0, stream, p);
-    FGN_LAUNCH_CHECK();
+    if (!p.sk_align) {
+        hipLaunchKernelGGL(streamk_fixup_kernel, dim3(cdiv(M_max, SK_TILE) * p.n_tiles_n), dim3(256), 0, stream, p);
+        FGN_LAUNCH_CHECK();
+    }
     return FGN_OK;
 }
 
@@ -1395,7 +1409,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
-    p.grp_count_dev = nullptr;
+    p.grp_count_dev = nullptr; p.sk_align = 0;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return FGN_ERR_SHAPE;

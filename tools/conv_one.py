@@ -4,7 +4,9 @@ sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__impo
 from fgn_amd import ops
 letter, tile, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 SH = {'A': (3, 50, 84, 1024, 1024, 3, 1, 3, False), 'B': (300, 7, 7, 512, 512, 3, 1, 0, False),
-      'D': (1, 200, 334, 64, 256, 1, 1, 0, True), 'C': (300, 7, 7, 1024, 512, 1, 1, 0, False)}
+      'D': (1, 200, 334, 64, 256, 1, 1, 0, True), 'C': (300, 7, 7, 1024, 512, 1, 1, 0, False),
+      'F': (1, 50, 84, 256, 256, 3, 1, 0, False), 'G': (1, 50, 84, 256, 1024, 1, 1, 0, True),
+      'L': (1, 100, 167, 128, 128, 3, 1, 0, False), 'I': (100, 7, 7, 512, 512, 3, 1, 0, False)}
 n, H, W, cin, cout, k, s, div, res = SH[letter]
 g = torch.Generator().manual_seed(0)
 pad = k // 2

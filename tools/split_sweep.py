@@ -28,7 +28,7 @@ for name, n, H, W, cin, cout, k, s, res in SH:
 print(' '.join(out))
 ''' % ROOT
 print('columns: l3-1x1a l3-3x3 l3-1x1b sh100a sh100b mask3x3 maskup l2-3x3 l2-1x1 spp-l3-3x3 spp-l3-1x1 spp-l2-3x3 spp-sh3x3  (us)')
-for s in ['auto', '1', '2', '3', '4', '5', '6', '8', '12']:
+for s in (os.environ.get('SWEEP', 'auto,1,2,3,4,5,6,8,12')).split(','):
     env = dict(os.environ)
     if s != 'auto':
         env['FGN_CONV_SPLITS'] = s
