@@ -299,3 +299,34 @@ def test_hip_graph_replay_is_identical():
     same(ref, model.simple_test(**q_only, support_code=code, rescale=True))
     same(ref, model.simple_test(**one, rescale=True))
     assert len(model._graphs) == 3
+
+
+def test_winograd_and_direct_paths_agree():
+    """`use_winograd=False` (direct form for every 3x3, the reference's formulation op for op) and the default
+    Winograd path give the same detections within the tolerance of the metric."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    sd = init_state_dict(cfg, 0)
+    batch = make_batch(3, 2, 3, 2, 160, 224, 64)
+    out = {}
+    for wg in (True, False):
+        model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                    test_cfg=cfg['test_cfg'], state_dict=sd)
+        model.use_winograd = wg
+        model.debug_trace = {}
+        out[wg] = (model.simple_test(**batch, rescale=True), model.debug_trace)
+        assert (model._P['rpn_conv_wg'] is not None) == wg
+    (a, ta), (b, tb) = out[True], out[False]
+    ref = tb['rpn_logits']
+    assert (ta['rpn_logits'] - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1.0)
+    for x, y in zip(a, b):
+        assert abs(len(x['dt_scores']) - len(y['dt_scores'])) <= max(2, len(y['dt_scores']) // 20)
+        n = min(len(x['dt_scores']), len(y['dt_scores']))
+        iou = _iou(x['dt_bboxes'][:, [1, 0, 3, 2]], y['dt_bboxes'][:, [1, 0, 3, 2]])
+        j = iou.argmax(1)
+        ok = (iou.max(1) > 0.98) & (x['dt_cat_ids'] == y['dt_cat_ids'][j]) & \
+             (np.abs(x['dt_scores'] - y['dt_scores'][j]) < 1e-3)
+        assert n == 0 or ok.mean() >= 0.9, ok.mean()
