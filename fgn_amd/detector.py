@@ -374,6 +374,15 @@ class FGN(torch.nn.Module):
                 x = blk(x)
         return x
 
+    @staticmethod
+    def _rois_of(boxes4, img_idx: int, dev):
+        """bbox2roi (fgn_roi_head.py:556, 654): [R,4] -> [R,5] with the batch index in column 0."""
+        rois = ops.zeros((boxes4.shape[0], 5), dev)
+        rois[:, 1:] = boxes4
+        if img_idx:
+            rois[:, 0] = float(img_idx)
+        return rois
+
     def _shared_head(self, x, n_img_dev=None):
         for blk in self._P['shared']:
             x = blk(x, n_img_dev)
@@ -488,6 +497,7 @@ class FGN(torch.nn.Module):
         inv_stride = 1.0 / rh['featmap_stride']
 
         qry = qry_img.to(dev, torch.float32, non_blocking=True)
+        ops.begin_arena(dev)          # zero-initialised small outputs of this episode: one fill (caller's stream only)
 
         # Two HIP streams: the support branch (9 small crops: low-occupancy launches) runs beside
         # the query branch, and its RoI/shared-head/reduction tail runs beside the single-workgroup
@@ -567,7 +577,7 @@ class FGN(torch.nn.Module):
         bh = rh['bbox_head']
         for i in range(B):
             cnt = n_props[i:i + 1]
-            rois = torch.cat([torch.full((props.shape[1], 1), float(i), device=dev), props[i, :, :4]], 1).contiguous()
+            rois = self._rois_of(props[i, :, :4], i, dev)
             feats = ops.roi_align(qry_fmap, rois, PS, inv_stride, rh['roi_sampling_ratio'], True, cnt)
             feats = self._shared_head(feats, cnt)
             Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt)
@@ -577,7 +587,7 @@ class FGN(torch.nn.Module):
                                            tc['rcnn']['score_thr'], tc['rcnn']['nms_iou_threshold'],
                                            tc['rcnn']['max_per_img'], cnt)
             # mask branch (fgn_roi_head.py:704-718, 360-382)
-            mrois = torch.cat([torch.full((det.shape[0], 1), float(i), device=dev), det[:, :4]], 1).contiguous()
+            mrois = self._rois_of(det[:, :4], i, dev)
             vmask = ops.gather_support_vectors(cat_mean_mp, lab, mrois, N, n_det)
             mf = ops.roi_align(qry_fmap, mrois, PS, inv_stride, rh['roi_sampling_ratio'], True, n_det)
             mf = self._shared_head(mf, n_det)
@@ -595,6 +605,7 @@ class FGN(torch.nn.Module):
                     n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
             outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mprob, rle_bytes=rle_bytes,
                              rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
+        ops.end_arena()
         if download:
             self._start_download(outs, main)
         return outs

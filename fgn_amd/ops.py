@@ -23,6 +23,47 @@ from . import lib as _lib
 PROFILE = None          # a list (or ConvProfile): conv2d appends (e0, e1, flop_per_img, n_img, n_img_dev, shape)
 
 
+class ZeroArena:
+    """One zero-filled allocation per episode from which the small zero-initialised outputs of the selection
+    / head kernels are carved (counters, logits of RoIs beyond the device count, ...): one fill kernel
+    instead of about ten 5 us ones on the critical path."""
+
+    def __init__(self, device, nbytes: int = 2 << 20):
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+
+    def take(self, shape, dtype):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + 255) // 256 * 256
+        if start + n > self.buf.numel():
+            return None
+        self.off = start + n
+        return self.buf[start:start + n].view(dtype).view(*shape)
+
+
+_ARENA: Optional[ZeroArena] = None
+
+
+def begin_arena(device) -> None:
+    global _ARENA
+    _ARENA = ZeroArena(device)
+
+
+def end_arena() -> None:
+    global _ARENA
+    _ARENA = None
+
+
+def zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
+    """torch.zeros, served from the episode's arena when one is open on this device."""
+    a = _ARENA
+    if a is not None and a.buf.device == torch.device(device):
+        t = a.take(tuple(shape), dtype)
+        if t is not None:
+            return t
+    return torch.zeros(tuple(shape), device=device, dtype=dtype)
+
+
 class ConvProfile(list):
     """Record list for the ``PROFILE`` hook with a pool of pre-created timing events: creating HIP
     timing events inside a timed region stalls now and then (tens of ms when the runtime grows its
@@ -408,7 +449,7 @@ def gather_support_vectors(table: torch.Tensor, labels: torch.Tensor, rois: Opti
         _chk(rois, 'rois')
         if rois.shape[0] < n or rois.shape[1] != 5:
             raise _lib.FgnHipError('gather_support_vectors: rois must be [>=n,5]')
-    out = torch.zeros((n, c), device=table.device, dtype=torch.float32)
+    out = zeros((n, c), table.device)
     rc = _lib.load().fgn_gather_support_vectors_f32(_ptr(table), _ptr(labels), _ptr(rois), _ptr(out), _ptr(n_dev),
                                                     n, n_ways, c, _stream())
     _lib.check(rc, 'fgn_gather_support_vectors_f32')
@@ -423,8 +464,8 @@ def relation_gn_head(q: torch.Tensor, s: torch.Tensor, rois: torch.Tensor, gn_w,
     r, p, _, c = q.shape
     if s.shape[1:] != q.shape[1:] or s.shape[0] % n_ways or rois.shape[0] < r or fc_w.shape != (6, c):
         raise _lib.FgnHipError('relation_gn_head: operand shapes inconsistent')
-    cls = torch.zeros((r * n_ways, 2), device=q.device, dtype=torch.float32)
-    reg = torch.zeros((r * n_ways, 4), device=q.device, dtype=torch.float32)
+    cls = zeros((r * n_ways, 2), q.device)
+    reg = zeros((r * n_ways, 4), q.device)
     rc = _lib.load().fgn_relation_gn_head_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
                                               _ptr(fc_b), _ptr(cls), _ptr(reg), _ptr(n_rois_dev), r, n_ways, c,
                                               gn_groups, p, float(eps), _stream())
@@ -482,7 +523,7 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
     scratch = torch.empty(L.fgn_rpn_proposals_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
                           dtype=torch.uint8)
     props = torch.empty((batch, max_per_img, 5), device=scores.device, dtype=torch.float32)
-    n_props = torch.zeros((batch,), device=scores.device, dtype=torch.int32)
+    n_props = zeros((batch,), scores.device, torch.int32)
     dbg = None
     if debug_topk:
         dbg = torch.full((batch, 8192), -1, device=scores.device, dtype=torch.int32)
@@ -508,7 +549,7 @@ def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n
     scratch = torch.empty(L.fgn_det_post_scratch_bytes(r, n_ways), device=rois.device, dtype=torch.uint8)
     det = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32)
     lab = torch.empty((max_per_img,), device=rois.device, dtype=torch.int64)
-    n_det = torch.zeros((1,), device=rois.device, dtype=torch.int32)
+    n_det = zeros((1,), rois.device, torch.int32)
     dbg = torch.zeros((r, n_ways + 1), device=rois.device, dtype=torch.float32) if debug_scores else None
     rc = L.fgn_det_post_f32(_ptr(rois), _ptr(cls_raw), _ptr(reg_raw), _ptr(n_rois_dev), _ptr(scratch), _ptr(det),
                             _ptr(lab), _ptr(n_det), _ptr(dbg), r, n_ways, float(img_h), float(img_w), _f4(means),
@@ -528,8 +569,8 @@ def mask_logits(x: torch.Tensor, w: torch.Tensor, bias: float, roi_size: int,
     c = w.numel()
     if x[0].numel() != roi_size * roi_size * 4 * c:
         raise _lib.FgnHipError('mask_logits: x shape inconsistent with weight')
-    logits = torch.zeros((d, 2 * roi_size, 2 * roi_size), device=x.device, dtype=torch.float32)
-    prob = torch.zeros_like(logits)
+    logits = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
+    prob = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
     rc = _lib.load().fgn_mask_logits_f32(_ptr(x), _ptr(w), float(bias), _ptr(logits), _ptr(prob), _ptr(n_dev), d,
                                          roi_size, c, _stream())
     _lib.check(rc, 'fgn_mask_logits_f32')
@@ -567,8 +608,8 @@ def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, th
     dev = prob.device
     scratch = torch.empty((d, RLE_TRANS_CAP), device=dev, dtype=torch.int32)
     out = torch.empty((d, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
-    lens = torch.zeros((d,), device=dev, dtype=torch.int32)
-    ovf = torch.zeros((d,), device=dev, dtype=torch.int32)
+    lens = zeros((d,), dev, torch.int32)
+    ovf = zeros((d,), dev, torch.int32)
     rc = _lib.load().fgn_mask_rle(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(scratch), _ptr(out), _ptr(lens),
                                   _ptr(ovf), _ptr(n_dev), d, img_h, img_w, m, float(thr), RLE_TRANS_CAP,
                                   RLE_BYTE_CAP, _stream())
