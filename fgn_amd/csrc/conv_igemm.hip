@@ -646,17 +646,21 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     // every lane moves 16 B of one output row - 4x fewer, fully coalesced global instructions than storing
     // the MFMA layout directly (each half-wave 128 B); this is what bounds the small-K 1x1 layers, whose
     // epilogue (68 MB residual read + 68 MB store at layer1) outweighs their K loop.
-    if constexpr (TM == 1 && TN == 1 && !(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
-        constexpr int PITCH = BN + 4;                 // floats; 272 B rows keep b128 alignment, shift banks by 4
-        static_assert(BM * PITCH <= NSTAGE * STAGE, "C tile fits in the stage buffers");
+    constexpr int PITCH = BN + 4;                     // floats; rows keep b128 alignment, shift banks by 4
+    if constexpr (BM * PITCH <= NSTAGE * STAGE && !(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
         float* const cbase = smem;
-        {
-            float* cw = cbase + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[0][0][r];
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* cw = cbase + (wm * WM + i * 32 + 4 * half) * PITCH + wn * WN + j * 32 + frag_row;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[i][j][r];
+            }
         __syncthreads();
-        const int c4 = t & 15, rr = t >> 4;
+        constexpr int C4 = BN / 4;                    // float4 per tile row
+        constexpr int RPP = 256 / C4;                 // rows per pass
+        const int c4 = t % C4, rr = t / C4;
         const int n = n0 + c4 * 4;
         if (n < p.Cout) {
             const bool raw = p.splits > 1;
@@ -664,27 +668,31 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             if (!raw && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
             if (!raw && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
             float* dst = raw ? p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout : p.y;
-            float4 res[BM / 16];
 #pragma unroll
-            for (int k = 0; k < BM / 16; ++k) {       // residual loads first: their latency overlaps the LDS reads
-                const int m = m0 + rr + 16 * k;
-                res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!raw && p.residual && m < M)
-                    res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
-            }
+            for (int k0 = 0; k0 < BM / RPP; k0 += 4) {
+                float4 res[4];
 #pragma unroll
-            for (int k = 0; k < BM / 16; ++k) {
-                const int m = m0 + rr + 16 * k;
-                if (m >= M) continue;
-                float4 v = *reinterpret_cast<const float4*>(cbase + (rr + 16 * k) * PITCH + c4 * 4);
-                if (!raw) {
-                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                    v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
-                    if (p.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
+                for (int k = 0; k < 4; ++k) {         // residual loads first: their latency overlaps the LDS reads
+                    const int m = m0 + rr + RPP * (k0 + k);
+                    res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!raw && p.residual && m < M)
+                        res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
                 }
-                if (!(CONV_DBG & 32) || v.x == 12345.678f) *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n) = v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = rr + RPP * (k0 + k);
+                    const int m = m0 + row;
+                    if (m >= M) continue;
+                    float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
+                    if (!raw) {
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                        v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
+                        if (p.relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                    if (!(CONV_DBG & 32) || v.x == 12345.678f) *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n) = v;
+                }
             }
         }
         return;
