@@ -167,8 +167,11 @@ class ClutteredCharsFewShotISEG(Dataset):
         # query always get a support; base_fst.py samples the same way from the query's categories)
         present = list(dict.fromkeys(im['cat_ids'].tolist()))
         rng.shuffle(present)
-        others = [c for c in rng.permutation(self.cats).tolist() if c not in present]
+        have = set(self.inst_cat.tolist())           # only classes with at least one instance can give a support
+        others = [c for c in rng.permutation(self.cats).tolist() if c not in present and c in have]
         real = np.array((present + others)[:self.n_ways], np.int64)
+        if len(real) < self.n_ways:
+            raise ValueError(f'the image pool holds {len(have)} classes, fewer than n_ways={self.n_ways}')
         mapping = np.full(int(self.cats.max()) + 1, -1, np.int64)
         mapping[real] = np.arange(len(real))
         keep = mapping[im['cat_ids']] >= 0
