@@ -270,6 +270,11 @@ def test_cluttered_chars_dataset_contract():
     ds.shuffle = True
     ds.reshuffle(e=3)
     assert sorted(ds.order.tolist()) == list(range(12))
+    # a pool smaller than the class vocabulary: supports come only from classes that have an instance
+    small = ClutteredCharsFewShotISEG('OMNIISEG', n_ways=3, k_shots=1, n_imgs=4, img_size=256, spp_img_size=128)
+    for i in range(4):
+        smp = small[i]
+        assert all(c in set(small.inst_cat.tolist()) for c in smp['cats_ids_to_sample_real'])
 
 
 def test_ar_grouped_batching():
