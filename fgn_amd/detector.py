@@ -124,7 +124,8 @@ class _Bottleneck:
     def __call__(self, x, n_img_dev=None):
         idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
         y = ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
-        if self.conv2_wg is not None and y.shape[0] >= self.WG_MIN_IMAGES:
+        if self.conv2_wg is not None and y.shape[0] >= self.WG_MIN_IMAGES and \
+                ops.winograd_fits(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout):
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
@@ -536,7 +537,8 @@ class FGN(torch.nn.Module):
         rpn_start = main.record_event()
         # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
         # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
-        if P['rpn_conv_wg'] is not None:      # Winograd F(2x2,3x3); the guidance multiply rides in its input transform
+        if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout):
+            # Winograd F(2x2,3x3); the guidance multiply rides in its input transform
             x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
         else:
             x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])

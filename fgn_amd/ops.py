@@ -266,6 +266,13 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
                          cout_pad, relu)
 
 
+def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
+    """The grouped GEMM addresses V / Mo through 32-bit buffer offsets: [16 * t_pad, C] must stay below 2 GiB."""
+    t_pad = (n_img * ((H + 1) // 2) * ((W + 1) // 2) + 127) // 128 * 128
+    rows = 16 * t_pad
+    return rows * cin * 4 < 0x7fffff00 and rows * cout < (1 << 31)
+
+
 def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[torch.Tensor] = None,
                      a_img_div: int = 1, n_img_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [n_in,H,W,Cin] -> relu?(conv3x3(x[i // a_img_div] * in_scale[i]) + shift) [n_in*a_img_div,H,W,Cout]."""
