@@ -204,7 +204,7 @@ def main():
     # ---- roofline of the dominant kernel (conv_igemm), from HIP events recorded live ----------
     # conv_flop: FLOPs of the convolutions as the layers define them (direct form, 2*M*N*K: what the
     # reference's formulation spends on these launches); mfma_flop: MFMA work actually issued, which is 16/36
-    # of that for the layers run in Winograd F(2x2,3x3) form (their event bracket spans transform + GEMM +
+    # of that (0.58 on the 7x7 RoI maps) for the layers run in Winograd F(2x2,3x3) form (their event bracket spans transform + GEMM +
     # transform).
     conv_ms = 0.0
     conv_flop = 0.0
@@ -268,7 +268,7 @@ def main():
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'flop_convention': 'direct-convolution FLOPs of the launched layers (2*M*N*K) / HIP-event time; '
                                             'achieved_mfma_issued counts the MFMA work actually issued '
-                                            '(Winograd layers issue 16/36 of their direct FLOPs)',
+                                            '(Winograd layers issue 16/36 of their direct FLOPs, 0.58 on 7x7 maps)',
                          'achieved_mfma_issued': round(achieved_mfma, 2),
                          'frac_mfma_issued': round(achieved_mfma / PEAK_FP32_MFMA_TFLOPS, 4),
                          'traffic': traffic,

@@ -310,9 +310,10 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     if prof is not None:
         e1.record()
         # direct-convolution FLOPs of the layer (what the reference's formulation executes); the MFMA work
-        # actually issued is 16/36 of it
+        # actually issued is 16 products per 2x2-output tile instead of 36: 16/36 of it on even maps, 0.58 on
+        # the 7x7 RoI maps (16 tiles cover 8x8)
         prof.append((e0, e1, 2.0 * H * W * layer.cout * 9 * cin, n_img, n_img_dev, (n_img, H, W, cin, layer.cout, 3, 1),
-                     16.0 / 36.0))
+                     16.0 * tiles / (9.0 * H * W)))
     return y
 
 
