@@ -13,22 +13,20 @@
 //     k's  8t+4h .. 8t+4h+3 with one ds_read_b128 and issue 4 MFMAs from it, so
 //     MFMA j contracts k in {8t+j, 8t+4+j}: a permutation of the K order that is
 //     applied identically to A and B.
-//   LDS       :  [rows][32 + 4 pad] floats; the 144-byte row stride makes both the
-//     ds_write_b128 staging stores and the ds_read_b128 fragment reads
-//     conflict-free (36*r mod 64 is a bijection on r mod 16).
-//   Pipeline  :  register prefetch of K-tile t+1 is issued before the MFMAs of
-//     tile t, written to the other LDS buffer after them; one barrier per K-tile.
-//   Epilogue  :  y = acc*scale[n] + shift[n] (+ residual) (ReLU)  -- folded
-//     eval-mode BN or conv bias -- written straight from the accumulators
-//     (each half-wave stores 128 contiguous bytes of one output pixel).
+//   Loader    :  LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane straight into LDS) in every kernel but
+//     conv_igemm_kernel; tile rows are the unpadded 128 B, bank conflicts are removed by XOR-swizzling the
+//     source chunk and the fragment read alike.  Two LDS stages, one barrier per K-tile.
+//   Epilogue  :  y = acc*scale[n] + shift[n] (+ residual) (ReLU)  -- folded eval-mode BN or conv bias.
+//     The accumulators take a round trip through LDS so that every lane moves 16 B of one output row.
 //   Fusions   :  optional per-(image, cin) input scale applied while staging A (register-staged
-//     kernel only): used for the mask-head support-vector multiply (fgn_roi_head.py:379);
-//     `a_img_div` lets several output images read one input image.  The AG-RPN guidance
-//     multiply (fgn_ag_rpn_head.py:44) is materialised instead (fgn_scale_channels_f32, 20 us)
-//     so that its 238 GFLOP conv can use the LDS-DMA stream-K kernel below.
-//   Kernels   :  conv_igemm_kernel (register-staged loader), conv_igemm_dma_kernel (LDS-DMA
-//     loader, optional split-K), conv_streamk_kernel (LDS-DMA, persistent stream-K); the
-//     dispatcher at the bottom of the file picks one per launch.
+//     kernel only): the mask-head support-vector multiply (fgn_roi_head.py:379); `a_img_div` lets several
+//     output images read one input image (AG-RPN guidance, fgn_ag_rpn_head.py:44, when the direct form is
+//     used; the Winograd form applies it in its input transform).
+//   Kernels   :  conv_igemm_dma_kernel (64x64 tile, optional split-K; modes generic / point-wise / stem),
+//     conv_streamk16_kernel and conv_streamk_kernel (128x128 tile, 512 persistent workgroups, stream-K;
+//     the 16x16x4 variant also runs the grouped Winograd GEMM), conv_igemm_kernel (register-staged loader,
+//     [rows][32 + 4 pad] LDS layout, for the fused input scale); the dispatcher at the bottom of the file
+//     picks one per launch.
 #include "common.h"
 #include <cstdlib>
 
@@ -78,10 +76,9 @@ constexpr int LDS_STRIDE = 36;  // floats
 // bounds test is one bit test - the im2col index arithmetic is out of the hot loop.
 template <int A_LD>
 struct AStage {
-    int off[A_LD];                    // ((img*H + iy0)*W + ix0)*Cin  (+ col4*4 for Cin>=32)
+    int off[A_LD];                    // ((img*H + iy0)*W + ix0)*Cin + col4*4
     unsigned long long taps[A_LD];    // bit (ky*KW+kx): tap inside the image and row < M
     int soff[A_LD];                   // in_scale row offset (img*Cin + col4*4)
-    int iy0[A_LD], ix0[A_LD];         // CIN4 path only
 };
 
 // Register staging buffers are ext_vector SSA values (not arrays): hipcc leaves float4 arrays
@@ -102,43 +99,28 @@ struct Pack {
 // Issue the global loads of one K-tile.  Nothing here consumes a loaded value: zero-fill of
 // out-of-image taps and the input-scale multiply happen in finish_tile(), after the MFMA block,
 // so the compiler places its s_waitcnt there and the loads fly under the MFMAs.
-template <int A_LD, int B_LD, bool CIN4, bool IN_SCALE>
+template <int A_LD, int B_LD, bool IN_SCALE>
 __device__ __forceinline__ unsigned load_tile(const ConvParams& p, const AStage<A_LD>& st, const float* b_base,
                                               int kt, int cin_tiles, int col4,
                                               typename Pack<4 * A_LD>::type& a_reg,
                                               typename Pack<4 * A_LD>::type& s_reg,
                                               typename Pack<4 * B_LD>::type& b_reg) {
     unsigned ok_mask = 0;
-    if (CIN4) {
-        // Cin == 4: one float4 is one filter tap; 8 taps per K-tile, tap differs per lane.
-        const int tap = kt * 8 + col4;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int tap_off = (ky * p.W + kx) * 4;
+    const int tap = kt / cin_tiles;                       // wave-uniform (scalar unit)
+    const int c0 = (kt - tap * cin_tiles) * BK;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int tap_off = (ky * p.W + kx) * p.Cin + c0;     // uniform
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const bool ok = tap < p.KH * p.KW && ((st.taps[i] >> tap) & 1ull);
-            const int off = ok ? st.off[i] + tap_off : 0;   // invalid taps read a valid dummy address
-            const float4 v = *reinterpret_cast<const float4*>(p.x + off);
-            PACK_SET4(a_reg, i, v);
-            ok_mask |= ok ? (1u << i) : 0u;
+    for (int i = 0; i < A_LD; ++i) {
+        const bool ok = (st.taps[i] >> tap) & 1ull;
+        const int off = ok ? st.off[i] + tap_off : 0;     // invalid taps read a valid dummy address
+        const float4 v = *reinterpret_cast<const float4*>(p.x + off);
+        PACK_SET4(a_reg, i, v);
+        if (IN_SCALE) {
+            const float4 sv = *reinterpret_cast<const float4*>(p.in_scale + st.soff[i] + c0);
+            PACK_SET4(s_reg, i, sv);
         }
-    } else {
-        const int tap = kt / cin_tiles;                       // wave-uniform (scalar unit)
-        const int c0 = (kt - tap * cin_tiles) * BK;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int tap_off = (ky * p.W + kx) * p.Cin + c0;     // uniform
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const bool ok = (st.taps[i] >> tap) & 1ull;
-            const int off = ok ? st.off[i] + tap_off : 0;
-            const float4 v = *reinterpret_cast<const float4*>(p.x + off);
-            PACK_SET4(a_reg, i, v);
-            if (IN_SCALE) {
-                const float4 sv = *reinterpret_cast<const float4*>(p.in_scale + st.soff[i] + c0);
-                PACK_SET4(s_reg, i, sv);
-            }
-            ok_mask |= ok ? (1u << i) : 0u;
-        }
+        ok_mask |= ok ? (1u << i) : 0u;
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -161,7 +143,7 @@ __device__ __forceinline__ void finish_tile(unsigned ok_mask, typename Pack<4 * 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN4, bool IN_SCALE, int MIN_WAVES>
+template <int BM, int BN, int WM, int WN, bool IN_SCALE, int MIN_WAVES>
 __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvParams p) {
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
@@ -204,14 +186,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + row0 + 32 * i;
-        st.off[i] = 0; st.taps[i] = 0ull; st.soff[i] = 0; st.iy0[i] = 0; st.ix0[i] = 0;
+        st.off[i] = 0; st.taps[i] = 0ull; st.soff[i] = 0;
         if (m < M) {
             const int img = m / HoWo;
             const int rem = m - img * HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-            st.off[i] = (((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + (CIN4 ? 0 : col4 * 4);
+            st.off[i] = (((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + col4 * 4;
             st.soff[i] = img * p.Cin + col4 * 4;
             unsigned long long tm = 0ull;
             int tp = 0;
@@ -228,7 +210,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     const int KT_all = p.K / BK;
     const int kt0 = blockIdx.y * p.kt_per_split;
     const int KT = min(KT_all, kt0 + p.kt_per_split);     // this block's K-tiles: [kt0, KT)
-    const int cin_tiles = CIN4 ? 1 : p.Cin / BK;
+    const int cin_tiles = p.Cin / BK;
 
     typename Pack<4 * A_LD>::type a_reg, s_reg;
     typename Pack<4 * B_LD>::type b_reg;
@@ -250,13 +232,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
     const float* const rd_b = smem + BM * LDS_STRIDE + (wn * WN + frag_row) * LDS_STRIDE + frag_k;
 
     // ---- prologue: tile kt0 -> LDS[0]; tile kt0+1 -> registers -------------------------------
-    unsigned okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, kt0, cin_tiles, col4, a_reg, s_reg, b_reg);
+    unsigned okm = load_tile<A_LD, B_LD, IN_SCALE>(p, st, b_base, kt0, cin_tiles, col4, a_reg, s_reg, b_reg);
     finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(st_a + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(st_b + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
-    okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base, min(kt0 + 1, KT - 1), cin_tiles, col4, a_reg, s_reg,
+    okm = load_tile<A_LD, B_LD, IN_SCALE>(p, st, b_base, min(kt0 + 1, KT - 1), cin_tiles, col4, a_reg, s_reg,
                                                 b_reg);
     __syncthreads();
 
@@ -319,7 +301,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
                 }
                 asm volatile("" ::: "memory");
                 if (!(CONV_DBG & 1))
-                    okm = load_tile<A_LD, B_LD, CIN4, IN_SCALE>(p, st, b_base,
+                    okm = load_tile<A_LD, B_LD, IN_SCALE>(p, st, b_base,
                                                                 (CONV_DBG & 16) ? kt0 : min(kt + 2, KT - 1), cin_tiles,
                                                                 col4, a_reg, s_reg, b_reg);
                 asm volatile("" ::: "memory");
@@ -1313,10 +1295,10 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     const dim3 grid(cdiv(M_max, BM) * p.n_tiles_n, p.splits);
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static const hipError_t attr_once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, MW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
@@ -1349,9 +1331,9 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     } else if (cin4)
         return FGN_ERR_SHAPE;      // the stem runs on the LDS-DMA kernel only (input < 2 GiB)
     else if (p.in_scale)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, MW>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, MW>), grid, dim3(256), lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false, MW>), grid, dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, MW>), grid, dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
     if (p.splits > 1) {
         const size_t total4 = (size_t)M_max * p.Cout / 4;
