@@ -83,12 +83,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # FGN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share cuda:0 and
+    # the collectives go through gloo): it checks the multi-rank control flow, not the scaling
+    backend = os.environ.get('FGN_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fgn_amd import ops
     from fgn_amd.config import fgn_r50_c4_config
@@ -122,6 +129,7 @@ def main():
     # one episode (proposal selection, 100-RoI mask head, small support layers) overlap with
     # the dense phases of the next.
     ep_streams = [torch.cuda.Stream() for _ in range(args.inflight)]
+    comm_stream = torch.cuda.Stream()
 
     def launch(i, profile=None):
         """Queue one episode's device work (asynchronous)."""
@@ -136,10 +144,21 @@ def main():
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
                                        e['img_shape'], support_code=e['code'])
             if world > 1:
-                # one RCCL all-gather of fixed-size padded records per step, queued on the episode's
-                # stream right behind its kernels (no host synchronisation)
-                recs, cnts = fdist.pack_detections(dets, max_det)
-                fdist.gather_detections(recs, cnts)
+                # one RCCL all-gather of fixed-size padded records per step, on a communication stream behind
+                # an event of the episode (no host synchronisation): the next episode's kernels do not queue
+                # behind the collective, so a rank that runs a step late does not stall the others' compute
+                if model.use_graphs:      # replayed graphs reuse their output buffers: keep the gather in stream order
+                    recs, cnts = fdist.pack_detections(dets, max_det)
+                    fdist.gather_detections(recs, cnts)
+                else:
+                    done = torch.cuda.current_stream().record_event()
+                    comm_stream.wait_event(done)
+                    with torch.cuda.stream(comm_stream):
+                        recs, cnts = fdist.pack_detections(dets, max_det)
+                        fdist.gather_detections(recs, cnts)
+                    for d in dets:
+                        for k in ('det_bboxes', 'det_labels', 'n_dets'):
+                            d[k].record_stream(comm_stream)
         if profile is not None and len(ep_streams) > 1:
             torch.cuda.synchronize()
         ops.PROFILE = None
@@ -196,7 +215,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_prof_steps = len(prof_steps)

@@ -37,8 +37,14 @@ def gather_detections(recs: torch.Tensor, cnts: torch.Tensor) -> Tuple[torch.Ten
     # one message: counts ride along as an extra row of the record tensor
     e, m, f = recs.shape
     msg = torch.cat([recs.reshape(e, m * f), cnts.to(recs.dtype)[:, None]], 1).contiguous()
-    out = torch.empty((world * e, msg.shape[1]), dtype=msg.dtype, device=msg.device)   # concatenated form
-    dist.all_gather_into_tensor(out, msg)
+    if dist.get_backend() == 'gloo' and msg.is_cuda:      # CPU rehearsals of the multi-rank flow: gloo has no CUDA all-gather
+        host = msg.cpu()
+        out = torch.empty((world * e, msg.shape[1]), dtype=msg.dtype)
+        dist.all_gather_into_tensor(out, host)
+        out = out.to(msg.device)
+    else:
+        out = torch.empty((world * e, msg.shape[1]), dtype=msg.dtype, device=msg.device)   # concatenated form
+        dist.all_gather_into_tensor(out, msg)
     out = out.view(world, e, -1)
     return out[:, :, :m * f].reshape(world, e, m, f), out[:, :, m * f].round().to(torch.int32)
 
