@@ -245,12 +245,23 @@ class FGN(torch.nn.Module):
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
         self.use_side_stream = True               # support branch on a second HIP stream
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
-        self.use_winograd = True                  # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
+        self._use_winograd = True                 # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
         self._graphs: dict = {}
         self._side_stream = None
         self._copy_stream = None
         self._pinned_ring: list = []
         self._pinned_next = 0
+
+    @property
+    def use_winograd(self) -> bool:
+        return self._use_winograd
+
+    @use_winograd.setter
+    def use_winograd(self, on: bool) -> None:
+        if bool(on) != self._use_winograd:        # the packed layers (and any captured graph) depend on it
+            self._use_winograd = bool(on)
+            self._packed_device = None
+            self._graphs = {}
 
     @classmethod
     def from_config(cls, model_cfg: dict, **kw) -> 'FGN':

@@ -26,7 +26,8 @@ PROFILE = None          # a list (or ConvProfile): conv2d appends (e0, e1, flop_
 class ZeroArena:
     """One zero-filled allocation per episode from which the small zero-initialised outputs of the selection
     / head kernels are carved (counters, logits of RoIs beyond the device count, ...): one fill kernel
-    instead of about ten 5 us ones on the critical path."""
+    instead of about ten 5 us ones on the critical path.  Module-level state: one episode at a time is being
+    queued per process (the detector is single-caller, as the reference's is, fgn_roi_head.py:439-447)."""
 
     def __init__(self, device, nbytes: int = 2 << 20):
         self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
