@@ -330,3 +330,64 @@ def test_winograd_and_direct_paths_agree():
         ok = (iou.max(1) > 0.98) & (x['dt_cat_ids'] == y['dt_cat_ids'][j]) & \
              (np.abs(x['dt_scores'] - y['dt_scores'][j]) < 1e-3)
         assert n == 0 or ok.mean() >= 0.9, ok.mean()
+
+
+def test_cfg4_batched_and_cfg5_full_size_invariants():
+    """The two multi-GPU configurations of BASELINE.json at their full sizes (per-GPU share):
+    cfg4 = 3-way 3-shot episodes batched at 800x1328 (the reference's x16 rounding, base_fst.py:693-694): a
+    batch of 2 gives each episode the result it gets alone; cfg5 = 5-way 5-shot, 1024x1024, 1000 proposals:
+    size-independent properties of the output (no oracle run: 2.9 TFLOP per episode on the CPU)."""
+    from fgn_amd import rle
+    from fgn_amd.config import fgn_r50_c4_config, with_caps
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import CONFIGS, RPN_MAX_PER_IMG, make_batch
+    from fgn_amd.weights import init_state_dict
+    # ---- cfg4
+    cfg = fgn_r50_c4_config(3, 3)
+    model = FGN(3, 3, state_dict=init_state_dict(cfg, 0))
+    both = make_batch(40, 2, **CONFIGS['cfg4'])
+    got2 = model.simple_test(**both, rescale=True)
+    for i in range(2):
+        one = make_batch(40 + i, 1, **CONFIGS['cfg4'])
+        got1 = model.simple_test(**one, rescale=True)[0]
+        a, b = got2[i], got1
+        assert a['qry_img_shape'].tolist() == [800, 1328, 3]
+        assert abs(len(a['dt_scores']) - len(b['dt_scores'])) <= 2 and len(b['dt_scores']) > 0
+        iou = _iou(a['dt_bboxes'][:, [1, 0, 3, 2]], b['dt_bboxes'][:, [1, 0, 3, 2]])
+        j = iou.argmax(1)
+        ok = (iou.max(1) > 0.98) & (a['dt_cat_ids'] == b['dt_cat_ids'][j]) & \
+             (np.abs(a['dt_scores'] - b['dt_scores'][j]) < 1e-3)       # tile partition differs with the batch: fp32 order
+        assert ok.mean() >= 0.95, ok.mean()
+    del model
+    # ---- cfg5
+    shape = CONFIGS['cfg5']
+    cfg5 = with_caps(fgn_r50_c4_config(5, 5), rpn_max=RPN_MAX_PER_IMG['cfg5'])
+    m5 = FGN(5, 5, test_cfg=cfg5['test_cfg'], state_dict=init_state_dict(cfg5, 0))
+    b5 = make_batch(3, 1, **shape)
+    m5.debug_trace = {}
+    g = m5.simple_test(**b5, rescale=True)[0]
+    tr = m5.debug_trace
+    m5.debug_trace = None
+    again = m5.simple_test(**b5, rescale=True)[0]
+    for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+        assert np.array_equal(g[key], again[key]), key                     # bit-reproducible
+    assert g['dt_isegmaps_rle'] == again['dt_isegmaps_rle']
+    n_props = int(tr['n_props'][0])
+    props = tr['proposals'][0, :n_props].cpu().numpy()
+    assert 300 < n_props <= 1000 and np.all(np.diff(props[:, 4]) <= 0)
+    assert props[:, :4].min() >= 0 and props[:, [0, 2]].max() <= 1024 and props[:, [1, 3]].max() <= 1024
+    iou = _iou(props[:, :4], props[:, :4])
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.7 + 1e-6
+    d = len(g['dt_scores'])
+    assert 0 < d <= 100 and np.all(np.diff(g['dt_scores']) <= 0) and g['dt_scores'].min() > 0.05
+    assert set(np.unique(g['dt_cat_ids'])) <= set(range(5))
+    bx = g['dt_bboxes'][:, [1, 0, 3, 2]]
+    for c in range(5):
+        bc = bx[g['dt_cat_ids'] == c]
+        if len(bc) > 1:
+            i2 = _iou(bc, bc)
+            np.fill_diagonal(i2, 0)
+            assert i2.max() <= 0.5 + 1e-6
+    m = rle.decode(g['dt_isegmaps_rle'][0])
+    assert m.shape == (1024, 1024)
