@@ -12,7 +12,7 @@
 // materialises the [R*N,2048,7,7] concat or the [R*N,1024,7,7] normalised tensor, and
 // writes 6 floats per (RoI, class).
 //
-// Mapping: one workgroup per RoI, 4 waves; a wave owns one GroupNorm group
+// Mapping: one workgroup per RoI, 8 waves; a wave owns one GroupNorm group
 // (32 channels x 49 pixels = 1568 values = 24.5 per lane): lane = (pixel slot 0..7,
 // channel quad 0..7), 7 float4 per lane stay in registers across the N classes.
 // Statistics are two-pass in registers (mean, then centred sum of squares) with
@@ -20,14 +20,15 @@
 #include "common.h"
 
 constexpr int REL_MAX_N = 8;
+constexpr int REL_WAVES = 8;     // 300 RoIs are 1.2 rounds of workgroups on 256 CUs: short workgroups keep the tail short
 
-__global__ __launch_bounds__(256) void relation_head_kernel(
+__global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
     const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ rois,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ fcw,
     const float* __restrict__ fcb, float* __restrict__ cls_out, float* __restrict__ reg_out,
     const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, float eps) {
     constexpr int P = 49;
-    __shared__ float fc_acc[4][REL_MAX_N][6];
+    __shared__ float fc_acc[REL_WAVES][REL_MAX_N][6];
     const int r = blockIdx.x;
     int nr = n_rois;
     if (n_rois_dev) nr = min(nr, *n_rois_dev);
@@ -36,12 +37,12 @@ __global__ __launch_bounds__(256) void relation_head_kernel(
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int quad = lane & 7, slot = lane >> 3;
     const int img = (int)rois[(size_t)r * 5];
-    for (int i = t; i < 4 * REL_MAX_N * 6; i += 256) (&fc_acc[0][0][0])[i] = 0.f;
+    for (int i = t; i < REL_WAVES * REL_MAX_N * 6; i += 64 * REL_WAVES) (&fc_acc[0][0][0])[i] = 0.f;
     __syncthreads();
 
     const float inv_cnt = 1.f / (32.f * (float)P);
     const int groups = C / 32;
-    for (int g = wv; g < groups; g += 4) {
+    for (int g = wv; g < groups; g += REL_WAVES) {
         const int c = g * 32 + quad * 4;
         float4 q[7];
 #pragma unroll
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(256) void relation_head_kernel(
     __syncthreads();
     if (t < n_ways * 6) {
         const int n = t / 6, j = t - n * 6;
-        const float v = ((fc_acc[0][n][j] + fc_acc[1][n][j]) + (fc_acc[2][n][j] + fc_acc[3][n][j])) + fcb[j];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < REL_WAVES; ++w) v += fc_acc[w][n][j];     // fixed order
+        v += fcb[j];
         const size_t row = (size_t)r * n_ways + n;
         if (j < 2) cls_out[row * 2 + j] = v;
         else reg_out[row * 4 + (j - 2)] = v;
@@ -139,7 +143,7 @@ extern "C" int fgn_relation_gn_head_f32(const float* Q, const float* S, const fl
     if (roi_size != 7 || gn_groups <= 0 || C != gn_groups * 32 || n_ways < 1 || n_ways > REL_MAX_N)
         return FGN_ERR_SHAPE;
     if (n_rois == 0) return FGN_OK;
-    hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois), dim3(256), 0, stream, Q, S, rois, gn_weight, gn_bias,
+    hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois), dim3(64 * REL_WAVES), 0, stream, Q, S, rois, gn_weight, gn_bias,
                        fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, eps);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
