@@ -387,12 +387,14 @@ class FGN(torch.nn.Module):
         return x
 
     @staticmethod
-    def _rois_of(boxes4, img_idx: int, dev):
-        """bbox2roi (fgn_roi_head.py:556, 654): [R,4] -> [R,5] with the batch index in column 0."""
-        rois = ops.zeros((boxes4.shape[0], 5), dev)
-        rois[:, 1:] = boxes4
-        if img_idx:
-            rois[:, 0] = float(img_idx)
+    def _rois_of(boxes4, batch: int, dev):
+        """bbox2roi (fgn_roi_head.py:556, 654): boxes [B,n,4] -> RoIs [B*n,5] with the image index in column 0."""
+        n = boxes4.shape[1]
+        rois = ops.zeros((batch * n, 5), dev)
+        v = rois.view(batch, n, 5)
+        v[:, :, 1:] = boxes4
+        if batch > 1:
+            v[:, :, 0] = torch.arange(batch, device=dev, dtype=torch.float32)[:, None]
         return rois
 
     def _shared_head(self, x, n_img_dev=None):
@@ -584,39 +586,54 @@ class FGN(torch.nn.Module):
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
                       n_props=n_props, spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
 
-        # ---- per image: box head, detections, mask head -----------------------------------
+        # ---- box head on the proposals of all B images at once (fgn_roi_head.py:531-616); a RoI carries its
+        # image index in column 0 (bbox2roi), which selects the feature map in RoIAlign and the support set
+        # in the relation head.  With one image the device-side proposal count bounds every launch; with
+        # several images the valid RoIs are not a prefix of the list, so the zero-box padding rows are
+        # computed too and dropped per image by det_post.
+        rel, bh = rh['relation'], rh['bbox_head']
+        R, D = props.shape[1], tc['rcnn']['max_per_img']
+        rois_all = self._rois_of(props[:, :, :4], B, dev)                         # [B*R,5]
+        cnt_all = n_props[0:1] if B == 1 else None
+        feats = ops.roi_align(qry_fmap, rois_all, PS, inv_stride, rh['roi_sampling_ratio'], True, cnt_all)
+        feats = self._shared_head(feats, cnt_all)
+        Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
+        cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
+                                                rel['gn_groups'], rel['gn_eps'], cnt_all)
+        dets, labs, n_dets = [], [], []
+        for i in range(B):                                                         # one selection workgroup per image
+            det, lab, n_det = ops.det_post(rois_all[i * R:(i + 1) * R], cls_raw[i * R * N:(i + 1) * R * N],
+                                           reg_raw[i * R * N:(i + 1) * R * N], N, ih, iw, bh['target_means'],
+                                           bh['target_stds'], tc['rcnn']['score_thr'],
+                                           tc['rcnn']['nms_iou_threshold'], D, n_props[i:i + 1])
+            dets.append(det); labs.append(lab); n_dets.append(n_det)
+        # ---- mask head on the detections of all images at once (fgn_roi_head.py:704-718, 360-382)
+        det_all = dets[0] if B == 1 else torch.cat(dets)
+        lab_all = labs[0] if B == 1 else torch.cat(labs)
+        nd_all = n_dets[0] if B == 1 else None
+        mrois_all = self._rois_of(det_all[:, :4].reshape(B, D, 4), B, dev)         # [B*D,5]
+        vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
+        mf = ops.roi_align(qry_fmap, mrois_all, PS, inv_stride, rh['roi_sampling_ratio'], True, nd_all)
+        mf = self._shared_head(mf, nd_all)
+        m = ops.conv2d(mf, P['mask_convs'][0], in_scale=vmask, n_img_dev=nd_all)     # guidance fused
+        for layer in P['mask_convs'][1:]:
+            m = ops.conv2d(m, layer, n_img_dev=nd_all)
+        up = ops.conv2d(m, P['upsample'], n_img_dev=nd_all)                        # [B*D,7,7,4*C']
+        mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, nd_all)
         outs = []
-        rel = rh['relation']
-        bh = rh['bbox_head']
         for i in range(B):
-            cnt = n_props[i:i + 1]
-            rois = self._rois_of(props[i, :, :4], i, dev)
-            feats = ops.roi_align(qry_fmap, rois, PS, inv_stride, rh['roi_sampling_ratio'], True, cnt)
-            feats = self._shared_head(feats, cnt)
-            Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt)
-            cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
-                                                    rel['gn_groups'], rel['gn_eps'], cnt)
-            det, lab, n_det = ops.det_post(rois, cls_raw, reg_raw, N, ih, iw, bh['target_means'], bh['target_stds'],
-                                           tc['rcnn']['score_thr'], tc['rcnn']['nms_iou_threshold'],
-                                           tc['rcnn']['max_per_img'], cnt)
-            # mask branch (fgn_roi_head.py:704-718, 360-382)
-            mrois = self._rois_of(det[:, :4], i, dev)
-            vmask = ops.gather_support_vectors(cat_mean_mp, lab, mrois, N, n_det)
-            mf = ops.roi_align(qry_fmap, mrois, PS, inv_stride, rh['roi_sampling_ratio'], True, n_det)
-            mf = self._shared_head(mf, n_det)
-            m = ops.conv2d(mf, P['mask_convs'][0], in_scale=vmask, n_img_dev=n_det)   # guidance fused
-            for layer in P['mask_convs'][1:]:
-                m = ops.conv2d(m, layer, n_img_dev=n_det)
-            up = ops.conv2d(m, P['upsample'], n_img_dev=n_det)                   # [D,7,7,4*C']
-            mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, n_det)
+            det, lab, n_det = dets[i], labs[i], n_dets[i]
+            mp_i = mprob[i * D:(i + 1) * D]
             # paste + threshold + COCO RLE fused on device: the D x H x W masks are never written
-            rle_bytes, rle_len, rle_ovf = ops.mask_rle(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+            rle_bytes, rle_len, rle_ovf = ops.mask_rle(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
             if tr is not None:
-                masks = ops.mask_paste(mprob, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+                masks = ops.mask_paste(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
                 tr.setdefault('per_image', []).append(dict(
-                    rois=rois, roi_feats=feats, Q=Q, cls_raw=cls_raw, reg_raw=reg_raw, det=det, lab=lab,
-                    n_det=n_det, mask_logits=mlog, mask_prob=mprob, masks=masks, mask_feats=mf))
-            outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mprob, rle_bytes=rle_bytes,
+                    rois=rois_all[i * R:(i + 1) * R], roi_feats=feats[i * R:(i + 1) * R], Q=Q[i * R:(i + 1) * R],
+                    cls_raw=cls_raw[i * R * N:(i + 1) * R * N], reg_raw=reg_raw[i * R * N:(i + 1) * R * N],
+                    det=det, lab=lab, n_det=n_det, mask_logits=mlog[i * D:(i + 1) * D], mask_prob=mp_i,
+                    masks=masks, mask_feats=mf[i * D:(i + 1) * D]))
+            outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mp_i, rle_bytes=rle_bytes,
                              rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
         ops.end_arena()
         if download:
