@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         float* __restrict__ out,
                                                         const int32_t* __restrict__ n_rois_dev, int n_rois,
                                                         int H, int W, int C, int P, float spatial_scale,
-                                                        int sampling_ratio, int aligned) {
+                                                        int sampling_ratio, int aligned,
+                                                        const float* __restrict__ post_shift, int relu) {
     const int bin = blockIdx.x;
     const int r = bin / (P * P);
     int nr = n_rois;
@@ -164,6 +165,13 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
             }
         }
         acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+        if (post_shift) {
+            const float4 sh = *reinterpret_cast<const float4*>(post_shift + c);
+            acc.x += sh.x; acc.y += sh.y; acc.z += sh.z; acc.w += sh.w;
+        }
+        if (relu) {
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
         *reinterpret_cast<float4*>(out + ((size_t)r * P * P + pb) * C + c) = acc;
     }
 }
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void roi_align_mask_kernel(const uint8_t* __re
 extern "C" int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, float* out,
                                       const int32_t* n_rois_dev, int n_rois, int n_img, int H, int W, int C,
                                       int out_size, float spatial_scale, int sampling_ratio, int aligned,
-                                      hipStream_t stream) {
+                                      const float* post_shift, int relu, hipStream_t stream) {
     if (!fmap || !rois || !out) return FGN_ERR_ARG;
     if (C % 4 || out_size <= 0) return FGN_ERR_SHAPE;
     (void)n_img;
@@ -227,7 +235,7 @@ extern "C" int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, floa
     const int threads = C >= 1024 ? 256 : (C >= 512 ? 128 : 64);
     hipLaunchKernelGGL(roi_align_kernel, dim3(n_rois * out_size * out_size), dim3(threads), 0, stream, fmap,
                        rois, out, n_rois_dev, n_rois, H, W, C, out_size, spatial_scale, sampling_ratio,
-                       aligned);
+                       aligned, post_shift, relu);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

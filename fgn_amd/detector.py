@@ -121,9 +121,10 @@ class _Bottleneck:
     def layers(self):
         return [l for l in (self.conv1, self.conv2, self.conv3, self.down, self.conv2_wg) if l is not None]
 
-    def __call__(self, x, n_img_dev=None):
+    def __call__(self, x, n_img_dev=None, y1=None):
+        """``y1``: the output of conv1 (+BN+ReLU) when the caller already has it (shared_head entry)."""
         idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
-        y = ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
+        y = y1 if y1 is not None else ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
         if self.conv2_wg is not None and y.shape[0] >= self.WG_MIN_IMAGES and \
                 ops.winograd_fits(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout):
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
@@ -246,6 +247,7 @@ class FGN(torch.nn.Module):
         self.use_side_stream = True               # support branch on a second HIP stream
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
         self._use_winograd = True                 # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
+        self.use_roi_commute = True               # shared_head conv1 on the feature map, RoIAlign after (set before first use)
         self._graphs: dict = {}
         self._side_stream = None
         self._copy_stream = None
@@ -329,6 +331,13 @@ class FGN(torch.nn.Module):
             bias=torch.cat([sd['rpn_head.rpn_cls.bias'], sd['rpn_head.rpn_reg.bias']], 0))
         P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
                        for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
+        # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
+        # (RoIAlign commutes with it); the shift is added after the pooling
+        c1 = P['shared'][0].conv1
+        P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
+                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
+            if self.use_roi_commute else None
+        P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
         # relation conv split along its input channels: [Wq | Ws] (fgn_roi_head.py:270)
         wrel = sd['roi_head.cls_reg_shared_conv.weight']
         c = wrel.shape[1] // 2
@@ -397,10 +406,23 @@ class FGN(torch.nn.Module):
             v[:, :, 0] = torch.arange(batch, device=dev, dtype=torch.float32)[:, None]
         return rois
 
-    def _shared_head(self, x, n_img_dev=None):
-        for blk in self._P['shared']:
-            x = blk(x, n_img_dev)
+    def _shared_head(self, x, n_img_dev=None, y1=None):
+        for bi, blk in enumerate(self._P['shared']):
+            x = blk(x, n_img_dev, y1=y1 if bi == 0 else None)
         return x
+
+    def _roi_feats(self, fmap, g_map, rois, n_dev):
+        """RoIAlign of the C4 map + the shared_head (fgn_roi_head.py:331-336 / 366-369).  RoIAlign is linear per
+        channel, so the first 1x1 conv of the shared_head is taken on the feature map (``g_map``, once per episode,
+        50x84 pixels instead of 49 per RoI) and only its BN shift + ReLU follow the pooling."""
+        P, rh = self._P, self.cfg['roi_head']
+        PS, inv = rh['roi_out_size'], 1.0 / rh['featmap_stride']
+        x = ops.roi_align(fmap, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev)
+        y1 = None
+        if g_map is not None:
+            y1 = ops.roi_align(g_map, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev,
+                               post_shift=P['sh0_shift'], relu=True)
+        return x, self._shared_head(x, n_dev, y1=y1)
 
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
@@ -595,8 +617,8 @@ class FGN(torch.nn.Module):
         R, D = props.shape[1], tc['rcnn']['max_per_img']
         rois_all = self._rois_of(props[:, :, :4], B, dev)                         # [B*R,5]
         cnt_all = n_props[0:1] if B == 1 else None
-        feats = ops.roi_align(qry_fmap, rois_all, PS, inv_stride, rh['roi_sampling_ratio'], True, cnt_all)
-        feats = self._shared_head(feats, cnt_all)
+        g_map = ops.conv2d(qry_fmap, P['sh0_lin']) if P['sh0_lin'] is not None else None    # [B,h,w,planes]
+        roi_in, feats = self._roi_feats(qry_fmap, g_map, rois_all, cnt_all)
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'], cnt_all)
@@ -613,8 +635,7 @@ class FGN(torch.nn.Module):
         nd_all = n_dets[0] if B == 1 else None
         mrois_all = self._rois_of(det_all[:, :4].reshape(B, D, 4), B, dev)         # [B*D,5]
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
-        mf = ops.roi_align(qry_fmap, mrois_all, PS, inv_stride, rh['roi_sampling_ratio'], True, nd_all)
-        mf = self._shared_head(mf, nd_all)
+        _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
         m = ops.conv2d(mf, P['mask_convs'][0], in_scale=vmask, n_img_dev=nd_all)     # guidance fused
         for layer in P['mask_convs'][1:]:
             m = ops.conv2d(m, layer, n_img_dev=nd_all)

@@ -29,7 +29,7 @@ SIGNATURES = {
     'fgn_group_norm_workspace_bytes': (C.c_size_t, [_i] * 4),
     'fgn_group_norm_nhwc_f32': (_i, [_p] * 6 + [C.c_size_t, _i, _i, _i, _i, _f, _i, _p]),
     'fgn_avgpool2x2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p]),
     'fgn_roi_align_mask_u8': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_support_class_vectors_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_scale_channels_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -374,11 +374,16 @@ def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
 
 
 def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
-              sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fmap [B,H,W,C], rois [R,5] -> [R,P,P,C]."""
+              sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None,
+              post_shift: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """fmap [B,H,W,C], rois [R,5] -> [R,P,P,C] (+ post_shift[C], ReLU)."""
     _chk(fmap, 'fmap')
     _chk(rois, 'rois')
     b, h, w, c = fmap.shape
+    if post_shift is not None:
+        _chk(post_shift, 'post_shift')
+        if post_shift.numel() != c:
+            raise _lib.FgnHipError('roi_align: post_shift must be [C]')
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise _lib.FgnHipError('roi_align: rois must be [R,5]')
     r = rois.shape[0]
@@ -387,7 +392,7 @@ def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_sca
         _chk(n_rois_dev, 'n_rois_dev', torch.int32)
     rc = _lib.load().fgn_roi_align_nhwc_f32(_ptr(fmap), _ptr(rois), _ptr(out), _ptr(n_rois_dev), r, b, h, w, c,
                                             out_size, float(spatial_scale), sampling_ratio, int(aligned),
-                                            _stream())
+                                            _ptr(post_shift), int(relu), _stream())
     _lib.check(rc, 'fgn_roi_align_nhwc_f32')
     return out
 

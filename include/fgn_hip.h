@@ -95,10 +95,13 @@ int fgn_avgpool2x2_nhwc_f32(const float* x, float* y, int n_img, int H, int W, i
 
 /* RoIAlign (avg), rois [R,5] = (batch_idx,x1,y1,x2,y2), out [R,P,P,C].
  * aligned=1,sampling_ratio=0 : mmcv.ops.RoIAlign (fgn_roi_head.py:331,366)
- * aligned=0,sampling_ratio=-1: torchvision.ops.roi_align (fgn_roi_head.py:429,432) */
+ * aligned=0,sampling_ratio=-1: torchvision.ops.roi_align (fgn_roi_head.py:429,432)
+ * post_shift [C] (optional) is added and ReLU applied after the average: RoIAlign is linear per channel, so
+ * the first 1x1 conv of the shared_head (fgn_roi_head.py:236) is applied to the feature map once and its
+ * BN shift + ReLU here, instead of a conv over every RoI's 49 pixels. */
 int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, float* out, const int32_t* n_rois_dev,
                            int n_rois, int n_img, int H, int W, int C, int out_size, float spatial_scale,
-                           int sampling_ratio, int aligned, void* stream);
+                           int sampling_ratio, int aligned, const float* post_shift, int relu, void* stream);
 /* same for a single-channel uint8/bool map [n_img,H,W] -> [R,P,P] (support masks,
  * fgn_roi_head.py:429) */
 int fgn_roi_align_mask_u8(const uint8_t* mask, const float* rois, float* out, int n_rois, int n_img, int H,
