@@ -302,8 +302,9 @@ def test_hip_graph_replay_is_identical():
 
 
 def test_winograd_and_direct_paths_agree():
-    """`use_winograd=False` (direct form for every 3x3, the reference's formulation op for op) and the default
-    Winograd path give the same detections within the tolerance of the metric."""
+    """`use_winograd=False`, `use_roi_commute=False` (direct form for every 3x3, shared_head conv1 on the RoIs: the
+    reference's formulation op for op) and the default path give the same detections within the tolerance of
+    the metric."""
     from fgn_amd.config import tiny_config
     from fgn_amd.detector import FGN
     from fgn_amd.episodes import make_batch
@@ -316,9 +317,10 @@ def test_winograd_and_direct_paths_agree():
         model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
                     test_cfg=cfg['test_cfg'], state_dict=sd)
         model.use_winograd = wg
+        model.use_roi_commute = wg          # False: shared_head conv1 on every RoI, as the reference formulates it
         model.debug_trace = {}
         out[wg] = (model.simple_test(**batch, rescale=True), model.debug_trace)
-        assert (model._P['rpn_conv_wg'] is not None) == wg
+        assert (model._P['rpn_conv_wg'] is not None) == wg and (model._P['sh0_lin'] is not None) == wg
     (a, ta), (b, tb) = out[True], out[False]
     ref = tb['rpn_logits']
     assert (ta['rpn_logits'] - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1.0)
