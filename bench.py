@@ -207,10 +207,10 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    # two of the timed steps carry the HIP-event brackets (live roofline measurement); they run the
-    # support branch on the same stream, which costs ~1.5 ms each - kept to two so that the headline
-    # value is not dominated by instrumentation at small K
-    prof_steps = sorted({args.steps // 3, (2 * args.steps) // 3})
+    # one of the timed steps (two from K = 40) carries the HIP-event brackets (live roofline measurement); it
+    # runs the support branch on the same stream, which costs ~1.5 ms - kept to that so the headline value is
+    # not dominated by instrumentation at small K
+    prof_steps = sorted({args.steps // 3, (2 * args.steps) // 3}) if args.steps >= 40 else [args.steps // 2]
     n_d = run(args.steps, prof, prof_steps=prof_steps)
     barrier()
     dt = time.perf_counter() - t0
