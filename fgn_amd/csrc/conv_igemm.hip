@@ -485,7 +485,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             a_taps[i] = tm;
         }
     }
-    const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;   // bytes; rows +32i add 32*K*4
+    int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;   // bytes; rows +32i add 32*K*4
+    if (PW && p.grp_rows) {      // grouped GEMM (Winograd): per-group weight matrix, rows beyond the valid count skipped
+        const int grp = m0 / p.grp_rows;
+        int valid = p.grp_valid;
+        if (p.grp_count_dev) valid = min(valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+        if (m0 - grp * p.grp_rows >= valid) return;          // workgroup-uniform, before any barrier
+        b_off0 += grp * p.grp_w_stride * 4;
+    }
 
     const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
     const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
@@ -1463,6 +1470,19 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
 // run as ONE stream-K launch over the stacked rows [16 * t_pad] with a per-group weight matrix.
 // t_pad is a multiple of the 128-row tile so no tile straddles two groups.
 // ------------------------------------------------------------------------------------------------
+// The 128x128 stream-K kernel wins when every persistent workgroup gets >= 40 K-tiles of work; smaller
+// GEMMs (100 RoIs, layer3) run data-parallel on the 64x64 kernel in grouped mode, whose 64-row granularity
+// also fits 1600 tiles (100 RoIs x 16) and 1050 tiles (50x84 map) without padding a whole 128-row tile.
+static bool wg_use_streamk(long long tiles_total, int Cin, int Cout) {
+    const long long t128 = (tiles_total + SK_TILE - 1) / SK_TILE;
+    return 16 * t128 * cdiv(Cout, SK_TILE) * (Cin / BK) >= (long long)SK_BLOCKS * 40;
+}
+
+extern "C" int fgn_winograd_t_pad(int tiles_total, int Cin, int Cout) {
+    const int g = wg_use_streamk(tiles_total, Cin, Cout) ? SK_TILE : 64;
+    return (tiles_total + g - 1) / g * g;
+}
+
 extern "C" size_t fgn_winograd_gemm_workspace_bytes(void) {
     return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
 }
@@ -1472,9 +1492,10 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
                                      size_t ws_bytes, hipStream_t stream) {
     if (!V || !U || !Mo || !ws) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
-    if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % SK_TILE != 0 ||
+    if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
         (long long)n_img * tiles_per_img > t_pad)
         return FGN_ERR_SHAPE;
+    const bool sk = (t_pad % SK_TILE == 0) && wg_use_streamk((long long)n_img * tiles_per_img, Cin, Cout);
     if (ws_bytes < fgn_winograd_gemm_workspace_bytes()) return FGN_ERR_ARG;
     const long long rows = 16ll * t_pad;
     const long long xb = rows * Cin * 4, wb = 16ll * cout_pad * Cin * 4;
@@ -1488,6 +1509,8 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
-    p.n_tiles_n = 0;
-    return launch_streamk(p, (int)rows, stream);
+    p.n_tiles_n = 0; p.sk_align = 0;
+    if (sk) return launch_streamk(p, (int)rows, stream);
+    p.ws = nullptr; p.splits = 1;
+    return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

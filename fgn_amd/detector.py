@@ -101,14 +101,12 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
 
 # ------------------------------------------------------------------------------------------
 class _Bottleneck:
-    WG_MIN_IMAGES = 64      # below this the 16 GEMMs are too small for the 512-workgroup stream-K launch
-
     def __init__(self, sd, prefix, stride, eps, winograd=False):
         bn = lambda n: {k: sd[f'{prefix}.{n}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
         self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'], bn=bn('bn1'), relu=True, eps=eps)
         self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], bn=bn('bn2'), stride=stride, pad=1, relu=True,
                                    eps=eps)
-        # Winograd form of the 3x3 for large RoI batches (shared_head only; 2.25x fewer MFMA passes)
+        # Winograd form of a stride-1 3x3 (2.25x fewer MFMA passes); chosen per call by ops.winograd_pays
         w2 = sd[prefix + '.conv2.weight']
         self.conv2_wg = ops.pack_winograd(w2, bn=bn('bn2'), relu=True, eps=eps) \
             if winograd and stride == 1 and w2.shape[1] % 32 == 0 and w2.shape[0] % 4 == 0 else None
@@ -125,8 +123,8 @@ class _Bottleneck:
         """``y1``: the output of conv1 (+BN+ReLU) when the caller already has it (shared_head entry)."""
         idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
         y = y1 if y1 is not None else ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
-        if self.conv2_wg is not None and y.shape[0] >= self.WG_MIN_IMAGES and \
-                ops.winograd_fits(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout):
+        if self.conv2_wg is not None and \
+                ops.winograd_pays(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout):
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
@@ -319,7 +317,8 @@ class FGN(torch.nn.Module):
             P['stages'].append([
                 _BottleneckGN(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, bb.get('gn_groups', 32),
                               eps, bb.get('avg_down', False)) if gn else
-                _Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps) for b in range(nblk)])
+                _Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps,
+                            winograd=self.use_winograd) for b in range(nblk)])
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
         wr = sd['rpn_head.rpn_conv.weight']
@@ -351,6 +350,12 @@ class FGN(torch.nn.Module):
         P['mask_convs'] = [ops.pack_conv(sd[f'roi_head.mask_head.convs.{i}.conv.weight'],
                                          bias=sd[f'roi_head.mask_head.convs.{i}.conv.bias'], pad=1, relu=True)
                            for i in range(mh['num_convs'])]
+        P['mask_convs_wg'] = [
+            ops.pack_winograd(sd[f'roi_head.mask_head.convs.{i}.conv.weight'],
+                              bias=sd[f'roi_head.mask_head.convs.{i}.conv.bias'], relu=True)
+            if self.use_winograd and sd[f'roi_head.mask_head.convs.{i}.conv.weight'].shape[1] % 32 == 0 and
+            sd[f'roi_head.mask_head.convs.{i}.conv.weight'].shape[0] % 4 == 0 else None
+            for i in range(mh['num_convs'])]
         # ConvTranspose2d(k=2,s=2) [Cin,Cout,2,2] -> 1x1 conv with 4*Cout outputs, n=(dy*2+dx)*Cout+co
         wt = sd['roi_head.mask_head.upsample.weight']
         cin_u, cout_u = wt.shape[:2]
@@ -636,9 +641,13 @@ class FGN(torch.nn.Module):
         mrois_all = self._rois_of(det_all[:, :4].reshape(B, D, 4), B, dev)         # [B*D,5]
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
         _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
-        m = ops.conv2d(mf, P['mask_convs'][0], in_scale=vmask, n_img_dev=nd_all)     # guidance fused
-        for layer in P['mask_convs'][1:]:
-            m = ops.conv2d(m, layer, n_img_dev=nd_all)
+        m = mf
+        for li, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
+            scale = vmask if li == 0 else None         # support-vector guidance (fgn_roi_head.py:379) fused into conv 0
+            if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout):
+                m = ops.conv3x3_winograd(m, wg, in_scale=scale, n_img_dev=nd_all)
+            else:
+                m = ops.conv2d(m, layer, in_scale=scale, n_img_dev=nd_all)
         up = ops.conv2d(m, P['upsample'], n_img_dev=nd_all)                        # [B*D,7,7,4*C']
         mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, nd_all)
         outs = []

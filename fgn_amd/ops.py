@@ -274,6 +274,14 @@ def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
     return rows * cin * 4 < 0x7fffff00 and rows * cout < (1 << 31)
 
 
+def winograd_pays(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
+    """Measured on MI355X (tools/wg_bench.py): the Winograd form wins from 128 input channels and a few hundred
+    tiles on (layer2/3, 100-RoI heads, the AG-RPN conv); with 64 channels the transforms cost more than the GEMM
+    saves, and below ~256 tiles the launch costs of its three kernels do."""
+    tiles = n_img * ((H + 1) // 2) * ((W + 1) // 2)
+    return cin >= 128 and tiles >= 256 and winograd_fits(n_img, H, W, cin, cout)
+
+
 def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[torch.Tensor] = None,
                      a_img_div: int = 1, n_img_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [n_in,H,W,Cin] -> relu?(conv3x3(x[i // a_img_div] * in_scale[i]) + shift) [n_in*a_img_div,H,W,Cout]."""
@@ -289,8 +297,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     if n_img_dev is not None:
         _chk(n_img_dev, 'n_img_dev', torch.int32)
     tiles = ((H + 1) // 2) * ((W + 1) // 2)
-    t_pad = (n_img * tiles + 127) // 128 * 128
     L = _lib.load()
+    t_pad = L.fgn_winograd_t_pad(n_img * tiles, cin, layer.cout)
     V = torch.empty((16, t_pad, cin), device=x.device, dtype=torch.float32)
     Mo = torch.empty((16, t_pad, layer.cout), device=x.device, dtype=torch.float32)
     y = torch.empty((n_img, H, W, layer.cout), device=x.device, dtype=torch.float32)

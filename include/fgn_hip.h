@@ -63,10 +63,12 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
  *   fgn_winograd_gemm_f32    Mo[g] = V[g] U[g]^T for the 16 tile positions, one stream-K MFMA launch;
  *                            U [16][cout_pad][Cin] = G w G^T (host-packed, BN scale folded)
  *   fgn_winograd_output_f32  y = A^T Mo A + shift (ReLU), y [n_img,H,W,Cout]
- * tiles per image = ceil(H/2)*ceil(W/2); t_pad >= n_img*tiles, multiple of 128.  Image i reads
+ * tiles per image = ceil(H/2)*ceil(W/2); t_pad = fgn_winograd_t_pad(n_img*tiles, Cin, Cout) (multiple of 128 for
+ * the stream-K kernel, of 64 for the small GEMMs that run on the 64x64 kernel in grouped mode).  Image i reads
  * x[i / a_img_div]; in_scale [n_img][C] optional (AG-RPN guidance, fgn_ag_rpn_head.py:44). */
 int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev, int n_img,
                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
+int fgn_winograd_t_pad(int tiles_total, int Cin, int Cout);   /* padded tile count the GEMM wants for this size */
 size_t fgn_winograd_gemm_workspace_bytes(void);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                           int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, float* ws, size_t ws_bytes,

@@ -5,7 +5,9 @@ import torch
 from fgn_amd import ops
 SHAPES = [('agrpn', 1, 50, 84, 1024, 1024, 3), ('sh300', 300, 7, 7, 512, 512, 1), ('sh100', 100, 7, 7, 512, 512, 1),
           ('mask0', 100, 7, 7, 1024, 256, 1), ('mask1', 100, 7, 7, 256, 256, 1), ('l3', 1, 50, 84, 256, 256, 1),
-          ('l2', 1, 100, 167, 128, 128, 1)]
+          ('l2', 1, 100, 167, 128, 128, 1), ('l1', 1, 200, 334, 64, 64, 1), ('spp_l3', 9, 16, 16, 256, 256, 1),
+          ('spp_l2', 9, 32, 32, 128, 128, 1), ('spp_l1', 9, 64, 64, 64, 64, 1), ('spp_sh', 9, 7, 7, 512, 512, 1),
+          ('mask2', 100, 7, 7, 256, 256, 1)]
 g = torch.Generator().manual_seed(0)
 for name, n, H, W, cin, cout, div in SHAPES:
     x = torch.randn(n, H, W, cin, generator=g).cuda()
