@@ -50,7 +50,7 @@ struct ConvParams {
     float* ws;
     int splits, kt_per_split;
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
-    // grouped GEMM (Winograd, stream-K 16x16x4 kernel only): rows [g*grp_rows, (g+1)*grp_rows) use the weight
+    // grouped GEMM (Winograd; 64x64 kernel, point-wise mode): rows [g*grp_rows, (g+1)*grp_rows) use the weight
     // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
     // grp_valid, or min(grp_items, *grp_count_dev) * grp_rows_per_item when the item count lives on the
     // device.  grp_rows == 0: plain convolution.
@@ -1006,15 +1006,6 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
         const int m0 = tile_m * BM;
         const int n0 = tile_n * BN;
 
-        int w_grp_off = 0;          // bytes
-        if (p.grp_rows) {
-            const int grp = m0 / p.grp_rows;
-            int valid = p.grp_valid;
-            if (p.grp_count_dev) valid = min(valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
-            if (m0 - grp * p.grp_rows >= valid) continue;      // tile of rows nobody reads (wave-uniform)
-            w_grp_off = grp * p.grp_w_stride * 4;
-        }
-
         int a_off[A_LD];
         unsigned long long a_taps[A_LD];
 #pragma unroll
@@ -1038,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams
                 a_taps[i] = tm;
             }
         }
-        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4 + w_grp_off;
+        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
 
         // incremental K-tile -> (tap, byte offset) decode (see conv_igemm_dma_kernel)
         int nx_tap = kb / cin_tiles;
@@ -1465,38 +1456,23 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// The 16 batched GEMMs of a Winograd F(2x2,3x3) convolution (winograd.hip holds the transforms):
+// The 16 GEMMs of a Winograd F(2x2,3x3) convolution (winograd.hip holds the transforms):
 //   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = 0..15 (position in the 4x4 transformed tile)
-// run as ONE stream-K launch over the stacked rows [16 * t_pad] with a per-group weight matrix.
-// t_pad is a multiple of the 128-row tile so no tile straddles two groups.
+// run as ONE launch of the 64x64 kernel in point-wise mode over the stacked rows [16 * t_pad] with a
+// per-group weight matrix.  t_pad is a multiple of the 64-row tile so no tile straddles two groups; 1600 tiles
+// (100 RoIs x 16) and 4800 (300 RoIs) need no padding at all.  (The grouped 128x128 stream-K variant measured
+// equal on the AG-RPN GEMM and 5 % slower on the 300-RoI one, and much slower on everything smaller.)
 // ------------------------------------------------------------------------------------------------
-// The 128x128 stream-K kernel wins when every persistent workgroup gets >= 40 K-tiles of work; smaller
-// GEMMs (100 RoIs, layer3) run data-parallel on the 64x64 kernel in grouped mode, whose 64-row granularity
-// also fits 1600 tiles (100 RoIs x 16) and 1050 tiles (50x84 map) without padding a whole 128-row tile.
-static bool wg_use_streamk(long long tiles_total, int Cin, int Cout) {
-    const long long t128 = (tiles_total + SK_TILE - 1) / SK_TILE;
-    return 16 * t128 * cdiv(Cout, SK_TILE) * (Cin / BK) >= (long long)SK_BLOCKS * 40;
-}
-
-extern "C" int fgn_winograd_t_pad(int tiles_total, int Cin, int Cout) {
-    const int g = wg_use_streamk(tiles_total, Cin, Cout) ? SK_TILE : 64;
-    return (tiles_total + g - 1) / g * g;
-}
-
-extern "C" size_t fgn_winograd_gemm_workspace_bytes(void) {
-    return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
-}
+extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
 
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                                     int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, float* ws,
-                                     size_t ws_bytes, hipStream_t stream) {
-    if (!V || !U || !Mo || !ws) return FGN_ERR_ARG;
+                                     int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad,
+                                     hipStream_t stream) {
+    if (!V || !U || !Mo) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
         (long long)n_img * tiles_per_img > t_pad)
         return FGN_ERR_SHAPE;
-    const bool sk = (t_pad % SK_TILE == 0) && wg_use_streamk((long long)n_img * tiles_per_img, Cin, Cout);
-    if (ws_bytes < fgn_winograd_gemm_workspace_bytes()) return FGN_ERR_ARG;
     const long long rows = 16ll * t_pad;
     const long long xb = rows * Cin * 4, wb = 16ll * cout_pad * Cin * 4;
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
@@ -1505,12 +1481,10 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.n_img_dev = nullptr;
     p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
-    p.ws = ws; p.splits = 16; p.kt_per_split = Cin / BK;
+    p.ws = nullptr; p.splits = 1; p.kt_per_split = Cin / BK;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
     p.n_tiles_n = 0; p.sk_align = 0;
-    if (sk) return launch_streamk(p, (int)rows, stream);
-    p.ws = nullptr; p.splits = 1;
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

@@ -269,7 +269,7 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
 
 def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
     """The grouped GEMM addresses V / Mo through 32-bit buffer offsets: [16 * t_pad, C] must stay below 2 GiB."""
-    t_pad = (n_img * ((H + 1) // 2) * ((W + 1) // 2) + 127) // 128 * 128
+    t_pad = (n_img * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64 * 64
     rows = 16 * t_pad
     return rows * cin * 4 < 0x7fffff00 and rows * cout < (1 << 31)
 
@@ -298,12 +298,10 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
         _chk(n_img_dev, 'n_img_dev', torch.int32)
     tiles = ((H + 1) // 2) * ((W + 1) // 2)
     L = _lib.load()
-    t_pad = L.fgn_winograd_t_pad(n_img * tiles, cin, layer.cout)
+    t_pad = L.fgn_winograd_t_pad(n_img * tiles)
     V = torch.empty((16, t_pad, cin), device=x.device, dtype=torch.float32)
     Mo = torch.empty((16, t_pad, layer.cout), device=x.device, dtype=torch.float32)
     y = torch.empty((n_img, H, W, layer.cout), device=x.device, dtype=torch.float32)
-    ws_bytes = L.fgn_winograd_gemm_workspace_bytes()
-    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     prof = PROFILE
     if prof is not None:
         e0, e1 = prof.pair() if isinstance(prof, ConvProfile) else \
@@ -313,7 +311,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     _lib.check(L.fgn_winograd_input_f32(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W,
                                         cin, t_pad, st), 'fgn_winograd_input_f32')
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, _ptr(ws), ws_bytes, st), 'fgn_winograd_gemm_f32')
+                                       layer.cout, layer.cout_pad, st), 'fgn_winograd_gemm_f32')
     _lib.check(L.fgn_winograd_output_f32(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W,
                                          layer.cout, t_pad, int(layer.relu), st), 'fgn_winograd_output_f32')
     if prof is not None:

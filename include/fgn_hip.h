@@ -60,19 +60,17 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
 /* Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 convolution (same call sites as
  * fgn_conv2d_nhwc_f32: fgn_ag_rpn_head.py:48 rpn_conv, fgn_roi_head.py:236 shared_head conv2):
  *   fgn_winograd_input_f32   V[16][t_pad][C]   = B^T (x * in_scale?) B per 4x4 input tile
- *   fgn_winograd_gemm_f32    Mo[g] = V[g] U[g]^T for the 16 tile positions, one stream-K MFMA launch;
- *                            U [16][cout_pad][Cin] = G w G^T (host-packed, BN scale folded)
+ *   fgn_winograd_gemm_f32    Mo[g] = V[g] U[g]^T for the 16 tile positions, one MFMA launch (64x64 kernel,
+ *                            per-group weights); U [16][cout_pad][Cin] = G w G^T (host-packed, BN scale folded)
  *   fgn_winograd_output_f32  y = A^T Mo A + shift (ReLU), y [n_img,H,W,Cout]
- * tiles per image = ceil(H/2)*ceil(W/2); t_pad = fgn_winograd_t_pad(n_img*tiles, Cin, Cout) (multiple of 128 for
- * the stream-K kernel, of 64 for the small GEMMs that run on the 64x64 kernel in grouped mode).  Image i reads
- * x[i / a_img_div]; in_scale [n_img][C] optional (AG-RPN guidance, fgn_ag_rpn_head.py:44). */
+ * tiles per image = ceil(H/2)*ceil(W/2); t_pad = fgn_winograd_t_pad(n_img*tiles) (multiple of the 64-row tile).
+ * Image i reads x[i / a_img_div]; in_scale [n_img][C] optional (AG-RPN guidance, fgn_ag_rpn_head.py:44; mask
+ * guidance, fgn_roi_head.py:379). */
 int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev, int n_img,
                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
-int fgn_winograd_t_pad(int tiles_total, int Cin, int Cout);   /* padded tile count the GEMM wants for this size */
-size_t fgn_winograd_gemm_workspace_bytes(void);
+int fgn_winograd_t_pad(int tiles_total);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, float* ws, size_t ws_bytes,
-                          void* stream);
+                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, void* stream);
 int fgn_winograd_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                             int H, int W, int C, int t_pad, int relu, void* stream);
 
