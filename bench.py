@@ -281,8 +281,8 @@ def main():
                        'algorithmic_gflop_per_episode': round(gflop, 1),
                        'algorithmic_tflops': round(gflop * world * args.steps * args.batch / dt / 1e3, 2)},
             'roofline': {'bound': 'mfma',
-                         'kernel': 'all convolution launches (conv_streamk16 / conv_igemm_dma / conv_igemm kernels; '
-                                   'Winograd layers: wg_input + grouped conv_streamk16 + wg_output)',
+                         'kernel': 'all convolution launches (conv_igemm_dma / conv_igemm kernels; '
+                                   'Winograd layers: wg_input + grouped conv_igemm_dma + wg_output)',
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          'flop_convention': 'direct-convolution FLOPs of the launched layers (2*M*N*K) / HIP-event time; '
