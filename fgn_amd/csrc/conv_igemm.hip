@@ -636,7 +636,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     // the MFMA layout directly (each half-wave 128 B); this is what bounds the small-K 1x1 layers, whose
     // epilogue (68 MB residual read + 68 MB store at layer1) outweighs their K loop.
     constexpr int PITCH = BN + 4;                     // floats; rows keep b128 alignment, shift banks by 4
-    if constexpr (BM * PITCH <= NSTAGE * STAGE && !(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
+    // (the launcher sizes the dynamic LDS to max(stages, C tile): 128x128 needs 67.6 KB for the C tile)
+    if constexpr (!(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
         float* const cbase = smem;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1303,7 +1304,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     if (attr_once != hipSuccess) return (int)attr_once;
     if (!p.in_scale && p.x_bytes != 0) {
         constexpr int NST = (BM + BN >= 256) ? 2 : CONV_DMA_STAGES;   // 128x128 keeps 2 blocks/CU
-        const size_t dlds = (size_t)NST * (BM + BN) * BK * sizeof(float);
+        const size_t dlds = std::max((size_t)NST * (BM + BN) * BK, (size_t)BM * (BN + 4)) * sizeof(float);
         static const hipError_t dma_attr = [] {
             hipError_t e = hipFuncSetAttribute(
                 reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>),
@@ -1436,7 +1437,12 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         return launch_streamk(p, (int)M, stream);
     }
     if (tile == 5 || tile == 6) tile = 1;       // stream-K not applicable here
-    if (tile == 0) tile = 4;     // with the float4 epilogue the 64x64 tile is at least as fast as 128x128 everywhere measured
+    if (tile == 0) {
+        // 64x64 everywhere, except when the 128x128 grid is one nearly full round of 2 workgroups per CU (the
+        // 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per MAC is worth ~8 %
+        const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
+        tile = (b128 >= 420 && b128 <= 512 && !residual && (Cout % 4) == 0) ? 1 : 4;
+    }
     if (tile == 4 && splitk_ws) {
         const int KT = p.K / BK;
         const int sp = plan_splits(M, Cout, KT, tile_hint);
