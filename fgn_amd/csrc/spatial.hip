@@ -262,17 +262,18 @@ extern "C" int fgn_roi_align_mask_u8(const uint8_t* mask, const float* rois, flo
 // One workgroup per (group, 256-channel slab): lanes own 4 channels each, waves split
 // the (k,p) range and combine through LDS.
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void class_vector_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ w,
-                                                           float* __restrict__ out, int K, int P, int C) {
-    __shared__ float4 part[4][64];
+constexpr int CV_WAVES = 16;      // 12 workgroups in all at cfg3 and a serial K*P loop per wave: many waves keep it short
+__global__ __launch_bounds__(64 * CV_WAVES) void class_vector_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ w,
+                                                                     float* __restrict__ out, int K, int P, int C) {
+    __shared__ float4 part[CV_WAVES][64];
     const int g = blockIdx.x;
     const int c = (blockIdx.y * 64 + (threadIdx.x & 63)) * 4;
     const int wv = threadIdx.x >> 6;
     const int KP = K * P;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        for (int i = wv; i < KP; i += 4) {
+        for (int i = wv; i < KP; i += CV_WAVES) {
             const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)g * KP + i) * C + c);
             const float s = w ? w[(size_t)g * KP + i] : 1.f;
             acc.x += v.x * s; acc.y += v.y * s; acc.z += v.z * s; acc.w += v.w * s;
@@ -281,14 +282,14 @@ __global__ __launch_bounds__(256) void class_vector_kernel(const float* __restri
     part[wv][threadIdx.x & 63] = acc;
     __syncthreads();
     if (wv == 0 && c < C) {
-        float4 a = part[0][threadIdx.x], b = part[1][threadIdx.x], d = part[2][threadIdx.x],
-               e = part[3][threadIdx.x];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < CV_WAVES; ++k) {            // fixed order
+            const float4 a = part[k][threadIdx.x];
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
         const float inv = 1.f / (float)KP;
-        float4 o;
-        o.x = ((a.x + b.x) + (d.x + e.x)) * inv;
-        o.y = ((a.y + b.y) + (d.y + e.y)) * inv;
-        o.z = ((a.z + b.z) + (d.z + e.z)) * inv;
-        o.w = ((a.w + b.w) + (d.w + e.w)) * inv;
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
         *reinterpret_cast<float4*>(out + (size_t)g * C + c) = o;
     }
 }
@@ -298,7 +299,7 @@ extern "C" int fgn_support_class_vectors_f32(const float* x, const float* weight
     if (!x || !out) return FGN_ERR_ARG;
     if (C % 4) return FGN_ERR_SHAPE;
     if (n_groups == 0) return FGN_OK;
-    hipLaunchKernelGGL(class_vector_kernel, dim3(n_groups, cdiv(C, 256)), dim3(256), 0, stream, x, weights,
+    hipLaunchKernelGGL(class_vector_kernel, dim3(n_groups, cdiv(C, 256)), dim3(64 * CV_WAVES), 0, stream, x, weights,
                        out, K, P, C);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
