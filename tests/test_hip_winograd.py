@@ -61,3 +61,28 @@ def test_winograd_bn_fold_and_device_count():
     ref = F.relu(F.batch_norm(y, bn['running_mean'], bn['running_var'], bn['weight'], bn['bias'], False, 0.0, 1e-5))
     d = (got[:23].cpu().permute(0, 3, 1, 2) - ref[:23]).abs().max().item()
     assert d <= 1e-4 * ref.abs().max().item(), d
+
+
+def test_full_size_linearity_and_guidance_equivalence():
+    """Size-independent properties at the cfg3 AG-RPN size (3 guided maps of 50x84x1024 -> 1024; no CPU reference
+    at this size: 238 GFLOP): (1) the layer is linear before its ReLU: conv(x1 + x2) = conv(x1) + conv(x2);
+    (2) the guidance multiply fused into the input transform equals scaling the input first; (3) Winograd and the
+    direct kernel agree.  Tolerance 1e-4 of the output range (fp32)."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cin = cout = 1024
+    x1 = torch.randn(1, 50, 84, cin, generator=g).cuda()
+    x2 = torch.randn(1, 50, 84, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    s = (torch.rand(3, cin, generator=g) + 0.5).cuda()
+    lin = ops.pack_winograd(wt, relu=False).to('cuda')
+    y1 = ops.conv3x3_winograd(x1, lin, in_scale=s, a_img_div=3)
+    y2 = ops.conv3x3_winograd(x2, lin, in_scale=s, a_img_div=3)
+    y12 = ops.conv3x3_winograd(x1 + x2, lin, in_scale=s, a_img_div=3)
+    rng = y12.abs().max().item()
+    assert y12.shape == (3, 50, 84, cout)
+    assert (y12 - (y1 + y2)).abs().max().item() <= 1e-4 * rng
+    pre = ops.conv3x3_winograd(ops.scale_channels(x1, s, 3), lin)
+    assert (pre - y1).abs().max().item() <= 1e-4 * rng
+    direct = ops.conv2d(ops.scale_channels(x1, s, 3), ops.pack_conv(wt, pad=1).to('cuda'))
+    assert (direct - y1).abs().max().item() <= 1e-4 * rng
