@@ -30,3 +30,15 @@ for name, n, H, W, cin, cout, k, s, res in SH:
             idx = torch.nonzero(d.reshape(-1, cout) > 0)
             print(f'   run {i}: {int((d > 0).sum())} elems differ, max {float(d.max()):.3g}, rows {idx[:, 0].min().item()}..{idx[:, 0].max().item()} cols {idx[:, 1].min().item()}..{idx[:, 1].max().item()}')
     print(f'{name:20s} {"OK" if bad == 0 else f"{bad}/{N} RUNS DIFFER"}', flush=True)
+
+# Winograd layers (transforms + grouped GEMM) at the cfg3 sizes
+for name, n, H, W, cin, cout, div in [('wg agrpn', 1, 50, 84, 1024, 1024, 3), ('wg sh300', 300, 7, 7, 512, 512, 1),
+                                      ('wg sh100', 100, 7, 7, 512, 512, 1), ('wg l3', 1, 50, 84, 256, 256, 1),
+                                      ('wg mask0', 100, 7, 7, 1024, 256, 1)]:
+    x = torch.randn(n, H, W, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.02
+    layer = ops.pack_winograd(wt, bias=torch.randn(cout, generator=g), relu=True).to('cuda')
+    s = (torch.rand(n * div, cin, generator=g) + 0.5).cuda() if (div > 1 or 'mask0' in name) else None
+    ref = ops.conv3x3_winograd(x, layer, in_scale=s, a_img_div=div).clone()
+    bad = sum(0 if torch.equal(ops.conv3x3_winograd(x, layer, in_scale=s, a_img_div=div), ref) else 1 for _ in range(N))
+    print(f'{name:20s} {"OK" if bad == 0 else f"{bad}/{N} RUNS DIFFER"}', flush=True)
