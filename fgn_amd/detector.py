@@ -590,14 +590,22 @@ class FGN(torch.nn.Module):
         # starts: its ~30 tiny 9-RoI launches (0.3 ms end to end, a handful of CUs each) hide under
         # the 2 ms stream-K conv and the single-workgroup proposal kernel instead of delaying the
         # query backbone or the RoI head
+        g_map = None
         if not cached:
             with torch.cuda.stream(side):
                 side.wait_event(rpn_start)
                 self._support_back(sc, B, dev)
+                if P['sh0_lin'] is not None and side is not main:
+                    # shared_head conv1 on the query map (see _roi_feats): independent of the proposals, so it
+                    # runs here, beside the single-workgroup proposal kernel, instead of after it
+                    g_map = ops.conv2d(qry_fmap, P['sh0_lin'])
                 spp_ready = side.record_event()
             if not torch.cuda.is_current_stream_capturing():
                 for key in ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):   # produced on side, consumed on main
                     sc[key].record_stream(main)
+                if g_map is not None:
+                    g_map.record_stream(main)
+                    qry_fmap.record_stream(side)
         S, cat_mean, cat_mean_mp, masks7 = sc['S'], sc['cat_mean'], sc['cat_mean_mp'], sc['masks7']
 
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
@@ -622,7 +630,8 @@ class FGN(torch.nn.Module):
         R, D = props.shape[1], tc['rcnn']['max_per_img']
         rois_all = self._rois_of(props[:, :, :4], B, dev)                         # [B*R,5]
         cnt_all = n_props[0:1] if B == 1 else None
-        g_map = ops.conv2d(qry_fmap, P['sh0_lin']) if P['sh0_lin'] is not None else None    # [B,h,w,planes]
+        if g_map is None and P['sh0_lin'] is not None:
+            g_map = ops.conv2d(qry_fmap, P['sh0_lin'])                                # [B,h,w,planes]
         roi_in, feats = self._roi_feats(qry_fmap, g_map, rois_all, cnt_all)
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
