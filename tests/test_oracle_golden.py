@@ -81,3 +81,28 @@ def test_mask_vector_gather_matches_reference(golden_dir):
     assert np.array_equal(vec.numpy(), z['spp_vecs_mask'])
     assert np.array_equal((torch.from_numpy(z['feats']) * vec).numpy(), z['mask_pred'])
     assert (z['labels_mask_0'] == 0).all()
+
+
+def test_published_known_answers_of_the_upstream_box_code():
+    """The parts of the path that live in mmdet 2.18 / mmcv 1.3.16 (absent from the image) are restated from their
+    published algorithm; their docstrings carry known-answer examples, reproduced here:
+    - mmdet/core/bbox/coder/delta_xywh_bbox_coder.py, `delta2bbox` example (means 0, stds 1, max_shape (32,32,3));
+    - mmdet/core/anchor/anchor_generator.py, `AnchorGenerator([16],[1.],[1.],[9]).grid_anchors([(2,2)])`;
+    - mmcv/ops/nms.py, `nms` example (7 boxes, IoU 0.6 -> 3 kept)."""
+    from oracle import fgn_ref_cpu as O
+    rois = np.array([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]], np.float32)
+    deltas = np.array([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]], np.float32)
+    out = O.delta2bbox(rois, deltas, (0., 0., 0., 0.), (1., 1., 1., 1.), (32, 32, 3))
+    want = np.array([[0.0000, 0.0000, 1.0000, 1.0000], [0.1409, 0.1409, 2.8591, 2.8591],
+                     [0.0000, 0.3161, 4.1945, 0.6839], [5.0000, 5.0000, 5.0000, 5.0000]], np.float32)
+    assert np.allclose(out, want, atol=5e-5)
+    base = O.base_anchors((1.,), (1.,), 9)
+    grid = O.grid_anchors(base, 2, 2, 16)
+    assert np.array_equal(grid, np.array([[-4.5, -4.5, 4.5, 4.5], [11.5, -4.5, 20.5, 4.5],
+                                          [-4.5, 11.5, 4.5, 20.5], [11.5, 11.5, 20.5, 20.5]], np.float32))
+    boxes = np.array([[49.1, 32.4, 51.0, 35.9], [49.3, 32.9, 51.0, 35.3], [49.2, 31.8, 51.0, 35.4],
+                      [35.1, 11.5, 39.1, 15.7], [35.6, 11.8, 39.3, 14.2], [35.3, 11.5, 39.9, 14.5],
+                      [35.2, 11.7, 39.7, 15.7]], np.float32)
+    scores = np.array([0.9, 0.9, 0.5, 0.5, 0.5, 0.4, 0.3], np.float32)
+    dets, inds = O.nms(boxes, scores, 0.6)
+    assert len(dets) == len(inds) == 3 and inds.tolist() == [0, 3, 4]
