@@ -15,6 +15,19 @@
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the
+// function object of the CURRENT device (a process may drive several GPUs): set once per (call site, device);
+// `done_mask` is a static of the call site, bit d = device d done.
+static inline hipError_t fgn_allow_full_lds(const void* fn, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev < 64) *done_mask |= 1ull << dev;
+    return e;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -22,11 +22,10 @@
 //     kernel only): the mask-head support-vector multiply (fgn_roi_head.py:379); `a_img_div` lets several
 //     output images read one input image (AG-RPN guidance, fgn_ag_rpn_head.py:44, when the direct form is
 //     used; the Winograd form applies it in its input transform).
-//   Kernels   :  conv_igemm_dma_kernel (64x64 tile, optional split-K; modes generic / point-wise / stem),
-//     conv_streamk16_kernel and conv_streamk_kernel (128x128 tile, 512 persistent workgroups, stream-K;
-//     the 16x16x4 variant also runs the grouped Winograd GEMM), conv_igemm_kernel (register-staged loader,
-//     [rows][32 + 4 pad] LDS layout, for the fused input scale); the dispatcher at the bottom of the file
-//     picks one per launch.
+//   Kernels   :  conv_igemm_dma_kernel (64x64 tile, optional split-K; modes generic / point-wise + grouped
+//     Winograd GEMM / stem), conv_igemm_kernel (register-staged loader, [rows][32 + 4 pad] LDS layout, for the
+//     fused input scale when a layer does not take the Winograd form); the dispatcher at the bottom of the
+//     file picks one per launch.
 #include "common.h"
 #include <cstdlib>
 
@@ -56,16 +55,10 @@ struct ConvParams {
     // device.  grp_rows == 0: plain convolution.
     int grp_rows, grp_valid, grp_items, grp_rows_per_item, grp_w_stride;
     const int32_t* grp_count_dev;
-    // stream-K: round the units per workgroup up to whole tiles (no split tiles, no slabs, no fix-up launch);
-    // chosen by the host when that idles < 7 % of the workgroups
-    int sk_align;
 };
 
 #ifndef CONV_DMA_STAGES
 #define CONV_DMA_STAGES 2
-#endif
-#ifndef CONV_DBG
-#define CONV_DBG 0   // diagnostic ablations (tools only): 1 no global loads, 2 no ds_write, 4 no ds_read, 8 no barrier, 16 loads always hit the first tile
 #endif
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats
@@ -257,12 +250,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = (CONV_DBG & 4) ? make_float4(acc[i][0][0], acc[i][0][1], 1.f, 2.f)
-                                       : *reinterpret_cast<const float4*>(As + i * 32 * LDS_STRIDE + kk * 8);
+                af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = (CONV_DBG & 4) ? make_float4(acc[0][j][2], acc[0][j][3], 1.f, 2.f)
-                                       : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_STRIDE + kk * 8);
+                bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -291,24 +282,20 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_kernel(const ConvPa
                 finish_tile<A_LD, IN_SCALE>(okm, a_reg, s_reg);
                 float* sa = st_a + (cur ^ 1) * STAGE;
                 float* sb = st_b + (cur ^ 1) * STAGE;
-                if (!(CONV_DBG & 2)) {
 #pragma unroll
-                    for (int i = 0; i < A_LD; ++i)
-                        *reinterpret_cast<float4*>(sa + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
+                for (int i = 0; i < A_LD; ++i)
+                    *reinterpret_cast<float4*>(sa + 32 * i * LDS_STRIDE) = PACK_GET4(a_reg, i);
 #pragma unroll
-                    for (int i = 0; i < B_LD; ++i)
-                        *reinterpret_cast<float4*>(sb + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
-                }
+                for (int i = 0; i < B_LD; ++i)
+                    *reinterpret_cast<float4*>(sb + 32 * i * LDS_STRIDE) = PACK_GET4(b_reg, i);
                 asm volatile("" ::: "memory");
-                if (!(CONV_DBG & 1))
-                    okm = load_tile<A_LD, B_LD, IN_SCALE>(p, st, b_base,
-                                                                (CONV_DBG & 16) ? kt0 : min(kt + 2, KT - 1), cin_tiles,
-                                                                col4, a_reg, s_reg, b_reg);
+                okm = load_tile<A_LD, B_LD, IN_SCALE>(p, st, b_base, min(kt + 2, KT - 1), cin_tiles, col4, a_reg,
+                                                      s_reg, b_reg);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!(CONV_DBG & 8)) __syncthreads();
+        __syncthreads();
         cur ^= 1;
     }
 
@@ -583,7 +570,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         if (nxt >= NSTAGE) nxt -= NSTAGE;
         // (with two stages the last iteration has nothing to prefetch; deeper pipelines keep the clamped
         // re-load so that the counted s_waitcnt below stays exact)
-        if (!(CONV_DBG & 1) && (NSTAGE > 2 || kt + 1 < KT)) issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
+        if (NSTAGE > 2 || kt + 1 < KT) issue_tile(min(kt + NSTAGE - 1, KT - 1), nxt);
         asm volatile("" ::: "memory");
 
         const float* As = rd_a + cur * STAGE;
@@ -626,7 +613,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         // tiles at 4-5 workgroups per CU: one wave's last k-slice of a K-tile wrong.)
         if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
-        if (!(CONV_DBG & 8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches
@@ -637,7 +624,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     // epilogue (68 MB residual read + 68 MB store at layer1) outweighs their K loop.
     constexpr int PITCH = BN + 4;                     // floats; rows keep b128 alignment, shift banks by 4
     // (the launcher sizes the dynamic LDS to max(stages, C tile): 128x128 needs 67.6 KB for the C tile)
-    if constexpr (!(CONV_DBG & 64)) if ((p.Cout & 3) == 0) {
+    if ((p.Cout & 3) == 0) {
         float* const cbase = smem;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -681,7 +668,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         }
                     }
-                    if (!(CONV_DBG & 32) || v.x == 12345.678f) *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n) = v;
+                    *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n) = v;
                 }
             }
         }
@@ -721,536 +708,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
                     float v = acc[i][j][r] * sc + sh;
                     if (p.residual) v += p.residual[o];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (!(CONV_DBG & 32) || v == 12345.678f) p.y[o] = v;
+                    p.y[o] = v;
                 }
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stream-K variant of the LDS-DMA kernel (128x128 tile, 4 waves of 64x64, 2 LDS stages).
-// A fixed grid of SK_BLOCKS = 2 x 256 CUs persistent workgroups splits the launch's total
-// work - (output tiles) x (K-tiles) units - into equal contiguous ranges, so every CU
-// finishes at the same time whatever the tile count.  Measured motivation (tools/
-// conv_tail_probe.py): the same kernel runs 134 TF/s at 768 tiles and 104 TF/s at 792,
-// because a data-parallel grid leaves most CUs idle during its last partial wave.
-// A range covers part of one tile, then whole tiles, then part of a last tile.  Whole tiles
-// take the fused epilogue; partial tiles store raw 128x128 accumulators to a per-(block, slot)
-// slab and streamk_fixup_kernel adds the 2-4 slabs of a split tile in ascending block order
-// (deterministic) before the same epilogue.
-// ------------------------------------------------------------------------------------------------
-constexpr int SK_BLOCKS = 512;
-constexpr int SK_TILE = 128;
-
-__host__ __device__ __forceinline__ int sk_units_per_block(int total_units, int KT, int align) {
-    const int per = (total_units + SK_BLOCKS - 1) / SK_BLOCKS;
-    return align ? (per + KT - 1) / KT * KT : per;
-}
-
-__global__ __launch_bounds__(256, 2) void conv_streamk_kernel(const ConvParams p) {
-    constexpr int BM = SK_TILE, BN = SK_TILE, WM = 64, WN = 64;
-    constexpr int TM = 2, TN = 2, A_LD = 4, B_LD = 4;
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr unsigned OOB = 0x7ffffff0u;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-
-    int bid = blockIdx.x;      // XCD-contiguous logical ids (SK_BLOCKS is a multiple of 8)
-    bid = (bid & 7) * (SK_BLOCKS / 8) + (bid >> 3);
-
-    const int HoWo = p.Ho * p.Wo;
-    int n_img = p.n_img;
-    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
-    const int M = n_img * HoWo;
-    const int KT = p.K / BK;
-    const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
-    const int total = tiles * KT;
-    const int per = sk_units_per_block(total, KT, p.sk_align);
-    int u = bid * per;
-    const int u_end = min(u + per, total);
-    if (u >= u_end) return;
-
-    const int col4 = t & 7;
-    const int row0 = t >> 3;
-    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
-    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
-    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
-    const int cin_tiles = p.Cin / BK;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
-    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
-    const int frag_row = lane & 31;
-    const int half = lane >> 5;
-    const int rswz = (frag_row >> 1) & 7;
-    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
-    float* const my_slabs = p.ws + (size_t)bid * 2 * (SK_TILE * SK_TILE);
-
-    while (u < u_end) {
-        const int tile = u / KT;
-        const int kb = u - tile * KT;
-        const int ke = min(KT, kb + (u_end - u));
-        const bool first_seg = (u == bid * per);
-        u += ke - kb;
-        const int tile_m = tile / p.n_tiles_n;
-        const int tile_n = tile - tile_m * p.n_tiles_n;
-        const int m0 = tile_m * BM;
-        const int n0 = tile_n * BN;
-
-        int a_off[A_LD];
-        unsigned long long a_taps[A_LD];
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int m = m0 + row0 + 32 * i;
-            a_off[i] = 0; a_taps[i] = 0ull;
-            if (m < M) {
-                const int img = m / HoWo;
-                const int rem = m - img * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_off[i] = ((((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + src_c4 * 4) * 4;
-                unsigned long long tm = 0ull;
-                int tp = 0;
-                for (int ky = 0; ky < p.KH; ++ky) {
-                    const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
-                    for (int kx = 0; kx < p.KW; ++kx, ++tp)
-                        if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
-                }
-                a_taps[i] = tm;
-            }
-        }
-        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
-
-        auto issue_tile = [&](int kt, int stage) {
-            const int tap = kt / cin_tiles;
-            const int c0 = (kt - tap * cin_tiles) * BK;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int tap_off = ((ky * p.W + kx) * p.Cin + c0) * 4;
-            const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const bool ok = (a_taps[i] >> tap) & 1ull;
-                lds_dma16(x_rs, sa + i * 32 * 128, ok ? (unsigned)(a_off[i] + tap_off) : OOB);
-            }
-            const unsigned sb = sa + BM * 128;
-            const unsigned bko = (unsigned)(kt * BK * 4);
-#pragma unroll
-            for (int i = 0; i < B_LD; ++i)
-                lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
-        };
-
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        // all waves are past the previous segment's LDS reads (barrier at the end of its loop)
-        issue_tile(kb, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
-        for (int kt = kb; kt < ke; ++kt) {
-            issue_tile(min(kt + 1, ke - 1), cur ^ 1);
-            asm volatile("" ::: "memory");
-            const float* As = rd_a + cur * STAGE;
-            const float* Bs = rd_b + cur * STAGE;
-            // fragment double buffering: the ds_reads of K-slice kk+1 are issued before the 16 MFMAs
-            // of slice kk, so their LDS latency is covered instead of exposed once per slice
-            float4 af[2][TM], bf[2][TN];
-            {
-                const int pc = ((0 * 2 + half) ^ rswz) * 4;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cb = kk & 1, nb = cb ^ 1;
-                if (kk < 3) {
-                    const int pc = (((kk + 1) * 2 + half) ^ rswz) * 4;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const float4*>(As + i * 32 * BK + pc);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK + pc);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].x, bf[cb][j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].y, bf[cb][j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].z, bf[cb][j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own LDS reads returned (see conv_igemm_dma_kernel)
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
-        }
-
-        if (kb == 0 && ke == KT) {
-            // whole tile: fused epilogue
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 32 + frag_row;
-                const bool n_ok = n < p.Cout;
-                const float sc = (n_ok && p.scale) ? p.scale[n] : 1.f;
-                const float sh = (n_ok && p.shift) ? p.shift[n] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int mb = m0 + wm * WM + i * 32 + 4 * half;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mb + (r & 3) + 8 * (r >> 2);
-                        if (n_ok && m < M) {
-                            const size_t o = (size_t)m * p.Cout + n;
-                            float v = acc[i][j][r] * sc + sh;
-                            if (p.residual) v += p.residual[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            p.y[o] = v;
-                        }
-                    }
-                }
-            }
-        } else {
-            // partial tile: raw accumulators to this block's slab (slot 0 = the block's first
-            // segment, slot 1 = a later one, which can only be its last)
-            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * WN + j * 32 + frag_row;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int rb = wm * WM + i * 32 + 4 * half;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) slab[(rb + (r & 3) + 8 * (r >> 2)) * SK_TILE + col] = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
-
-// 16x16x4 MFMA variant of the stream-K kernel (same tiles, LDS image, partition and slabs):
-// experiment for the clock the chip holds per MFMA shape (MI355X_MICROARCH.md, DVFS item 7).
-__global__ __launch_bounds__(256, 2) void conv_streamk16_kernel(const ConvParams p) {
-    constexpr int BM = SK_TILE, BN = SK_TILE, WM = 64, WN = 64;
-    constexpr int TM = 4, TN = 4, A_LD = 4, B_LD = 4;   // 4x4 MFMA tiles of 16x16 per wave
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr unsigned OOB = 0x7ffffff0u;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-
-    int bid = blockIdx.x;      // XCD-contiguous logical ids (SK_BLOCKS is a multiple of 8)
-    bid = (bid & 7) * (SK_BLOCKS / 8) + (bid >> 3);
-
-    const int HoWo = p.Ho * p.Wo;
-    int n_img = p.n_img;
-    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
-    const int M = n_img * HoWo;
-    const int KT = p.K / BK;
-    const int tiles = ((M + BM - 1) / BM) * p.n_tiles_n;
-    const int total = tiles * KT;
-    const int per = sk_units_per_block(total, KT, p.sk_align);
-    int u = bid * per;
-    const int u_end = min(u + per, total);
-    if (u >= u_end) return;
-
-    const int col4 = t & 7;
-    const int row0 = t >> 3;
-    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
-    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
-    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
-    const int cin_tiles = p.Cin / BK;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
-    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
-    const int frag_row = lane & 15;        // 16x16x4: lane l feeds A[row l&15][k = l>>4]
-    const int kgrp = lane >> 4;            // which float4 of a 16-wide K chunk this lane reads
-    const int rswz = (frag_row >> 1) & 7;
-    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
-    float* const my_slabs = p.ws + (size_t)bid * 2 * (SK_TILE * SK_TILE);
-
-    while (u < u_end) {
-        const int tile = u / KT;
-        const int kb = u - tile * KT;
-        const int ke = min(KT, kb + (u_end - u));
-        const bool first_seg = (u == bid * per);
-        u += ke - kb;
-        const int tile_m = tile / p.n_tiles_n;
-        const int tile_n = tile - tile_m * p.n_tiles_n;
-        const int m0 = tile_m * BM;
-        const int n0 = tile_n * BN;
-
-        int a_off[A_LD];
-        unsigned long long a_taps[A_LD];
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int m = m0 + row0 + 32 * i;
-            a_off[i] = 0; a_taps[i] = 0ull;
-            if (m < M) {
-                const int img = m / HoWo;
-                const int rem = m - img * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_off[i] = ((((img / p.a_img_div) * p.H + iy0) * p.W + ix0) * p.Cin + src_c4 * 4) * 4;
-                unsigned long long tm = 0ull;
-                int tp = 0;
-                for (int ky = 0; ky < p.KH; ++ky) {
-                    const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)p.H;
-                    for (int kx = 0; kx < p.KW; ++kx, ++tp)
-                        if (y_ok && (unsigned)(ix0 + kx) < (unsigned)p.W) tm |= 1ull << tp;
-                }
-                a_taps[i] = tm;
-            }
-        }
-        const int b_off0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
-
-        // incremental K-tile -> (tap, byte offset) decode (see conv_igemm_dma_kernel)
-        int nx_tap = kb / cin_tiles;
-        int nx_c0t = kb - nx_tap * cin_tiles;
-        int nx_kx, nx_off;
-        {
-            const int ky = nx_tap / p.KW;
-            nx_kx = nx_tap - ky * p.KW;
-            nx_off = ((ky * p.W + nx_kx) * p.Cin + nx_c0t * BK) * 4;
-        }
-        auto issue_tile = [&](int kt, int stage) {
-            const int tap = nx_tap;
-            const int tap_off = nx_off;
-            nx_off += BK * 4;
-            if (++nx_c0t == cin_tiles) {
-                nx_c0t = 0;
-                ++nx_tap;
-                if (++nx_kx == p.KW) {
-                    nx_kx = 0;
-                    nx_off += (p.W - p.KW) * p.Cin * 4;
-                }
-            }
-            const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const bool ok = (a_taps[i] >> tap) & 1ull;
-                lds_dma16(x_rs, sa + i * 32 * 128, ok ? (unsigned)(a_off[i] + tap_off) : OOB);
-            }
-            const unsigned sb = sa + BM * 128;
-            const unsigned bko = (unsigned)(kt * BK * 4);
-#pragma unroll
-            for (int i = 0; i < B_LD; ++i)
-                lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
-        };
-
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-        // all waves are past the previous segment's LDS reads (barrier at the end of its loop)
-        issue_tile(kb, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
-        for (int kt = kb; kt < ke; ++kt) {
-            if (kt + 1 < ke) issue_tile(kt + 1, cur ^ 1);      // nothing to prefetch behind the segment's last tile
-            asm volatile("" ::: "memory");
-            const float* As = rd_a + cur * STAGE;
-            const float* Bs = rd_b + cur * STAGE;
-            // two 16-wide K chunks per K-tile; per chunk one ds_read_b128 per 16-row fragment feeds
-            // 4 MFMAs (element j of lane group g contracts k = 4g + j)
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const int pc = ((kc * 4 + kgrp) ^ rswz) * 4;
-                float4 af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 16 * BK + pc);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 16 * BK + pc);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own LDS reads returned (see conv_igemm_dma_kernel)
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
-        }
-
-        // C/D layout of 16x16x4: col = lane&15 (-> n), row = 4*(lane>>4) + r (-> m).  Stored straight from
-        // registers that is 64 B per (row, 16-lane group); instead the 128x128 tile takes a round trip through
-        // the 64 KB of LDS (idle between segments): columns rotated by 16*((row>>2)&3) floats so the four
-        // row groups of a wave land in different banks, then every lane moves 16 B and a half-wave one
-        // 512 B row segment - to y with the fused epilogue, or raw to this block's slab.
-        {
-            const int g16 = 16 * kgrp;                     // (row >> 2) & 3 == kgrp for row = 16i + 4*kgrp + r
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = (wn * WN + j * 16 + frag_row + g16) & (SK_TILE - 1);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float* cw = smem + (wm * WM + i * 16 + 4 * kgrp) * SK_TILE + col;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cw[r * SK_TILE] = acc[i][j][r];
-                }
-            }
-        }
-        __syncthreads();
-        {
-            const bool whole = (kb == 0 && ke == KT);
-            const int c4 = t & 31, rr = t >> 5;            // 32 float4 per row, 8 rows per pass
-            const int n = n0 + c4 * 4;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool n_ok = n < p.Cout;                  // Cout % 4 == 0 (dispatcher)
-            if (whole && n_ok && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
-            if (whole && n_ok && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
-            float* slab = my_slabs + (first_seg ? 0 : SK_TILE * SK_TILE);
-#pragma unroll 4
-            for (int k = 0; k < SK_TILE / 8; ++k) {
-                const int row = rr + 8 * k;
-                const int pc = (c4 * 4 + 16 * ((row >> 2) & 3)) & (SK_TILE - 1);
-                float4 v = *reinterpret_cast<const float4*>(smem + row * SK_TILE + pc);
-                if (!whole) {
-                    *reinterpret_cast<float4*>(slab + row * SK_TILE + c4 * 4) = v;
-                    continue;
-                }
-                const int m = m0 + row;
-                if (!n_ok || m >= M) continue;
-                const size_t o = (size_t)m * p.Cout + n;
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (p.residual) {
-                    const float4 rs = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-                }
-                if (p.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *reinterpret_cast<float4*>(p.y + o) = v;
-            }
-        }
-        __syncthreads();                                   // LDS is the DMA target of the next segment
-    }
-}
-
-
-// one workgroup per output tile: sums the slabs of a split tile in ascending block order
-__global__ __launch_bounds__(256) void streamk_fixup_kernel(const ConvParams p) {
-    const int HoWo = p.Ho * p.Wo;
-    int n_img = p.n_img;
-    if (p.n_img_dev) n_img = min(n_img, *p.n_img_dev);
-    const int M = n_img * HoWo;
-    const int KT = p.K / BK;
-    const int tiles = ((M + SK_TILE - 1) / SK_TILE) * p.n_tiles_n;
-    const int tile = blockIdx.x;
-    if (tile >= tiles) return;
-    const int per = sk_units_per_block(tiles * KT, KT, p.sk_align);
-    const int b_lo = (tile * KT) / per, b_hi = ((tile + 1) * KT - 1) / per;
-    if (b_lo == b_hi) return;                          // produced whole by one block
-    const int tile_m = tile / p.n_tiles_n, tile_n = tile - tile_m * p.n_tiles_n;
-    const int m0 = tile_m * SK_TILE, n0 = tile_n * SK_TILE;
-    for (int e = threadIdx.x; e < SK_TILE * SK_TILE / 4; e += 256) {
-        const int row = e >> 5, c4 = (e & 31) * 4;
-        const int m = m0 + row, n = n0 + c4;
-        if (m >= M || n >= p.Cout) continue;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = b_lo; b <= b_hi; ++b) {
-            const int slot = (max(tile * KT, b * per) == b * per) ? 0 : 1;
-            const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)b * 2 + slot) * (SK_TILE * SK_TILE) +
-                                                              row * SK_TILE + c4);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-        if (p.scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-            a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w;
-        }
-        if (p.shift) {
-            const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
-            a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w;
-        }
-        const size_t o = (size_t)m * p.Cout + n;
-        if (p.residual) {
-            const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
-            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
-        }
-        if (p.relu) {
-            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(p.y + o) = a;
-    }
-}
-
-static int launch_streamk(const ConvParams& p0, int M_max, hipStream_t stream) {
-    ConvParams p = p0;
-    p.n_tiles_n = cdiv(p.Cout, SK_TILE);
-    const size_t dlds = (size_t)2 * (SK_TILE + SK_TILE) * BK * sizeof(float);
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_streamk16_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return e;
-    }();
-    if (attr != hipSuccess) return (int)attr;
-    {
-        const int KT = p.K / BK;
-        const long long total = (long long)cdiv(M_max, SK_TILE) * p.n_tiles_n * KT;
-        const int per = sk_units_per_block((int)total, KT, 0), per_al = sk_units_per_block((int)total, KT, 1);
-        p.sk_align = (per_al * 100 <= per * 107) ? 1 : 0;
-    }
-    if (p0.splits == 16)
-        hipLaunchKernelGGL(conv_streamk16_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
-    else
-        hipLaunchKernelGGL(conv_streamk_kernel, dim3(SK_BLOCKS), dim3(256), dlds, stream, p);
-    FGN_LAUNCH_CHECK();
-    if (!p.sk_align) {
-        hipLaunchKernelGGL(streamk_fixup_kernel, dim3(cdiv(M_max, SK_TILE) * p.n_tiles_n), dim3(256), 0, stream, p);
-        FGN_LAUNCH_CHECK();
-    }
-    return FGN_OK;
 }
 
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
@@ -1293,33 +755,20 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     p.n_tiles_n = cdiv(p.Cout, BN);
     const dim3 grid(cdiv(M_max, BM) * p.n_tiles_n, p.splits);
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    static const hipError_t attr_once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, MW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return e;
-    }();
-    if (attr_once != hipSuccess) return (int)attr_once;
+    static unsigned long long lds_ok[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>), &lds_ok[0]);
+    if (attr == hipSuccess)
+        attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, false, MW>), &lds_ok[1]);
+    if (attr != hipSuccess) return (int)attr;
     if (!p.in_scale && p.x_bytes != 0) {
         constexpr int NST = (BM + BN >= 256) ? 2 : CONV_DMA_STAGES;   // 128x128 keeps 2 blocks/CU
         const size_t dlds = std::max((size_t)NST * (BM + BN) * BK, (size_t)BM * (BN + 4)) * sizeof(float);
-        static const hipError_t dma_attr = [] {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            return e;
-        }();
-        if (dma_attr != hipSuccess) return (int)dma_attr;
+        attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>), &lds_ok[2]);
+        if (attr == hipSuccess)
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), &lds_ok[3]);
+        if (attr == hipSuccess)
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), &lds_ok[4]);
+        if (attr != hipSuccess) return (int)attr;
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
         if (cin4)
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
@@ -1357,14 +806,38 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
     return s < 2 ? 1 : s;
 }
 
-// Stream-K pays for deep reductions (K >= 2048) with >= 24 K-tiles of work per persistent block
-// (measured, tools/conv_bench.py: 3x3 convs on >= 100 RoIs, the AG-RPN conv); tile_hint 5 forces it (tests), any other non-zero hint disables it.
-static bool use_streamk(long long M, int Cin, int Cout, int KT, int tile_hint) {
-    if (Cin == 4 || (Cout % 4) != 0) return false;
-    if (tile_hint == 5 || tile_hint == 6) return true;     // 6 = the 16x16x4 MFMA variant
-    if (tile_hint != 0) return false;
-    const long long tiles = ((M + SK_TILE - 1) / SK_TILE) * cdiv(Cout, SK_TILE);
-    return Cout >= 128 && KT >= 64 && tiles * KT >= (long long)SK_BLOCKS * 24;
+// tile choice (measured on MI355X, tools/conv_bench.py): 64x64 everywhere, except when the 128x128 grid is one nearly
+// full round of 2 workgroups per CU (the 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per
+// MAC is worth ~8 %.  1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (tile_hint forces one; tests).
+static int pick_tile(long long M, int Cout, bool has_residual, int tile_hint) {
+    int tile = tile_hint < 0 ? -tile_hint : tile_hint;
+    if (tile >= 100) tile -= 100;
+    if (tile == 0) {
+        const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
+        tile = (b128 >= 420 && b128 <= 512 && !has_residual && (Cout % 4) == 0) ? 1 : 4;
+    }
+    return tile;
+}
+
+// Which kernel the dispatcher launches for a layer: tile * 10 + mode, mode 0 = LDS-DMA generic, 1 = LDS-DMA
+// point-wise, 2 = LDS-DMA stem, 3 = register-staged (fused input scale, or operands beyond the 2 GiB buffer
+// descriptors).  Lets a profiler attribute a launch to the kernel name rocprofv3 reports, e.g. 41 =
+// conv_igemm_dma_kernel<64, 64, 32, 32, 2, 4, 1>.
+extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
+                                    int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || n_img <= 0 || a_img_div < 1) return FGN_ERR_SHAPE;
+    const bool cin4 = Cin == 4;
+    const long long M = (long long)n_img * Ho * Wo;
+    const int K = cin4 ? KH * BK : cdiv(KH * KW * Cin, BK) * BK;
+    const long long xb = (long long)((n_img + a_img_div - 1) / a_img_div) * H * W * Cin * 4;
+    const long long wb = (long long)cout_pad * K * 4;
+    const bool use_dma = (tile_hint < 100 || cin4) && xb < 0x7fffff00ll && wb < 0x7fffff00ll;
+    const int tile = pick_tile(M, Cout, has_residual != 0, tile_hint);
+    int mode = 3;
+    if (use_dma && !has_in_scale)
+        mode = cin4 ? 2 : (KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1) ? 1 : 0;
+    return tile * 10 + mode;
 }
 
 extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -1374,7 +847,6 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     if (tile_hint >= 100) tile_hint -= 100;
     const long long M = (long long)n_img * Ho * Wo;
     const int KT = cdiv(KH * KW * Cin, BK);
-    if (use_streamk(M, Cin, Cout, KT, tile_hint)) return (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float);
     if (tile_hint > 0 && tile_hint != 4) return 0;
     const int s = plan_splits(M, Cout, KT, tile_hint);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
@@ -1398,7 +870,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
-    p.grp_count_dev = nullptr; p.sk_align = 0;
+    p.grp_count_dev = nullptr;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return FGN_ERR_SHAPE;
@@ -1414,10 +886,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     const long long M = (long long)n_img * p.Ho * p.Wo;
     if (M * (long long)Cout >= (1ll << 31) * 4) return FGN_ERR_SHAPE;
 
-    // tile choice (measured on MI355X, tools_conv_bench.py): the 64x64 tile (4 blocks/CU,
-    // ~4 waves/SIMD) wins almost everywhere because it quantises best over 256 CUs; the
-    // 128x128 tile (2 blocks/CU) is ~10 % better only when its grid is one nearly full wave.
-    int tile = tile_hint < 0 ? -tile_hint : tile_hint;
+    int tile;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = p.K / BK;
     {
         // descriptor extents (< 4 GiB checked below); tile_hint >= 100 forces the register-staged kernel
@@ -1428,21 +897,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         p.w_bytes = use_dma ? (unsigned)wb : 0u;
         if (tile_hint >= 100) tile_hint -= 100;
     }
-    tile = tile_hint < 0 ? -tile_hint : tile_hint;
-    if (p.x_bytes && !in_scale && splitk_ws &&
-        splitk_ws_bytes >= (size_t)SK_BLOCKS * 2 * SK_TILE * SK_TILE * sizeof(float) &&
-        use_streamk(M, Cin, Cout, p.K / BK, tile_hint)) {
-        p.ws = splitk_ws;
-        p.splits = (tile_hint == 5) ? 1 : 16;      // MFMA-shape selector of launch_streamk: 16x16x4 by default (+2..4 % measured), hint 5 = 32x32x2
-        return launch_streamk(p, (int)M, stream);
-    }
-    if (tile == 5 || tile == 6) tile = 1;       // stream-K not applicable here
-    if (tile == 0) {
-        // 64x64 everywhere, except when the 128x128 grid is one nearly full round of 2 workgroups per CU (the
-        // 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per MAC is worth ~8 %
-        const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
-        tile = (b128 >= 420 && b128 <= 512 && !residual && (Cout % 4) == 0) ? 1 : 4;
-    }
+    tile = pick_tile(M, Cout, residual != nullptr, tile_hint);
     if (tile == 4 && splitk_ws) {
         const int KT = p.K / BK;
         const int sp = plan_splits(M, Cout, KT, tile_hint);
@@ -1466,7 +921,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
 //   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = 0..15 (position in the 4x4 transformed tile)
 // run as ONE launch of the 64x64 kernel in point-wise mode over the stacked rows [16 * t_pad] with a
 // per-group weight matrix.  t_pad is a multiple of the 64-row tile so no tile straddles two groups; 1600 tiles
-// (100 RoIs x 16) and 4800 (300 RoIs) need no padding at all.  (The grouped 128x128 stream-K variant measured
+// (100 RoIs x 16) and 4800 (300 RoIs) need no padding at all.  (A grouped 128x128 persistent variant measured
 // equal on the AG-RPN GEMM and 5 % slower on the 300-RoI one, and much slower on everything smaller.)
 // ------------------------------------------------------------------------------------------------
 extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
@@ -1491,6 +946,6 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
-    p.n_tiles_n = 0; p.sk_align = 0;
+    p.n_tiles_n = 0;
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

@@ -188,9 +188,9 @@ extern "C" int fgn_det_post_f32(const float* rois, const float* cls_raw, const f
     p.max_ratio = max_ratio; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_per_img;
     const size_t lds = (size_t)cap * 8 + 64 * 4 + (size_t)max_per_img * sizeof(NmsBox) +
                        NMS_ROUND * sizeof(NmsBox) + NMS_ROUND * NMS_WORDS * 8 + (NMS_ROUND + 2) * 4 + (size_t)max_per_img * 4 + (size_t)cap * 4;
-    static const hipError_t attr_once = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(det_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_once != hipSuccess) return (int)attr_once;
+    static unsigned long long lds_ok = 0ull;
+    const hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(det_post_kernel), &lds_ok);
+    if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(det_post_kernel, dim3(1), dim3(POST_THREADS), lds, stream, p);
     FGN_LAUNCH_CHECK();
     return FGN_OK;

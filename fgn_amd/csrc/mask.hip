@@ -200,6 +200,52 @@ __device__ __forceinline__ int rle_char_count(long long x) {
     return n;
 }
 
+// Step 3 of both RLE kernels: sorted transition positions tr[0..T) of the column-major pixel sequence -> run
+// lengths -> COCO string (rleToString of pycocotools: delta against the run two back from the 4th run on, 5 data
+// bits + continuation bit per character, +48).  Whole workgroup (RLE_THREADS); writes *out_len / *overflow.
+__device__ inline void emit_coco_string(const uint32_t* __restrict__ tr, int T, long long HWl, uint8_t* __restrict__ ob,
+                                        int byte_cap, int32_t* out_len, int32_t* overflow, int* wave_sums) {
+    const int t = threadIdx.x;
+    auto run_len = [&](int i) -> long long {   // i in [0, T]
+        const long long hi = (i < T) ? (long long)tr[i] : HWl;
+        const long long lo = (i > 0) ? (long long)tr[i - 1] : 0;
+        return hi - lo;
+    };
+    const int n_runs = T + 1;
+    const int rpt = (n_runs + RLE_THREADS - 1) / RLE_THREADS;
+    int nchar = 0;
+    for (int j = 0; j < rpt; ++j) {
+        const int i = t * rpt + j;
+        if (i < n_runs) {
+            long long x = run_len(i);
+            if (i > 2) x -= run_len(i - 2);
+            nchar += rle_char_count(x);
+        }
+    }
+    int total_chars;
+    int o = block_exclusive_scan(nchar, wave_sums, &total_chars);
+    if (total_chars > byte_cap) {
+        if (t == 0) { *overflow = 1; *out_len = 0; }
+        return;
+    }
+    for (int j = 0; j < rpt; ++j) {
+        const int i = t * rpt + j;
+        if (i < n_runs) {
+            long long x = run_len(i);
+            if (i > 2) x -= run_len(i - 2);
+            bool more = true;
+            while (more) {
+                int c = (int)(x & 0x1f);
+                x >>= 5;
+                more = (c & 0x10) ? (x != -1) : (x != 0);
+                if (more) c |= 0x20;
+                ob[o++] = (uint8_t)(c + 48);
+            }
+        }
+    }
+    if (t == 0) { *out_len = total_chars; *overflow = 0; }
+}
+
 __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
     const float* __restrict__ prob, const float* __restrict__ boxes, int box_stride, uint32_t* __restrict__ trans,
     uint8_t* __restrict__ out_bytes, int32_t* __restrict__ out_len, int32_t* __restrict__ overflow,
@@ -270,47 +316,8 @@ __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
         }
     }
     __syncthreads();
-    // ---- 3. run lengths -> COCO string ---------------------------------------------------------
-    const long long HWl = (long long)H * W;
-    auto run_len = [&](int i) -> long long {   // i in [0, T]
-        const long long hi = (i < T) ? (long long)tr[i] : HWl;
-        const long long lo = (i > 0) ? (long long)tr[i - 1] : 0;
-        return hi - lo;
-    };
-    const int n_runs = T + 1;
-    const int rpt = (n_runs + RLE_THREADS - 1) / RLE_THREADS;
-    int nchar = 0;
-    for (int j = 0; j < rpt; ++j) {
-        const int i = t * rpt + j;
-        if (i < n_runs) {
-            long long x = run_len(i);
-            if (i > 2) x -= run_len(i - 2);
-            nchar += rle_char_count(x);
-        }
-    }
-    int total_chars;
-    int o = block_exclusive_scan(nchar, wave_sums, &total_chars);
-    if (total_chars > byte_cap) {
-        if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
-        return;
-    }
-    uint8_t* ob = out_bytes + (size_t)d * byte_cap;
-    for (int j = 0; j < rpt; ++j) {
-        const int i = t * rpt + j;
-        if (i < n_runs) {
-            long long x = run_len(i);
-            if (i > 2) x -= run_len(i - 2);
-            bool more = true;
-            while (more) {
-                int c = (int)(x & 0x1f);
-                x >>= 5;
-                more = (c & 0x10) ? (x != -1) : (x != 0);
-                if (more) c |= 0x20;
-                ob[o++] = (uint8_t)(c + 48);
-            }
-        }
-    }
-    if (t == 0) { out_len[d] = total_chars; overflow[d] = 0; }
+    emit_coco_string(tr, T, (long long)H * W, out_bytes + (size_t)d * byte_cap, byte_cap, out_len + d, overflow + d,
+                     wave_sums);
 }
 
 extern "C" int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
@@ -324,6 +331,121 @@ extern "C" int fgn_mask_rle(const float* prob, const float* boxes, int box_strid
     hipLaunchKernelGGL(mask_rle_kernel, dim3(n_det), dim3(RLE_THREADS), 0, stream, prob, boxes, box_stride,
                        trans_scratch, out_bytes, out_len, overflow, n_dev, n_det, img_h, img_w, mask_size, thr,
                        trans_cap, byte_cap);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// COCO RLE of DENSE binary masks: the ground-truth masks of the query image, which the reference moves to the
+// GPU with the rest of the batch (fgn.py:92-99) and run-length encodes on the host at the end of simple_test
+// (fgn.py:298, `qry_isegmaps_rle`).  Here they stay on the device: 4 host milliseconds of numpy per episode become
+// two small kernels beside the network, and only the strings cross PCIe.
+//   1. mask_to_columns_kernel: [n][H][W] bytes -> column-major [n][W][Hp] (Hp = H rounded up to 16, the pad rows
+//      repeat the column's last pixel), i.e. pycocotools' Fortran scan order as contiguous 16-byte chunks;
+//   2. dense_rle_kernel, one workgroup per mask: every thread owns a contiguous range of 16-row chunks, counts
+//      value changes against the preceding pixel (the pad makes "previous pixel of row 0" the last row of the
+//      previous column), block scan, writes the positions x*H + y in order, then the shared string emitter.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_to_columns_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               int H, int W, int Hp) {
+    __shared__ uint8_t tile[64][65];
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const uint8_t* src = in + (size_t)n * H * W;
+    uint8_t* dst = out + (size_t)n * W * Hp;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int y = min(y0 + r, H - 1), x = x0 + tx;          // rows past H repeat row H-1 (the pad)
+        tile[r][tx] = (x < W) ? (src[(size_t)y * W + x] != 0) : 0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int x = x0 + c, y = y0 + tx;
+        if (x < W && y < Hp) dst[(size_t)x * Hp + y] = tile[tx][c];
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void dense_rle_kernel(const uint8_t* __restrict__ cols, uint32_t* __restrict__ trans,
+                                                                uint8_t* __restrict__ out_bytes,
+                                                                int32_t* __restrict__ out_len,
+                                                                int32_t* __restrict__ overflow, int H, int W, int Hp,
+                                                                int trans_cap, int byte_cap) {
+    __shared__ int wave_sums[RLE_THREADS / 64];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const uint8_t* m = cols + (size_t)d * W * Hp;
+    const int cpc = Hp / 16;                                   // chunks per column
+    const int n_chunks = W * cpc;
+    const int per = (n_chunks + RLE_THREADS - 1) / RLE_THREADS;
+    const int c_lo = min(t * per, n_chunks), c_hi = min(c_lo + per, n_chunks);
+    // change bits of chunk c: bit r set iff pixel (x, 16*k + r) differs from its predecessor in scan order
+    auto chunk_bits = [&](int c, int& prev) -> unsigned {
+        const uint4 v = *reinterpret_cast<const uint4*>(m + (size_t)c * 16);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = (w[r >> 2] >> (8 * (r & 3))) & 1;
+            bits |= (unsigned)(b != prev) << r;
+            prev = b;
+        }
+        const int k = c % cpc;
+        const int valid = min(16, H - 16 * k);                  // pad rows never differ, but mask them anyway
+        return valid >= 16 ? bits : (bits & ((1u << valid) - 1u));
+    };
+    int prev0 = 0;
+    if (c_lo > 0 && c_lo < n_chunks) prev0 = m[(size_t)c_lo * 16 - 1] & 1;
+    int cnt = 0;
+    {
+        int prev = prev0;
+        for (int c = c_lo; c < c_hi; ++c) cnt += __popc(chunk_bits(c, prev));
+    }
+    int T;
+    int o = block_exclusive_scan(cnt, wave_sums, &T);
+    if (T > trans_cap) {
+        if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
+        return;
+    }
+    uint32_t* tr = trans + (size_t)d * trans_cap;
+    {
+        int prev = prev0;
+        for (int c = c_lo; c < c_hi; ++c) {
+            unsigned bits = chunk_bits(c, prev);
+            const int x = c / cpc, k = c - x * cpc;
+            while (bits) {
+                const int r = __ffs(bits) - 1;
+                bits &= bits - 1;
+                tr[o++] = (uint32_t)x * (uint32_t)H + (uint32_t)(16 * k + r);
+            }
+        }
+    }
+    __syncthreads();
+    emit_coco_string(tr, T, (long long)H * W, out_bytes + (size_t)d * byte_cap, byte_cap, out_len + d, overflow + d,
+                     wave_sums);
+}
+
+extern "C" size_t fgn_dense_rle_scratch_bytes(int n_masks, int img_h, int img_w, int trans_cap) {
+    const size_t hp = (size_t)(img_h + 15) / 16 * 16;
+    return (size_t)n_masks * img_w * hp + (size_t)n_masks * trans_cap * sizeof(uint32_t) + 256;
+}
+
+extern "C" int fgn_dense_mask_rle(const uint8_t* masks, void* scratch, size_t scratch_bytes, uint8_t* out_bytes,
+                                  int32_t* out_len, int32_t* overflow, int n_masks, int img_h, int img_w, int trans_cap,
+                                  int byte_cap, hipStream_t stream) {
+    if (!masks || !scratch || !out_bytes || !out_len || !overflow) return FGN_ERR_ARG;
+    if (n_masks == 0) return FGN_OK;
+    if (img_h < 1 || img_w < 1 || trans_cap < 1 || byte_cap < 8 || (long long)img_h * img_w >= (1ll << 32) ||
+        n_masks > 65535)
+        return FGN_ERR_SHAPE;
+    if (scratch_bytes < fgn_dense_rle_scratch_bytes(n_masks, img_h, img_w, trans_cap)) return FGN_ERR_ARG;
+    const int hp = (img_h + 15) / 16 * 16;
+    uint8_t* cols = reinterpret_cast<uint8_t*>(scratch);
+    const size_t cols_bytes = ((size_t)n_masks * img_w * hp + 255) / 256 * 256;
+    uint32_t* trans = reinterpret_cast<uint32_t*>(cols + cols_bytes);
+    hipLaunchKernelGGL(mask_to_columns_kernel, dim3(cdiv(img_w, 64), cdiv(hp, 64), n_masks), dim3(256), 0, stream, masks,
+                       cols, img_h, img_w, hp);
+    FGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_rle_kernel, dim3(n_masks), dim3(RLE_THREADS), 0, stream, cols, trans, out_bytes, out_len,
+                       overflow, img_h, img_w, hp, trans_cap, byte_cap);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
     const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ rois,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ fcw,
     const float* __restrict__ fcb, float* __restrict__ cls_out, float* __restrict__ reg_out,
-    const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, float eps) {
+    const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, float eps, float* __restrict__ rel_out) {
     constexpr int P = 49;
     __shared__ float fc_acc[REL_WAVES][REL_MAX_N][6];
     const int r = blockIdx.x;
@@ -89,10 +89,13 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
             for (int i = 0; i < 7; ++i) {
                 const int p = slot + 8 * i;
                 if (p < P) {
-                    pool.x += fmaxf((x[i].x - mean) * rstd * ga.x + be.x, 0.f);
-                    pool.y += fmaxf((x[i].y - mean) * rstd * ga.y + be.y, 0.f);
-                    pool.z += fmaxf((x[i].z - mean) * rstd * ga.z + be.z, 0.f);
-                    pool.w += fmaxf((x[i].w - mean) * rstd * ga.w + be.w, 0.f);
+                    const float4 y = make_float4(fmaxf((x[i].x - mean) * rstd * ga.x + be.x, 0.f),
+                                                 fmaxf((x[i].y - mean) * rstd * ga.y + be.y, 0.f),
+                                                 fmaxf((x[i].z - mean) * rstd * ga.z + be.z, 0.f),
+                                                 fmaxf((x[i].w - mean) * rstd * ga.w + be.w, 0.f));
+                    pool.x += y.x; pool.y += y.y; pool.z += y.z; pool.w += y.w;
+                    // parity tests only: the relation feature map the reference materialises (fgn_roi_head.py:274)
+                    if (rel_out) *reinterpret_cast<float4*>(rel_out + (((size_t)r * n_ways + n) * P + p) * C + c) = y;
                 }
             }
             // reduce over the 8 pixel slots (lanes differing in bits 3..5), then over quads
@@ -137,14 +140,14 @@ extern "C" int fgn_relation_gn_head_f32(const float* Q, const float* S, const fl
                                         const float* gn_bias, const float* fc_weight, const float* fc_bias,
                                         float* cls_out, float* reg_out, const int32_t* n_rois_dev, int n_rois,
                                         int n_ways, int C, int gn_groups, int roi_size, float eps,
-                                        hipStream_t stream) {
+                                        float* rel_out_debug, hipStream_t stream) {
     if (!Q || !S || !rois || !gn_weight || !gn_bias || !fc_weight || !fc_bias || !cls_out || !reg_out)
         return FGN_ERR_ARG;
     if (roi_size != 7 || gn_groups <= 0 || C != gn_groups * 32 || n_ways < 1 || n_ways > REL_MAX_N)
         return FGN_ERR_SHAPE;
     if (n_rois == 0) return FGN_OK;
     hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois), dim3(64 * REL_WAVES), 0, stream, Q, S, rois, gn_weight, gn_bias,
-                       fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, eps);
+                       fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, eps, rel_out_debug);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

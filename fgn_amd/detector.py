@@ -196,11 +196,11 @@ class _GraphedEpisode:
         args = lambda: (self.static['qry_img'], self.static.get('spp_imgs'), self.static.get('spp_bboxes'),
                         self.static.get('spp_isegmaps'), self.img_shape, self.code)
         # eager pass first: packs the weights, sets kernel attributes, sizes the allocator pools
-        model._detect_eager(*args(), download=False)
+        model._detect_eager(*args())
         torch.cuda.current_stream().synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.outs = model._detect_eager(*args(), download=False)
+            self.outs = model._detect_eager(*args())
 
     def run(self, model, ins: dict, support_code, main) -> list:
         for k, v in ins.items():
@@ -217,9 +217,7 @@ class _GraphedEpisode:
             d = dict(d)
             d['mask_prob'], d['det_bboxes_copy'] = d['mask_prob'].clone(), d['det_bboxes'].clone()
             outs.append(d)
-        model._start_download(outs, main)
-        self.last_download = outs[0]['host_ready']
-        return outs
+        return outs          # detect_device queues the download and sets ``last_download``
 
 
 class FGN(torch.nn.Module):
@@ -247,10 +245,8 @@ class FGN(torch.nn.Module):
         self._use_winograd = True                 # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
         self.use_roi_commute = True               # shared_head conv1 on the feature map, RoIAlign after (set before first use)
         self._graphs: dict = {}
-        self._side_stream = None
-        self._copy_stream = None
-        self._pinned_ring: list = []
-        self._pinned_next = 0
+        self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
+        self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
 
     @property
     def use_winograd(self) -> bool:
@@ -429,6 +425,21 @@ class FGN(torch.nn.Module):
                                post_shift=P['sh0_shift'], relu=True)
         return x, self._shared_head(x, n_dev, y1=y1)
 
+    def _mask_head(self, mf, vmask, n_dev=None):
+        """``_mask_forward`` after the shared_head (fgn_roi_head.py:379-380): support-vector guidance, FCNMaskHead
+        (4 x conv3x3+ReLU, ConvTranspose 2x2/2 + ReLU as one 1x1 conv with 4*C' outputs, 1x1 logits), sigmoid.
+        mf [D,7,7,C], vmask [D,C] -> logits, probabilities [D,14,14]."""
+        P = self._P
+        m = mf
+        for li, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
+            scale = vmask if li == 0 else None         # support-vector guidance (fgn_roi_head.py:379) fused into conv 0
+            if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout):
+                m = ops.conv3x3_winograd(m, wg, in_scale=scale, n_img_dev=n_dev)
+            else:
+                m = ops.conv2d(m, layer, in_scale=scale, n_img_dev=n_dev)
+        up = ops.conv2d(m, P['upsample'], n_img_dev=n_dev)                         # [D,7,7,4*C']
+        return ops.mask_logits(up, P['logit_w'], P['logit_b'], self.cfg['roi_head']['roi_out_size'], n_dev)
+
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(**kwargs)
@@ -445,7 +456,8 @@ class FGN(torch.nn.Module):
                     support_code=None, **kwargs) -> List[Dict]:
         """Test without augmentation (fgn.py:187-303).  ``support_code`` (optional, from
         ``encode_supports``) replaces the three ``spp_*`` inputs."""
-        dets = self.detect_device(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
+        dets = self.detect_device(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code,
+                                  qry_isegmaps=qry_isegmaps)
         return self.pack_results(dets, qry_img.shape[0], qry_bboxes=qry_bboxes, qry_cat_ids=qry_cat_ids,
                                  qry_isegmaps=qry_isegmaps, img_shape=img_shape, qry_child_idx=qry_child_idx,
                                  cats_ids_to_sample_real=cats_ids_to_sample_real, spp_insts_ids=spp_insts_ids,
@@ -457,9 +469,10 @@ class FGN(torch.nn.Module):
         backbone pass and the AG-RPN class vectors."""
         N, K = self.n_ways, self.k_shots
         spp = spp_imgs.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, *spp_imgs.shape[-3:])
-        b = spp_bboxes.to(dev, torch.float32).reshape(B * N * K, 4)
+        b = spp_bboxes.to(dev, torch.float32, non_blocking=True).reshape(B * N * K, 4)
         spp_xyxy = torch.stack((b[:, 1], b[:, 0], b[:, 3], b[:, 2]), 1)      # no host-built index tensor: graph-capturable
-        spp_masks = spp_isegmaps.to(dev).reshape(B * N * K, *spp_isegmaps.shape[-2:]).to(torch.uint8).contiguous()
+        m = spp_isegmaps.to(dev, non_blocking=True).reshape(B * N * K, *spp_isegmaps.shape[-2:])
+        spp_masks = (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
         spp_fmaps = self.extract_feat(spp)                                      # [B*N*K,s,s,C]
         vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
         return dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp_fmaps=spp_fmaps, vec=vec)
@@ -496,39 +509,98 @@ class FGN(torch.nn.Module):
         self._support_back(sc, B, dev)
         return sc
 
+    def _stream_for(self, role: str, main) -> 'torch.cuda.Stream':
+        """One auxiliary HIP stream per (role, caller stream)."""
+        key = (role, main.cuda_stream)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = torch.cuda.Stream()
+        return st
+
+    def _upload(self, tensors: dict, gt_masks, dev, main):
+        """``modify_input`` (fgn.py:79-108): host -> device copies of one batch, on an upload stream so that they
+        overlap the previous batch's kernels (a pinned source makes them asynchronous); the compute streams wait
+        on one event.  Tensors already on the device pass through.  The ground-truth masks (copied to the GPU by
+        the reference too, fgn.py:95) are run-length encoded right there (``qry_isegmaps_rle``, fgn.py:298): two
+        small kernels on the upload stream instead of ~4 ms of host work per 800x1333 episode."""
+        gts = None
+        if gt_masks is not None:
+            gts = [g if isinstance(g, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(g)) for g in gt_masks]
+        on_host = [t for t in list(tensors.values()) + (gts or []) if t is not None and not t.is_cuda]
+        if not on_host and gts is None:
+            return tensors, None, None
+        up = self._stream_for('upload', main)
+        if not on_host:
+            up.wait_stream(main)               # device-resident inputs may still be being produced on the caller's stream
+        out, gt_out = {}, None
+        with torch.cuda.stream(up):
+            for k, t in tensors.items():
+                out[k] = None if t is None else t.to(dev, non_blocking=True)
+            if gts is not None:
+                gt_out = []
+                for g in gts:
+                    g = g.to(dev, non_blocking=True)
+                    g = g if g.dtype in (torch.bool, torch.uint8) else (g != 0)
+                    gt_out.append(ops.dense_mask_rle(g.contiguous()))
+            ready = up.record_event()
+        for t in out.values():
+            if t is not None:
+                t.record_stream(main)
+        return out, gt_out, ready
+
     @torch.no_grad()
-    def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None) -> list:
-        """Everything up to the host wait: queues the whole path and the device->host copies of the
-        results.  Returns, per image, a dict of device tensors (det_bboxes [D,5], det_labels [D],
+    def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None,
+                      qry_isegmaps=None) -> list:
+        """Everything up to the host wait: queues the host->device copies, the whole path and the device->host
+        copies of the results.  Returns, per image, a dict of device tensors (det_bboxes [D,5], det_labels [D],
         n_dets [1], mask_prob, RLE bytes) plus the pinned host slot ``pack_results`` reads.
-        With ``support_code`` (from ``encode_supports``) the support branch is skipped.  With
-        ``use_graphs`` the launch sequence of one input geometry is captured once into a hipGraph
-        and replayed (same kernels, same results; ~0.2 ms of host time instead of ~10 ms)."""
+        With ``support_code`` (from ``encode_supports``) the support branch is skipped.  ``qry_isegmaps`` (list of
+        [n_i,H,W] bool): the ground-truth masks, RLE-encoded on the device for ``qry_isegmaps_rle``.  With
+        ``use_graphs`` the launch sequence of one input geometry is captured once into a hipGraph and replayed
+        (same kernels, same results; ~0.2 ms of host time instead of ~2 ms)."""
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('FGN.simple_test needs a GPU: the HIP path has no CPU fallback')
-        if self.use_graphs and self.debug_trace is None and ops.PROFILE is None:
-            return self._detect_graphed(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
-        return self._detect_eager(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code)
-
-    def _detect_graphed(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code) -> list:
-        main = torch.cuda.current_stream()
         dev = torch.device('cuda', torch.cuda.current_device())
+        main = torch.cuda.current_stream()
         ins = {'qry_img': qry_img}
         if support_code is None:
             ins.update(spp_imgs=spp_imgs, spp_bboxes=spp_bboxes, spp_isegmaps=spp_isegmaps)
+        ins, gt_rle, uploaded = self._upload(ins, qry_isegmaps, dev, main)
+        if uploaded is not None:
+            main.wait_event(uploaded)
+        graphed = self.use_graphs and self.debug_trace is None and ops.PROFILE is None
+        if graphed:
+            ge, outs = self._detect_graphed(ins, img_shape, support_code)
+        else:
+            outs = self._detect_eager(ins['qry_img'], ins.get('spp_imgs'), ins.get('spp_bboxes'),
+                                      ins.get('spp_isegmaps'), img_shape, support_code)
+        if gt_rle is not None:
+            for d, g in zip(outs, gt_rle):
+                d['gt_rle'] = g
+        self._start_download(outs, main, uploaded if gt_rle is not None else None)
+        if graphed:
+            ge.last_download = outs[0]['host_ready']
+        return outs
+
+    def _detect_graphed(self, ins: dict, img_shape, support_code):
+        main = torch.cuda.current_stream()
+        dev = torch.device('cuda', torch.cuda.current_device())
         hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
         key = (main.cuda_stream, dev.index, hw, support_code is not None) + \
             tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
         ge = self._graphs.get(key)
         if ge is None:
             ge = self._graphs[key] = _GraphedEpisode(self, ins, img_shape, support_code, dev)
-        return ge.run(self, ins, support_code, main)
+        return ge, ge.run(self, ins, support_code, main)
 
-    def _detect_eager(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None,
-                      download=True) -> list:
+    def _detect_eager(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None) -> list:
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._packed_device != dev:
             self._pack(dev)
+        with ops.arena(dev):     # zero-initialised small outputs of this episode: one fill (caller's stream only)
+            return self._detect_body(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev)
+
+    def _detect_body(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev) -> list:
         P, cfg = self._P, self.cfg
         N, K = self.n_ways, self.k_shots
         tr = self.debug_trace
@@ -538,7 +610,6 @@ class FGN(torch.nn.Module):
         inv_stride = 1.0 / rh['featmap_stride']
 
         qry = qry_img.to(dev, torch.float32, non_blocking=True)
-        ops.begin_arena(dev)          # zero-initialised small outputs of this episode: one fill (caller's stream only)
 
         # Two HIP streams: the support branch (9 small crops: low-occupancy launches) runs beside
         # the query branch, and its RoI/shared-head/reduction tail runs beside the single-workgroup
@@ -550,11 +621,7 @@ class FGN(torch.nn.Module):
                 raise ValueError('support_code was encoded for another batch size or device')
             side = main
         elif self.use_side_stream:
-            if self._side_stream is None:
-                self._side_stream = {}
-            side = self._side_stream.get(main.cuda_stream)     # one side stream per caller stream
-            if side is None:
-                side = self._side_stream[main.cuda_stream] = torch.cuda.Stream()
+            side = self._stream_for('side', main)              # one side stream per caller stream
         else:
             side = main
         if cached:
@@ -575,8 +642,8 @@ class FGN(torch.nn.Module):
         if not cached:
             main.wait_event(vec_ready)
         rpn_start = main.record_event()
-        # guidance multiply (fgn_ag_rpn_head.py:44): materialised once (51 MB at cfg3, ~20 us) so the
-        # 238 GFLOP conv behind it runs on the stream-K LDS-DMA kernel
+        # guidance multiply (fgn_ag_rpn_head.py:44): never materialised - it rides in the Winograd input transform,
+        # or in the A-operand staging of the direct kernel where the layer is too small for the Winograd form
         if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout):
             # Winograd F(2x2,3x3); the guidance multiply rides in its input transform
             x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
@@ -650,15 +717,7 @@ class FGN(torch.nn.Module):
         mrois_all = self._rois_of(det_all[:, :4].reshape(B, D, 4), B, dev)         # [B*D,5]
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
         _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
-        m = mf
-        for li, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
-            scale = vmask if li == 0 else None         # support-vector guidance (fgn_roi_head.py:379) fused into conv 0
-            if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout):
-                m = ops.conv3x3_winograd(m, wg, in_scale=scale, n_img_dev=nd_all)
-            else:
-                m = ops.conv2d(m, layer, in_scale=scale, n_img_dev=nd_all)
-        up = ops.conv2d(m, P['upsample'], n_img_dev=nd_all)                        # [B*D,7,7,4*C']
-        mlog, mprob = ops.mask_logits(up, P['logit_w'], P['logit_b'], PS, nd_all)
+        mlog, mprob = self._mask_head(mf, vmask, nd_all)
         outs = []
         for i in range(B):
             det, lab, n_det = dets[i], labs[i], n_dets[i]
@@ -674,43 +733,56 @@ class FGN(torch.nn.Module):
                     masks=masks, mask_feats=mf[i * D:(i + 1) * D]))
             outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mp_i, rle_bytes=rle_bytes,
                              rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
-        ops.end_arena()
-        if download:
-            self._start_download(outs, main)
         return outs
 
-    def _pinned_slot(self, batch: int, max_det: int) -> dict:
-        """Ring of pinned host buffers (pinned allocation is slow; 4 slots cover a pipeline of
-        several episodes in flight)."""
+    MAX_SLOTS = 64
+
+    def _pinned_slot(self, batch: int, max_det: int, n_gt: int) -> dict:
+        """A free pinned host slot for one batch's results (pinned allocation is slow, so slots are kept per
+        (batch, max_det) and reused).  A slot is busy from ``detect_device`` until ``pack_results`` has read it;
+        when every slot is busy (more batches in flight than ever before) another one is allocated."""
         key = (batch, max_det, ops.RLE_BYTE_CAP)
-        if not self._pinned_ring or self._pinned_ring[0]['key'] != key:
-            pin = lambda *shape, dtype: torch.empty(shape, dtype=dtype, pin_memory=True)
-            self._pinned_ring = [dict(key=key,
-                                      det=pin(batch, max_det, 5, dtype=torch.float32),
-                                      lab=pin(batch, max_det, dtype=torch.int64),
-                                      cnt=pin(batch, 1, dtype=torch.int32),
-                                      rle_len=pin(batch, max_det, dtype=torch.int32),
-                                      rle_ovf=pin(batch, max_det, dtype=torch.int32),
-                                      rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
-                                 for _ in range(6)]
-            self._pinned_next = 0
-        slot = self._pinned_ring[self._pinned_next % len(self._pinned_ring)]
-        self._pinned_next += 1
+        ring = self._pinned.setdefault(key, [])
+        slot = next((s for s in ring if not s['busy']), None)
+        pin = lambda *shape, dtype: torch.empty(shape, dtype=dtype, pin_memory=True)
+        if slot is None:
+            if len(ring) >= self.MAX_SLOTS:
+                raise ops._lib.FgnHipError(f'{self.MAX_SLOTS} batches are in flight without pack_results(); '
+                                           'pack (or drop and call release_results on) earlier detect_device outputs')
+            slot = dict(key=key, busy=False, gt_cap=0,
+                        det=pin(batch, max_det, 5, dtype=torch.float32),
+                        lab=pin(batch, max_det, dtype=torch.int64),
+                        cnt=pin(batch, 1, dtype=torch.int32),
+                        rle_len=pin(batch, max_det, dtype=torch.int32),
+                        rle_ovf=pin(batch, max_det, dtype=torch.int32),
+                        rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
+            ring.append(slot)
+        if n_gt > slot['gt_cap']:
+            cap = max(8, 2 * n_gt)
+            slot.update(gt_cap=cap, gt_rle=pin(cap, ops.RLE_BYTE_CAP, dtype=torch.uint8),
+                        gt_len=pin(cap, dtype=torch.int32), gt_ovf=pin(cap, dtype=torch.int32))
+        slot['busy'] = True
         return slot
 
-    def _start_download(self, outs: list, main) -> None:
+    @staticmethod
+    def release_results(dets: list) -> None:
+        """Give back the pinned host slot of ``detect_device`` outputs that will not be packed."""
+        if dets and 'host' in dets[0]:
+            dets[0]['host']['busy'] = False
+
+    def _start_download(self, outs: list, main, also_wait=None) -> None:
         """Queue the device->host copies of one batch on a copy stream behind the compute work;
         ``pack_results`` later waits on the event only, so the next batch's kernels are not
         serialised behind a host round trip."""
-        if self._copy_stream is None:
-            self._copy_stream = {}
-        cp = self._copy_stream.get(main.cuda_stream)
-        if cp is None:
-            cp = self._copy_stream[main.cuda_stream] = torch.cuda.Stream()
+        cp = self._stream_for('copy', main)
         max_det = outs[0]['det_bboxes'].shape[0]
-        slot = self._pinned_slot(len(outs), max_det)
+        n_gt = sum(d['gt_rle'][1].shape[0] for d in outs if 'gt_rle' in d)
+        slot = self._pinned_slot(len(outs), max_det, n_gt)
         cp.wait_stream(main)
+        if also_wait is not None:
+            cp.wait_event(also_wait)           # the ground-truth RLE kernels run on the upload stream
         with torch.cuda.stream(cp):
+            g0 = 0
             for i, d in enumerate(outs):
                 slot['det'][i].copy_(d['det_bboxes'], non_blocking=True)
                 slot['lab'][i].copy_(d['det_labels'], non_blocking=True)
@@ -720,6 +792,17 @@ class FGN(torch.nn.Module):
                 slot['rle'][i].copy_(d['rle_bytes'], non_blocking=True)
                 for k in ('det_bboxes', 'det_labels', 'n_dets', 'rle_len', 'rle_overflow', 'rle_bytes'):
                     d[k].record_stream(cp)
+                if 'gt_rle' in d:
+                    gb, gl, go = d['gt_rle']
+                    n = gl.shape[0]
+                    if n:
+                        slot['gt_rle'][g0:g0 + n].copy_(gb, non_blocking=True)
+                        slot['gt_len'][g0:g0 + n].copy_(gl, non_blocking=True)
+                        slot['gt_ovf'][g0:g0 + n].copy_(go, non_blocking=True)
+                        for t in (gb, gl, go):
+                            t.record_stream(cp)
+                    d['gt_slice'] = (g0, n)
+                    g0 += n
             ev = cp.record_event()
         for d in outs:
             d['host'] = slot
@@ -760,8 +843,17 @@ class FGN(torch.nn.Module):
                 v = val[i] if val is not None else None
                 one[key] = v.cpu().numpy() if isinstance(v, torch.Tensor) else v
             gt = qry_isegmaps[i] if qry_isegmaps is not None else None
-            if gt is not None:
+            if 'gt_slice' in di:                   # ground-truth masks were encoded on the device (detect_device)
+                g0, ng = di['gt_slice']
+                glen, govf = host['gt_len'][g0:g0 + ng].numpy(), host['gt_ovf'][g0:g0 + ng].numpy()
+                gstr = host['gt_rle'][g0:g0 + ng].numpy()
+                one['qry_isegmaps_rle'] = [
+                    {'size': [ih, iw], 'counts': gstr[j, :glen[j]].tobytes()} if not govf[j] else
+                    rle.encode(np.asarray(gt[j].cpu() if isinstance(gt[j], torch.Tensor) else gt[j]))
+                    for j in range(ng)]
+            elif gt is not None:
                 gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
                 one['qry_isegmaps_rle'] = rle.encode_many(gt)
             results.append(one)
+        host['busy'] = False
         return results

@@ -66,7 +66,7 @@ def _xywh(yxyx: np.ndarray) -> np.ndarray:
 
 class FSISEGEval:
     def __init__(self, results: Iterable[Dict] = None, results_pkl_dir_fp: str = None, n_ways: int = 3,
-                 iou_type: str = 'segm'):
+                 iou_type: str = 'segm', iou_thr: float = 0.5):
         if results is None:
             results = []
             for f in sorted(os.listdir(results_pkl_dir_fp)):
@@ -75,7 +75,7 @@ class FSISEGEval:
         self.results = list(results)
         self.n_ways = n_ways
         self.iou_type = iou_type
-        self.iou_thr = 0.5
+        self.iou_thr = iou_thr          # the reference evaluates at 0.5 only (fsisegeval.py:108-116)
         self.rec_thrs = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .10)) + 1, endpoint=True)
         self.max_dets = 100
         self.eval = {}
@@ -158,11 +158,24 @@ class FSISEGEval:
         return self.summarize_short()
 
 
-def evaluate_results(results: List[Dict], n_ways: int) -> Dict[str, float]:
-    """bbox and segm mAP50/mAR of a list of ``simple_test`` result dicts."""
+def evaluate_results(results: List[Dict], n_ways: int, iou_thr: float = 0.5) -> Dict[str, float]:
+    """bbox and segm mAP/mAR of a list of ``simple_test`` result dicts at one IoU threshold (keys are named
+    ``*_mAP50`` at the reference's threshold 0.5, ``*_mAP<thr*100>`` otherwise)."""
     out = {}
+    tag = f'mAP{int(round(iou_thr * 100))}'
     for kind in ('bbox', 'segm'):
-        r = FSISEGEval(results=results, n_ways=n_ways, iou_type=kind).run()
-        out[f'{kind}_mAP50'] = r['mAP']
+        r = FSISEGEval(results=results, n_ways=n_ways, iou_type=kind, iou_thr=iou_thr).run()
+        out[f'{kind}_{tag}'] = r['mAP']
         out[f'{kind}_mAR'] = r['mAR']
+    return out
+
+
+def as_ground_truth(reference: List[Dict], scored: List[Dict]) -> List[Dict]:
+    """Result dicts of ``scored`` with the detections of ``reference`` installed as ground truth: AP of one
+    implementation's detections against another's (1.0 = every detection reproduced at the IoU threshold)."""
+    out = []
+    for c, h in zip(reference, scored):
+        r = dict(h)
+        r['qry_bboxes'], r['qry_cat_ids'], r['qry_isegmaps_rle'] = c['dt_bboxes'], c['dt_cat_ids'], c['dt_isegmaps_rle']
+        out.append(r)
     return out

@@ -19,6 +19,7 @@ _f = C.c_float
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
+    'fgn_conv2d_kernel_id': (_i, [_i] * 14),
     'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_t_pad': (_i, [_i]),
@@ -35,7 +36,7 @@ SIGNATURES = {
     'fgn_scale_channels_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_support_kmean_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_gather_support_vectors_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p]),
+    'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p, _p]),
     'fgn_rpn_merge_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'fgn_rpn_proposals_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
     'fgn_rpn_proposals_f32': (_i, [_p] * 7 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
@@ -45,9 +46,11 @@ SIGNATURES = {
     'fgn_mask_logits_f32': (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
     'fgn_mask_paste_u8': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
+    'fgn_dense_rle_scratch_bytes': (C.c_size_t, [_i, _i, _i, _i]),
+    'fgn_dense_mask_rle': (_i, [_p, _p, C.c_size_t, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -18,16 +18,30 @@ import torch
 from . import lib as _lib
 
 
-# When set to a list, conv2d appends (start_event, end_event, flop_per_image, n_img,
-# n_img_dev) per launch: live HIP-event timing of the dominant kernel (bench.py roofline).
-PROFILE = None          # a list (or ConvProfile): conv2d appends (e0, e1, flop_per_img, n_img, n_img_dev, shape)
+# Live HIP-event timing of the convolution launches (bench.py roofline): when set to a ConvProfile, every conv
+# launch appends a record dict(kind, kernel, e0, e1, flop_direct, flop_issued, n_img, n_img_dev, shape):
+#   kind        'conv' (one fgn_conv2d launch, incl. its split-K reduce), 'wg_in' / 'wg_gemm' / 'wg_out' (the three
+#               kernels of a Winograd layer, bracketed separately)
+#   kernel      name of the device kernel as rocprofv3 reports it (from fgn_conv2d_kernel_id)
+#   flop_*      per image: direct-convolution FLOPs of the layer / MFMA FLOPs actually issued (0 for the transforms)
+PROFILE = None
+
+_TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
+
+
+def kernel_name(kid: int) -> str:
+    """fgn_conv2d_kernel_id -> the kernel name in a rocprofv3 kernel trace."""
+    bm, bn, wm, wn, mw = _TILES[kid // 10]
+    mode = kid % 10
+    if mode == 3:
+        return f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, *, {mw}>'
+    return f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, 2, {mw}, {mode}>'
 
 
 class ZeroArena:
     """One zero-filled allocation per episode from which the small zero-initialised outputs of the selection
     / head kernels are carved (counters, logits of RoIs beyond the device count, ...): one fill kernel
-    instead of about ten 5 us ones on the critical path.  Module-level state: one episode at a time is being
-    queued per process (the detector is single-caller, as the reference's is, fgn_roi_head.py:439-447)."""
+    instead of about ten 5 us ones on the critical path.  Opened with ``ops.arena``."""
 
     def __init__(self, device, nbytes: int = 2 << 20):
         self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
@@ -45,14 +59,25 @@ class ZeroArena:
 _ARENA: Optional[ZeroArena] = None
 
 
-def begin_arena(device) -> None:
-    global _ARENA
-    _ARENA = ZeroArena(device)
+class arena:
+    """``with ops.arena(device):`` - the zero arena of one episode; closed on every exit path, so an error raised
+    mid-episode cannot leave a stale arena (allocated on another stream) for later ``ops.zeros`` callers.  Arenas do
+    not nest and belong to one caller thread (the detector is single-caller, as the reference's is)."""
 
+    def __init__(self, device):
+        self.device = device
 
-def end_arena() -> None:
-    global _ARENA
-    _ARENA = None
+    def __enter__(self):
+        global _ARENA
+        if _ARENA is not None:
+            raise _lib.FgnHipError('ops.arena: an episode is already being queued in this process')
+        _ARENA = ZeroArena(self.device)
+        return _ARENA
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = None
+        return False
 
 
 def zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
@@ -74,15 +99,15 @@ class ConvProfile(list):
         super().__init__()
         self.pool = []
 
-    def reserve(self, n_pairs: int):
-        self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * n_pairs))
+    def reserve(self, n_events: int):
+        self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n_events))
         return self
 
-    def pair(self):
-        if len(self.pool) >= 2:
-            return self.pool.pop(), self.pool.pop()
-        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
+    def event(self):
+        """A timing event recorded on the current stream."""
+        e = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
 
 def _stream() -> int:
@@ -201,11 +226,9 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     if n_img_dev is not None:
         _chk(n_img_dev, 'n_img_dev', torch.int32)
     prof = PROFILE
-    if prof is not None:
-        e0, e1 = prof.pair() if isinstance(prof, ConvProfile) else \
-            (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        e0.record()
     L = _lib.load()
+    if prof is not None:
+        e0 = prof.event()
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
                                             layer.pad, tile_hint)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
@@ -215,9 +238,13 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
         layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
-        e1.record()
-        prof.append((e0, e1, 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * cin, n_img, n_img_dev,
-                     (n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
+        kid = L.fgn_conv2d_kernel_id(n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw, layer.stride,
+                                     layer.pad, a_img_div, int(in_scale is not None), int(residual is not None),
+                                     tile_hint)
+        flop = 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * (3 if cin == 4 else cin)
+        prof.append(dict(kind='conv', kernel=kernel_name(kid), e0=e0, e1=prof.event(), flop_direct=flop,
+                         flop_issued=flop, n_img=n_img, n_img_dev=n_img_dev,
+                         shape=(n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
     return out
 
 
@@ -303,24 +330,32 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     Mo = torch.empty((16, t_pad, layer.cout), device=x.device, dtype=torch.float32)
     y = torch.empty((n_img, H, W, layer.cout), device=x.device, dtype=torch.float32)
     prof = PROFILE
-    if prof is not None:
-        e0, e1 = prof.pair() if isinstance(prof, ConvProfile) else \
-            (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        e0.record()
     st = _stream()
+    ev = [prof.event()] if prof is not None else None
     _lib.check(L.fgn_winograd_input_f32(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W,
                                         cin, t_pad, st), 'fgn_winograd_input_f32')
+    if ev is not None:
+        ev.append(prof.event())
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
                                        layer.cout, layer.cout_pad, st), 'fgn_winograd_gemm_f32')
+    if ev is not None:
+        ev.append(prof.event())
     _lib.check(L.fgn_winograd_output_f32(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W,
                                          layer.cout, t_pad, int(layer.relu), st), 'fgn_winograd_output_f32')
-    if prof is not None:
-        e1.record()
-        # direct-convolution FLOPs of the layer (what the reference's formulation executes); the MFMA work
-        # actually issued is 16 products per 2x2-output tile instead of 36: 16/36 of it on even maps, 0.58 on
-        # the 7x7 RoI maps (16 tiles cover 8x8)
-        prof.append((e0, e1, 2.0 * H * W * layer.cout * 9 * cin, n_img, n_img_dev, (n_img, H, W, cin, layer.cout, 3, 1),
-                     16.0 * tiles / (9.0 * H * W)))
+    if ev is not None:
+        ev.append(prof.event())
+        # direct-convolution FLOPs of the layer (what the reference's formulation executes) are booked on the GEMM
+        # record; the MFMA work actually issued is 16 products per 2x2-output tile instead of 36: 16/36 of it on
+        # even maps, 0.58 on the 7x7 RoI maps (16 tiles cover 8x8)
+        shape = (n_img, H, W, cin, layer.cout, 3, 1)
+        common = dict(n_img=n_img, n_img_dev=n_img_dev, shape=shape)
+        prof.append(dict(kind='wg_in', kernel='wg_input_kernel', e0=ev[0], e1=ev[1], flop_direct=0.0, flop_issued=0.0,
+                         **common))
+        prof.append(dict(kind='wg_gemm', kernel=kernel_name(41), e0=ev[1], e1=ev[2],
+                         flop_direct=2.0 * H * W * layer.cout * 9 * cin,
+                         flop_issued=2.0 * 16 * tiles * layer.cout * cin, **common))
+        prof.append(dict(kind='wg_out', kernel='wg_output_kernel', e0=ev[2], e1=ev[3], flop_direct=0.0,
+                         flop_issued=0.0, **common))
     return y
 
 
@@ -477,18 +512,24 @@ def gather_support_vectors(table: torch.Tensor, labels: torch.Tensor, rois: Opti
 
 
 def relation_gn_head(q: torch.Tensor, s: torch.Tensor, rois: torch.Tensor, gn_w, gn_b, fc_w, fc_b,
-                     n_ways: int, gn_groups: int, eps: float, n_rois_dev: Optional[torch.Tensor] = None):
-    """q [R,7,7,C]; s [B*N,7,7,C]; rois [R,5] -> cls_raw [R*N,2], reg_raw [R*N,4]."""
+                     n_ways: int, gn_groups: int, eps: float, n_rois_dev: Optional[torch.Tensor] = None,
+                     rel_out: Optional[torch.Tensor] = None):
+    """q [R,7,7,C]; s [B*N,7,7,C]; rois [R,5] -> cls_raw [R*N,2], reg_raw [R*N,4].  ``rel_out`` (parity tests):
+    [R*N,7,7,C] receives the relation feature map the reference materialises (fgn_roi_head.py:274)."""
     for t, nm in ((q, 'Q'), (s, 'S'), (rois, 'rois'), (gn_w, 'gn_w'), (gn_b, 'gn_b'), (fc_w, 'fc_w'), (fc_b, 'fc_b')):
         _chk(t, nm)
     r, p, _, c = q.shape
     if s.shape[1:] != q.shape[1:] or s.shape[0] % n_ways or rois.shape[0] < r or fc_w.shape != (6, c):
         raise _lib.FgnHipError('relation_gn_head: operand shapes inconsistent')
+    if rel_out is not None:
+        _chk(rel_out, 'rel_out')
+        if tuple(rel_out.shape) != (r * n_ways, p, p, c):
+            raise _lib.FgnHipError('relation_gn_head: rel_out must be [R*N,P,P,C]')
     cls = zeros((r * n_ways, 2), q.device)
     reg = zeros((r * n_ways, 4), q.device)
     rc = _lib.load().fgn_relation_gn_head_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
                                               _ptr(fc_b), _ptr(cls), _ptr(reg), _ptr(n_rois_dev), r, n_ways, c,
-                                              gn_groups, p, float(eps), _stream())
+                                              gn_groups, p, float(eps), _ptr(rel_out), _stream())
     _lib.check(rc, 'fgn_relation_gn_head_f32')
     return cls, reg
 
@@ -634,4 +675,27 @@ def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, th
                                   _ptr(ovf), _ptr(n_dev), d, img_h, img_w, m, float(thr), RLE_TRANS_CAP,
                                   RLE_BYTE_CAP, _stream())
     _lib.check(rc, 'fgn_mask_rle')
+    return out, lens, ovf
+
+
+def dense_mask_rle(masks: torch.Tensor):
+    """COCO RLE of dense binary masks [n,H,W] (bool / uint8) on the device: the ground-truth masks of the query
+    (``qry_isegmaps_rle``, fgn.py:298).  Returns (bytes [n,RLE_BYTE_CAP] u8, lens [n] i32, overflow [n] i32)."""
+    if masks.dtype == torch.bool:
+        masks = masks.view(torch.uint8)
+    _chk(masks, 'masks', torch.uint8)
+    if masks.dim() != 3:
+        raise _lib.FgnHipError('dense_mask_rle: masks must be [n,H,W]')
+    n, h, w = masks.shape
+    dev = masks.device
+    out = torch.empty((n, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
+    lens = torch.zeros((n,), device=dev, dtype=torch.int32)
+    ovf = torch.zeros((n,), device=dev, dtype=torch.int32)
+    if n == 0:
+        return out, lens, ovf
+    L = _lib.load()
+    nbytes = L.fgn_dense_rle_scratch_bytes(n, h, w, RLE_TRANS_CAP)
+    scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    _lib.check(L.fgn_dense_mask_rle(_ptr(masks), _ptr(scratch), nbytes, _ptr(out), _ptr(lens), _ptr(ovf), n, h, w,
+                                    RLE_TRANS_CAP, RLE_BYTE_CAP, _stream()), 'fgn_dense_mask_rle')
     return out, lens, ovf

@@ -44,13 +44,17 @@ int fgn_abi_version(void);
  *   cout_pad multiple of 128, zero rows)   y [n_img, Ho, Wo, Cout]
  *   scale/shift [Cout] or NULL; residual like y or NULL; in_scale [n_img, Cin] or NULL
  *   Cin must be a multiple of 32, or exactly 4 (stem, NHWC4 input)
- *   tile_hint 0 = auto, 1..4 = force a tile configuration, 5 = stream-K, negative = no split-K,
+ *   tile_hint 0 = auto, 1..4 = force a tile configuration, negative = no split-K,
  *   +100 = register-staged loader instead of LDS-DMA (tests)
  *   splitk_ws: optional workspace of fgn_conv2d_workspace_bytes() bytes; when given and the plain
  *   grid would under-fill the GPU, K is split over blockIdx.y into slabs that a second kernel
  *   sums in a fixed order (bit-reproducible) before the epilogue.  NULL = never split. */
 size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                   int pad, int tile_hint);
+/* Which kernel the dispatcher launches for a layer (tile*10 + mode; 41 = conv_igemm_dma_kernel<64,64,32,32,2,4,1>):
+ * lets a profiler attribute a launch to the kernel name rocprofv3 reports.  No reference counterpart. */
+int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
+                         int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint);
 int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                         const float* shift, const float* residual, const float* in_scale,
                         const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
@@ -129,7 +133,7 @@ int fgn_scale_channels_f32(const float* x, const float* v, float* out, int n_out
 int fgn_relation_gn_head_f32(const float* Q, const float* S, const float* rois, const float* gn_weight,
                              const float* gn_bias, const float* fc_weight, const float* fc_bias, float* cls_out,
                              float* reg_out, const int32_t* n_rois_dev, int n_rois, int n_ways, int C,
-                             int gn_groups, int roi_size, float eps, void* stream);
+                             int gn_groups, int roi_size, float eps, float* rel_out_debug, void* stream);
 
 /* AG-RPN merge: per-anchor arg-max over the N guided passes (fgn_ag_rpn_head.py:81-113) + sigmoid.
  * head [B*N,HW,head_channels]: channels [0,A) objectness, [A,5A) deltas. Outputs in (y,x,a) order. */
@@ -171,6 +175,15 @@ int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uin
 int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
                  uint8_t* out_bytes, int32_t* out_len, int32_t* overflow, const int32_t* n_dev, int n_det,
                  int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap, void* stream);
+
+/* COCO RLE of dense binary masks on the device: the query's ground-truth masks, which the reference copies to
+ * the GPU with the batch (fgn.py:92-99) and encodes on the host with pycocotools (fgn.py:298, `qry_isegmaps_rle`).
+ * masks [n][H][W] bytes (non-zero = set); out_bytes [n][byte_cap], out_len [n], overflow [n] (a cap was exceeded:
+ * the caller encodes that mask on the host).  scratch: fgn_dense_rle_scratch_bytes(). */
+size_t fgn_dense_rle_scratch_bytes(int n_masks, int img_h, int img_w, int trans_cap);
+int fgn_dense_mask_rle(const uint8_t* masks, void* scratch, size_t scratch_bytes, uint8_t* out_bytes,
+                       int32_t* out_len, int32_t* overflow, int n_masks, int img_h, int img_w, int trans_cap,
+                       int byte_cap, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,42 @@ import numpy as np
 import pytest
 import torch
 
+from fgn_amd.agreement import episode_maxima, match_detections
+
 pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # BASELINE.json north_star: "masks/scores within 1e-4 fp32"; boxes/labels of matched pairs within 1e-2 px
+
+
+def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=2):
+    """Per image: match HIP detections to the oracle's (same label, box within 1e-2 px), assert
+    |d score| <= 1e-4 and max |d mask probability| <= 1e-4 on EVERY matched pair, and report the
+    detections without a partner (an upstream selection flipped) as a count, not a percentage."""
+    start = 0
+    out = []
+    for i in range(len(ref)):
+        n_ref = len(ref[i]['dt_scores'])
+        pi = tr['per_image'][i]
+        n_got = int(pi['n_det'][0])
+        assert n_got == len(got[i]['dt_scores'])
+        if n_ref == 0 or n_got == 0:
+            assert n_ref + n_got <= max_flips, (name, i, n_ref, n_got)
+            start += n_ref
+            continue
+        m = episode_maxima(ref[i], got[i], tr_ref['mask_prob'][start:start + n_ref].numpy(),
+                           pi['mask_prob'][:n_got].cpu().numpy(),
+                           tr_ref['mask_logits'][start:start + n_ref].numpy(), pi['mask_logits'][:n_got].cpu().numpy())
+        start += n_ref
+        print(f'[parity {name} img {i}] detections ref/hip {m["n_ref"]}/{m["n_got"]}, matched {m["matched"]}, '
+              f'selection flips ref/hip {m["flips_ref"]}/{m["flips_got"]}; on matched pairs: max|d score| '
+              f'{m["max_dscore"]:.2e}, max|d mask prob| {m["max_dprob"]:.2e}, max|d box| {m["max_dbox"]:.2e} px, '
+              f'max|d mask logit| {m["max_dlogit"]:.2e} (|logit| <= {m.get("max_abs_logit", 0):.1f})')
+        assert m['matched'] > 0
+        assert m['max_dscore'] <= TOL, (name, i, m)
+        assert m['max_dprob'] <= TOL, (name, i, m)
+        assert m['flips_ref'] <= max_flips and m['flips_got'] <= max_flips, (name, i, m)
+        out.append(m)
+    return out
 
 
 def _iou(a, b):
@@ -46,18 +81,13 @@ def test_e2e_half_width(n_ways, k_shots, hw):
         assert d <= 1e-4 * r.abs().max().item(), (name, d)
     d = (tr['spp_cat_mean_mp'].cpu().reshape(-1) - tr_ref['spp_cat_mean_mp'].reshape(-1)).abs().max().item()
     assert d <= 1e-4 * tr_ref['spp_cat_mean_mp'].abs().max().item()
-    # detections: same count, boxes/scores within tolerance after matching, same labels
+    # detections: every matched pair within north_star's tolerance; flips counted
+    _check_tolerance(ref, got, tr_ref, tr, f'half-width N{n_ways}K{k_shots}')
     for i in range(2):
         rb, gb = ref[i]['dt_bboxes'], got[i]['dt_bboxes']
         assert got[i]['dt_bboxes'].dtype == np.float32 and got[i]['dt_cat_ids'].dtype == np.int64
-        assert abs(len(rb) - len(gb)) <= max(2, len(rb) // 20)
         if len(rb) == 0:
             continue
-        iou = _iou(rb[:, [1, 0, 3, 2]], gb[:, [1, 0, 3, 2]])
-        j = iou.argmax(1)
-        ok = (iou.max(1) > 0.98) & (ref[i]['dt_cat_ids'] == got[i]['dt_cat_ids'][j]) & \
-             (np.abs(ref[i]['dt_scores'] - got[i]['dt_scores'][j]) < 1e-3)
-        assert ok.mean() >= 0.9, ok.mean()
         # passthrough keys
         for key in ('idx', 'qry_bboxes', 'qry_cat_ids', 'qry_img_shape', 'spp_insts_ids'):
             assert np.array_equal(np.asarray(ref[i][key]), np.asarray(got[i][key])), key
@@ -117,12 +147,7 @@ def test_e2e_full_width_reference_configs(name):
     ref, tr_ref, got, tr = _run(cfg, batch)
     r = tr_ref['qry_fmap']
     assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
-    rb, gb = ref[0]['dt_bboxes'], got[0]['dt_bboxes']
-    assert abs(len(rb) - len(gb)) <= max(2, len(rb) // 20)
-    if len(rb):
-        iou = _iou(rb[:, [1, 0, 3, 2]], gb[:, [1, 0, 3, 2]])
-        ok = (iou.max(1) > 0.98) & (ref[0]['dt_cat_ids'] == got[0]['dt_cat_ids'][iou.argmax(1)])
-        assert ok.mean() >= 0.9, ok.mean()
+    _check_tolerance(ref, got, tr_ref, tr, name)
     # HIP detections scored against the CPU path's detections as ground truth
     as_gt = dict(got[0])
     as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
@@ -213,11 +238,7 @@ def test_cfg3_full_size_parity_and_invariants():
     ref = O.simple_test(sd, cfg, **batch, trace=tr_ref)
     r = tr_ref['qry_fmap']
     assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
-    rb = ref[0]['dt_bboxes'][:, [1, 0, 3, 2]]
-    assert abs(len(rb) - d) <= 5
-    iou = _iou(rb, b)
-    ok = (iou.max(1) > 0.98) & (ref[0]['dt_cat_ids'] == g['dt_cat_ids'][iou.argmax(1)])
-    assert ok.mean() >= 0.9, ok.mean()
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg3')
     as_gt = dict(g)
     as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
     as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
@@ -337,7 +358,7 @@ def test_winograd_and_direct_paths_agree():
 def test_cfg4_batched_and_cfg5_full_size_invariants():
     """The two multi-GPU configurations of BASELINE.json at their full sizes (per-GPU share):
     cfg4 = 3-way 3-shot episodes batched at 800x1328 (the reference's x16 rounding, base_fst.py:693-694): a
-    batch of 2 gives each episode the result it gets alone; cfg5 = 5-way 5-shot, 1024x1024, 1000 proposals:
+    batch of 8 (the per-GPU share) gives each episode the result it gets alone; cfg5 = 5-way 5-shot, 1024x1024, 1000 proposals:
     size-independent properties of the output (no oracle run: 2.9 TFLOP per episode on the CPU)."""
     from fgn_amd import rle
     from fgn_amd.config import fgn_r50_c4_config, with_caps
@@ -347,19 +368,22 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
     # ---- cfg4
     cfg = fgn_r50_c4_config(3, 3)
     model = FGN(3, 3, state_dict=init_state_dict(cfg, 0))
-    both = make_batch(40, 2, **CONFIGS['cfg4'])
+    EPB = 8                                      # BASELINE.json cfg4: 8 episodes per GPU per step
+    both = make_batch(40, EPB, **CONFIGS['cfg4'])
     got2 = model.simple_test(**both, rescale=True)
-    for i in range(2):
+    assert len(got2) == EPB
+    for i in range(EPB):
         one = make_batch(40 + i, 1, **CONFIGS['cfg4'])
         got1 = model.simple_test(**one, rescale=True)[0]
         a, b = got2[i], got1
-        assert a['qry_img_shape'].tolist() == [800, 1328, 3]
+        assert a['qry_img_shape'].tolist() == [800, 1328, 3] and int(a['idx']) == 40 + i
         assert abs(len(a['dt_scores']) - len(b['dt_scores'])) <= 2 and len(b['dt_scores']) > 0
-        iou = _iou(a['dt_bboxes'][:, [1, 0, 3, 2]], b['dt_bboxes'][:, [1, 0, 3, 2]])
-        j = iou.argmax(1)
-        ok = (iou.max(1) > 0.98) & (a['dt_cat_ids'] == b['dt_cat_ids'][j]) & \
-             (np.abs(a['dt_scores'] - b['dt_scores'][j]) < 1e-3)       # tile partition differs with the batch: fp32 order
-        assert ok.mean() >= 0.95, ok.mean()
+        pairs, ma, mb = match_detections(a['dt_bboxes'], a['dt_cat_ids'], b['dt_bboxes'], b['dt_cat_ids'])
+        ia, ib = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+        ds = np.abs(a['dt_scores'][ia] - b['dt_scores'][ib]).max()
+        print(f'[cfg4 batch {EPB} vs alone, episode {i}] matched {len(pairs)}/{len(b["dt_scores"])}, '
+              f'flips {len(ma)}/{len(mb)}, max|d score| {ds:.2e}')
+        assert ds <= TOL and len(ma) <= 2 and len(mb) <= 2      # tile partition differs with the batch: fp32 order
     del model
     # ---- cfg5
     shape = CONFIGS['cfg5']
@@ -393,3 +417,34 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
             assert i2.max() <= 0.5 + 1e-6
     m = rle.decode(g['dt_isegmaps_rle'][0])
     assert m.shape == (1024, 1024)
+
+
+def test_gathered_records_rebuild_the_result_dicts_and_slots_are_not_overwritten():
+    """(1) What the RCCL gather carries (boxes, scores, labels, 14x14 mask probabilities) is enough for any rank to
+    emit the complete result dict of an episode: ``results_from_gathered`` on the packed records == ``pack_results``
+    of the producing rank, RLE strings byte for byte.  (2) Eight batches queued before the first is packed (more
+    than the six host slots round 1 cycled through blindly): every batch still gets its own results."""
+    from fgn_amd import dist as fd
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+    batches = [make_batch(3 * q, 2, 3, 2, 160, 224, 64) for q in range(8)]
+    serial = [model.simple_test(**b, rescale=True) for b in batches]
+    queued = [model.detect_device(b['qry_img'], b['spp_imgs'], b['spp_bboxes'], b['spp_isegmaps'], b['img_shape'],
+                                  qry_isegmaps=b['qry_isegmaps']) for b in batches]
+    assert len({id(d[0]['host']) for d in queued}) == 8                 # eight distinct pinned slots in flight
+    for b, dets, want in zip(batches, queued, serial):
+        recs, cnts = fd.pack_detections(dets, 100)
+        rebuilt = fd.results_from_gathered(recs, cnts, (160, 224), cfg['test_cfg']['rcnn']['mask_thr_binary'])
+        got = model.pack_results(dets, 2, qry_isegmaps=b['qry_isegmaps'], img_shape=b['img_shape'])
+        for w, g, r in zip(want, got, rebuilt):
+            assert len(w['dt_scores']) > 0
+            for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+                assert np.array_equal(w[key], g[key]) and np.array_equal(w[key], r[key]), key
+            assert w['dt_isegmaps_rle'] == g['dt_isegmaps_rle'] == r['dt_isegmaps_rle']
+            assert w['qry_isegmaps_rle'] == g['qry_isegmaps_rle']
+    assert all(not s['busy'] for ring in model._pinned.values() for s in ring)

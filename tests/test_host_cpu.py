@@ -137,17 +137,34 @@ def test_collate_matches_reference_layout():
     assert b['qry_isegmaps'][1].shape == (3, 64, 96)
 
 
+def _fake_det(e, max_det=4, m=14):
+    """Detections of episode e as FGN.detect_device returns them (device dict), with recognisable payloads:
+    box values e, labels e % 3, mask probabilities e + 0.01 * detection + 1e-4 * pixel."""
+    n = e % max_det
+    prob = float(e) + 0.01 * torch.arange(max_det, dtype=torch.float32)[:, None, None] + \
+        1e-4 * torch.arange(m * m, dtype=torch.float32).reshape(1, m, m)
+    return dict(det_bboxes=torch.full((max_det, 5), float(e)), det_labels=torch.full((max_det,), e % 3, dtype=torch.int64),
+                n_dets=torch.tensor([n], dtype=torch.int32), mask_prob=prob.contiguous())
+
+
 def _dist_worker(rank, world, port, q):
     import torch.distributed as dist
     from fgn_amd import dist as fd
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     try:
-        mine = fd.shard_episodes(5, rank, world)
-        dets = [dict(det_bboxes=torch.full((4, 5), float(e)), det_labels=torch.full((4,), e, dtype=torch.int64),
-                     n_dets=torch.tensor([e % 4], dtype=torch.int32)) for e in (mine + [99])[:3]]
-        recs, cnts = fd.pack_detections(dets, 4)
+        n_episodes = 5                                           # world 2: ranks hold 3 and 2 episodes
+        mine = fd.shard_episodes(n_episodes, rank, world)
+        per = fd.episodes_per_rank(n_episodes, world)
+        recs, cnts = fd.pack_detections([_fake_det(e) for e in mine], 4, pad_to=per)
+        assert recs.shape == (per, 4, 6 + 196) and cnts.shape == (per,)
         g_recs, g_cnts = fd.gather_detections(recs, cnts)
-        q.put((rank, mine, fd.interleave(g_recs)[:, 0, 0].tolist(), fd.interleave(g_cnts).tolist()))
+        allr, allc = fd.interleave(g_recs), fd.interleave(g_cnts)       # global episode order
+        # every rank can emit the result dicts of every episode; a host RLE stand-in keeps this test CPU-only
+        rle_fn = lambda prob, boxes, h, w, thr: [{'size': [h, w], 'counts': bytes([int(p[0, 0] * 100) % 256])} for p in prob]
+        res = fd.results_from_gathered(allr[:n_episodes], allc[:n_episodes], (32, 48), rle_fn=rle_fn)
+        q.put((rank, mine, allr[:, 0, 0].tolist(), allc.tolist(),
+               [float(allr[e, 1, 6 + 5]) for e in range(n_episodes)],           # mask payload: detection 1, pixel 5
+               [(len(r['dt_scores']), r['dt_cat_ids'].tolist(), r['dt_bboxes'].shape) for r in res]))
     finally:
         dist.destroy_process_group()
 
@@ -165,10 +182,24 @@ def test_episode_sharding_and_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out[0][1] == [0, 2, 4] and out[1][1] == [1, 3]
-    # every rank sees the same globally ordered result: episodes 0,1,2,3,4,(pad 99)
+    # every rank sees the same globally ordered result: episodes 0,1,2,3,4 and the zero-count pad of rank 1
     for r in out:
-        assert r[2] == [0.0, 1.0, 2.0, 3.0, 4.0, 99.0]
-        assert r[3] == [0, 1, 2, 3, 0, 3]
+        assert r[2] == [0.0, 1.0, 2.0, 3.0, 4.0, 0.0]
+        assert r[3] == [0, 1, 2, 3, 0, 0]
+        # the mask probabilities travel with their detection, in detection and pixel order
+        assert np.allclose(r[4], [e + 0.01 + 5e-4 for e in range(5)], atol=1e-6)
+        # result dicts of all episodes, materialised on every rank from the gathered records
+        assert [x[0] for x in r[5]] == [0, 1, 2, 3, 0]
+        assert r[5][3][1] == [0, 0, 0] and r[5][2][1] == [2, 2] and r[5][3][2] == (3, 4)
+
+
+def test_gather_is_identity_without_process_group():
+    from fgn_amd import dist as fd
+    recs, cnts = fd.pack_detections([_fake_det(3), _fake_det(6)], 4)
+    g_recs, g_cnts = fd.gather_detections(recs, cnts)
+    assert g_recs.shape == (1, 2, 4, 202) and g_cnts.tolist() == [[3, 2]]
+    with pytest.raises(ValueError):
+        fd.results_from_gathered(recs[:, :, :6], cnts, (8, 8))          # records without mask payload
 
 
 def _res(h, w, gt_boxes, gt_cats, dt_boxes, dt_cats, dt_scores):
