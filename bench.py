@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=1, help='episodes per step per GPU (the reference evaluates with '
                     'batch 4, fgn_test.py:49; cfg4 of BASELINE.json is 8 per GPU); default 1 = cfg3 as surveyed')
     ap.add_argument('--no-winograd', action='store_true', help='direct implicit-GEMM form for every 3x3 convolution')
+    ap.add_argument('--winograd', type=int, default=None, choices=(2, 4),
+                    help='output tile edge of the Winograd form: 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3)')
     ap.add_argument('--resident-inputs', action='store_true',
                     help='not the headline: park the inputs in HBM before timing (no host->device copy in the step)')
     ap.add_argument('--cache-supports', action='store_true',
@@ -151,7 +153,7 @@ def main():
     sd = init_state_dict(cfg, 0)
     model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
     model.use_graphs = args.graphs
-    model.use_winograd = not args.no_winograd
+    model.use_winograd = False if args.no_winograd else (args.winograd or True)
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);
     # every step copies its episode to the device (--resident-inputs: parked in HBM instead, not the headline)
@@ -249,9 +251,9 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    # one of the timed steps (two from K = 40) carries HIP-event brackets around every convolution kernel launch,
-    # on the stream it is launched on, in the normal two-stream execution mode of every other step (= what a
-    # rocprofv3 kernel trace of this command sees)
+    # one of the timed steps (two from K = 40) has every convolution kernel launch stamp a start/stop HIP event pair
+    # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on), in the normal two-stream
+    # execution mode of every other step (= what a rocprofv3 kernel trace of this command sees)
     n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps)
     barrier()
     dt = time.perf_counter() - t0
@@ -319,7 +321,7 @@ def main():
                        'gt_mask_rle_in_step': True, 'gt_masks_per_step': n_gt / args.steps,
                        'world_size_seen': world, 'collective_backend': backend if world > 1 else None,
                        'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
-                       'winograd_3x3': bool(model.use_winograd),
+                       'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,
                        'avg_detections': n_d / args.steps / args.batch,
                        'algorithmic_gflop_per_episode': round(gflop, 1),
@@ -336,8 +338,8 @@ def main():
                          'kernel_ms_per_step': round(dom['ms'] / n_prof_steps, 3),
                          'share_of_conv_time': round(dom['ms'] / tot['ms'], 3) if tot['ms'] else None,
                          'profiled_steps': n_prof_steps,
-                         'timing': 'HIP events around each launch of the kernel on its own stream, inside the timed region, '
-                                   'in the normal two-stream execution mode',
+                         'timing': 'start/stop HIP events stamped by each launch of the kernel itself (hipExtLaunchKernelGGL) on '
+                                   'its own stream, inside the timed region, in the normal two-stream execution mode',
                          'all_conv_launches': {
                              'what': 'every convolution-family kernel of a step (implicit-GEMM kernels, Winograd transforms, '
                                      'split-K reduces)',

@@ -15,6 +15,24 @@
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Kernel-exact timing for a profiler (bench.py roofline): fgn_profile_next_launch(start, stop) arms the calling
+// thread; the next launch that goes through FGN_LAUNCH_TIMED is dispatched with hipExtLaunchKernelGGL, which stamps
+// the two events with the start / end of that kernel alone (what a rocprofv3 kernel trace reports), instead of
+// bracketing it with hipEventRecord, which also measures the command processor's gaps around it.
+#include <hip/hip_ext.h>
+extern thread_local hipEvent_t fgn_prof_start;
+extern thread_local hipEvent_t fgn_prof_stop;
+#define FGN_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                            \
+    do {                                                                                                   \
+        if (fgn_prof_start) {                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, fgn_prof_start, fgn_prof_stop, 0, __VA_ARGS__); \
+            fgn_prof_start = nullptr;                                                                      \
+            fgn_prof_stop = nullptr;                                                                       \
+        } else {                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                             \
+        }                                                                                                  \
+    } while (0)
+
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the
 // function object of the CURRENT device (a process may drive several GPUs): set once per (call site, device);
 // `done_mask` is a static of the call site, bit d = device d done.

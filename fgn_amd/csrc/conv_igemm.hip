@@ -43,6 +43,12 @@ struct ConvParams {
     int relu;
     int K;          // padded reduction length (multiple of 32)
     int n_tiles_n;  // Cout tiles
+    // banded tile raster (LDS-DMA kernel): when the weight matrix of a launch (Cout x K) does not fit an XCD's L2
+    // next to the activations, the plain order (all Cout tiles of one row tile, then the next row tile) re-streams
+    // it from the Infinity Cache for every row tile (measured: 1.53 GB fetched by the AG-RPN Winograd GEMM against
+    // 0.28 GB of operands).  Tiles are therefore walked band by band: `band_nt` Cout tiles (<= ~2 MB of weights)
+    // x all `band_mt` row tiles of the group (grouped GEMM) or launch, then the next band.  0 = plain order.
+    int band_nt, band_mt;
     // split-K: blockIdx.y owns K-tiles [y*kt_per_split, (y+1)*kt_per_split) and writes its raw
     // partial tile to slab y of `ws` ([splits][n_img*Ho*Wo][Cout]); splitk_epilogue_kernel sums
     // the slabs in a fixed order (deterministic) and applies the epilogue.
@@ -418,8 +424,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / p.n_tiles_n;
-    const int tile_n = bid - tile_m * p.n_tiles_n;
+    int tile_m = bid / p.n_tiles_n;
+    int tile_n = bid - tile_m * p.n_tiles_n;
+    if (p.band_nt > 0) {
+        const int per_grp = p.band_mt * p.n_tiles_n;
+        const int grp = bid / per_grp;
+        int r = bid - grp * per_grp;
+        const int per_band = p.band_mt * p.band_nt;
+        const int band = r / per_band;
+        r -= band * per_band;
+        const int mi = r / p.band_nt;
+        tile_m = grp * p.band_mt + mi;
+        tile_n = band * p.band_nt + (r - mi * p.band_nt);
+    }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -753,7 +770,20 @@ template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, BN);
-    const dim3 grid(cdiv(M_max, BM) * p.n_tiles_n, p.splits);
+    const int m_tiles = cdiv(M_max, BM);
+    const dim3 grid(m_tiles * p.n_tiles_n, p.splits);
+    {
+        // banded raster when the launch's weights exceed the L2 budget (see ConvParams::band_nt)
+        static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
+        const long long per_nt = (long long)BN * (p.K / p.splits) * 4;
+        p.band_nt = 0; p.band_mt = 0;
+        if (budget > 0 && per_nt * p.n_tiles_n > budget) {
+            int nb = (int)std::max<long long>(1, budget / per_nt);
+            while (nb > 1 && p.n_tiles_n % nb) --nb;
+            const int mt = p.grp_rows ? p.grp_rows / BM : m_tiles;
+            if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
+        }
+    }
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static unsigned long long lds_ok[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>), &lds_ok[0]);
@@ -771,17 +801,17 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         if (attr != hipSuccess) return (int)attr;
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
         if (cin4)
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
+            FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
         else if (pw)
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
+            FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>), grid, dim3(256), dlds, stream, p);
+            FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>), grid, dim3(256), dlds, stream, p);
     } else if (cin4)
         return FGN_ERR_SHAPE;      // the stem runs on the LDS-DMA kernel only (input < 2 GiB)
     else if (p.in_scale)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, MW>), grid, dim3(256), lds, stream, p);
+        FGN_LAUNCH_TIMED((conv_igemm_kernel<BM, BN, WM, WN, true, MW>), grid, dim3(256), lds, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, MW>), grid, dim3(256), lds, stream, p);
+        FGN_LAUNCH_TIMED((conv_igemm_kernel<BM, BN, WM, WN, false, MW>), grid, dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
     if (p.splits > 1) {
         const size_t total4 = (size_t)M_max * p.Cout / 4;
@@ -917,9 +947,9 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// The 16 GEMMs of a Winograd F(2x2,3x3) convolution (winograd.hip holds the transforms):
-//   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = 0..15 (position in the 4x4 transformed tile)
-// run as ONE launch of the 64x64 kernel in point-wise mode over the stacked rows [16 * t_pad] with a
+// The 16 / 36 GEMMs of a Winograd F(2x2,3x3) / F(4x4,3x3) convolution (winograd.hip holds the transforms):
+//   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = position in the 4x4 / 6x6 transformed tile
+// run as ONE launch of the 64x64 kernel in point-wise mode over the stacked rows [n_groups * t_pad] with a
 // per-group weight matrix.  t_pad is a multiple of the 64-row tile so no tile straddles two groups; 1600 tiles
 // (100 RoIs x 16) and 4800 (300 RoIs) need no padding at all.  (A grouped 128x128 persistent variant measured
 // equal on the AG-RPN GEMM and 5 % slower on the 300-RoI one, and much slower on everything smaller.)
@@ -927,15 +957,15 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
 extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
 
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                                     int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad,
+                                     int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
                                      hipStream_t stream) {
     if (!V || !U || !Mo) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
-        (long long)n_img * tiles_per_img > t_pad)
+        (n_groups != 16 && n_groups != 36) || (long long)n_img * tiles_per_img > t_pad)
         return FGN_ERR_SHAPE;
-    const long long rows = 16ll * t_pad;
-    const long long xb = rows * Cin * 4, wb = 16ll * cout_pad * Cin * 4;
+    const long long rows = (long long)n_groups * t_pad;
+    const long long xb = rows * Cin * 4, wb = (long long)n_groups * cout_pad * Cin * 4;
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;

@@ -101,14 +101,14 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
 
 # ------------------------------------------------------------------------------------------
 class _Bottleneck:
-    def __init__(self, sd, prefix, stride, eps, winograd=False):
+    def __init__(self, sd, prefix, stride, eps, winograd=0):
         bn = lambda n: {k: sd[f'{prefix}.{n}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
         self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'], bn=bn('bn1'), relu=True, eps=eps)
         self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], bn=bn('bn2'), stride=stride, pad=1, relu=True,
                                    eps=eps)
-        # Winograd form of a stride-1 3x3 (2.25x fewer MFMA passes); chosen per call by ops.winograd_pays
+        # Winograd form of a stride-1 3x3 (F(4x4,3x3): 4x fewer MFMA passes); chosen per call by ops.winograd_pays
         w2 = sd[prefix + '.conv2.weight']
-        self.conv2_wg = ops.pack_winograd(w2, bn=bn('bn2'), relu=True, eps=eps) \
+        self.conv2_wg = ops.pack_winograd(w2, bn=bn('bn2'), relu=True, eps=eps, m=winograd) \
             if winograd and stride == 1 and w2.shape[1] % 32 == 0 and w2.shape[0] % 4 == 0 else None
         self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'], bn=bn('bn3'), relu=True, eps=eps)
         self.down = None
@@ -124,7 +124,8 @@ class _Bottleneck:
         idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
         y = y1 if y1 is not None else ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
         if self.conv2_wg is not None and \
-                ops.winograd_pays(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout):
+                ops.winograd_pays(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout,
+                                  self.conv2_wg.m):
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
@@ -242,20 +243,25 @@ class FGN(torch.nn.Module):
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
         self.use_side_stream = True               # support branch on a second HIP stream
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
-        self._use_winograd = True                 # Winograd F(2x2,3x3) for the AG-RPN conv and the shared_head 3x3
+        self._use_winograd = ops.WINOGRAD_M       # Winograd form of the 3x3 / stride 1 convs: 4 = F(4x4,3x3), 2 = F(2x2,3x3), 0 = direct
         self.use_roi_commute = True               # shared_head conv1 on the feature map, RoIAlign after (set before first use)
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
 
     @property
-    def use_winograd(self) -> bool:
+    def use_winograd(self) -> int:
         return self._use_winograd
 
     @use_winograd.setter
-    def use_winograd(self, on: bool) -> None:
-        if bool(on) != self._use_winograd:        # the packed layers (and any captured graph) depend on it
-            self._use_winograd = bool(on)
+    def use_winograd(self, on) -> None:
+        """False / 0: direct implicit GEMM for every 3x3; True: the default Winograd form (F(4x4,3x3)); 2 or 4: that
+        output tile edge."""
+        m = ops.WINOGRAD_M if on is True else int(on)
+        if m not in (0, 2, 4):
+            raise ValueError('use_winograd: False, True, 2 or 4')
+        if m != self._use_winograd:               # the packed layers (and any captured graph) depend on it
+            self._use_winograd = m
             self._packed_device = None
             self._graphs = {}
 
@@ -318,7 +324,7 @@ class FGN(torch.nn.Module):
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
         wr = sd['rpn_head.rpn_conv.weight']
-        P['rpn_conv_wg'] = ops.pack_winograd(wr, bias=sd['rpn_head.rpn_conv.bias'], relu=True) \
+        P['rpn_conv_wg'] = ops.pack_winograd(wr, bias=sd['rpn_head.rpn_conv.bias'], relu=True, m=self.use_winograd) \
             if self.use_winograd and wr.shape[1] % 32 == 0 and wr.shape[0] % 4 == 0 else None
         # objectness and delta 1x1 convs fused into one launch: channels [0,A) | [A,5A)
         P['rpn_head'] = ops.pack_conv(
@@ -348,7 +354,7 @@ class FGN(torch.nn.Module):
                            for i in range(mh['num_convs'])]
         P['mask_convs_wg'] = [
             ops.pack_winograd(sd[f'roi_head.mask_head.convs.{i}.conv.weight'],
-                              bias=sd[f'roi_head.mask_head.convs.{i}.conv.bias'], relu=True)
+                              bias=sd[f'roi_head.mask_head.convs.{i}.conv.bias'], relu=True, m=self.use_winograd)
             if self.use_winograd and sd[f'roi_head.mask_head.convs.{i}.conv.weight'].shape[1] % 32 == 0 and
             sd[f'roi_head.mask_head.convs.{i}.conv.weight'].shape[0] % 4 == 0 else None
             for i in range(mh['num_convs'])]
@@ -433,7 +439,7 @@ class FGN(torch.nn.Module):
         m = mf
         for li, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
             scale = vmask if li == 0 else None         # support-vector guidance (fgn_roi_head.py:379) fused into conv 0
-            if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout):
+            if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout, wg.m):
                 m = ops.conv3x3_winograd(m, wg, in_scale=scale, n_img_dev=n_dev)
             else:
                 m = ops.conv2d(m, layer, in_scale=scale, n_img_dev=n_dev)
@@ -644,7 +650,8 @@ class FGN(torch.nn.Module):
         rpn_start = main.record_event()
         # guidance multiply (fgn_ag_rpn_head.py:44): never materialised - it rides in the Winograd input transform,
         # or in the A-operand staging of the direct kernel where the layer is too small for the Winograd form
-        if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout):
+        if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout,
+                                                              P['rpn_conv_wg'].m):
             # Winograd F(2x2,3x3); the guidance multiply rides in its input transform
             x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
         else:

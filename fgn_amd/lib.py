@@ -18,12 +18,15 @@ _f = C.c_float
 # name -> (restype, argtypes); mirrors include/fgn_hip.h one to one
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
+    'fgn_profile_next_launch': (_i, [_p, _p]),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
     'fgn_conv2d_kernel_id': (_i, [_i] * 14),
     'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_t_pad': (_i, [_i]),
-    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd4_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
     'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -50,7 +53,7 @@ SIGNATURES = {
     'fgn_dense_mask_rle': (_i, [_p, _p, C.c_size_t, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

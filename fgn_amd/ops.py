@@ -109,6 +109,20 @@ class ConvProfile(list):
         e.record()
         return e
 
+    def arm(self):
+        """Arm the library so that the next convolution-family kernel launched by this thread stamps a fresh
+        (start, stop) event pair with its own start and end (fgn_profile_next_launch)."""
+        pair = []
+        for _ in range(2):
+            if self.pool:
+                pair.append(self.pool.pop())        # pool events have been recorded once: their handles exist
+            else:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                pair.append(e)
+        _lib.check(_lib.load().fgn_profile_next_launch(pair[0].cuda_event, pair[1].cuda_event), 'fgn_profile_next_launch')
+        return pair
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -228,7 +242,7 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     prof = PROFILE
     L = _lib.load()
     if prof is not None:
-        e0 = prof.event()
+        e0, e1 = prof.arm()
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
                                             layer.pad, tile_hint)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
@@ -242,7 +256,7 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
                                      layer.pad, a_img_div, int(in_scale is not None), int(residual is not None),
                                      tile_hint)
         flop = 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * (3 if cin == 4 else cin)
-        prof.append(dict(kind='conv', kernel=kernel_name(kid), e0=e0, e1=prof.event(), flop_direct=flop,
+        prof.append(dict(kind='conv', kernel=kernel_name(kid), e0=e0, e1=e1, flop_direct=flop,
                          flop_issued=flop, n_img=n_img, n_img_dev=n_img_dev,
                          shape=(n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
     return out
@@ -253,13 +267,19 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
 # --------------------------------------------------------------------------------------
 @dataclass
 class WinogradLayer:
-    """U [16, cout_pad, Cin] = G w G^T with the per-channel epilogue scale folded in; shift [Cout]."""
+    """U [m_in^2, cout_pad, Cin] = G w G^T with the per-channel epilogue scale folded in; shift [Cout].
+    ``m`` = output tile edge: 4 = F(4x4,3x3), 36 tile positions; 2 = F(2x2,3x3), 16 positions."""
     u: torch.Tensor
     shift: Optional[torch.Tensor]
     cin: int
     cout: int
     cout_pad: int
     relu: bool
+    m: int = 2
+
+    @property
+    def groups(self) -> int:
+        return (self.m + 2) ** 2
 
     def to(self, device):
         self.u = self.u.to(device)
@@ -267,15 +287,22 @@ class WinogradLayer:
         return self
 
 
-_WG_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+_WG_G = {
+    2: torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64),
+    # Cook-Toom, points {0, 1, -1, 1/2, -2, inf} (csrc/winograd.hip holds the matching B^T / A^T)
+    4: torch.tensor([[1.0, 0.0, 0.0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15],
+                     [1 / 15, -2 / 15, 4 / 15], [0.0, 0.0, 1.0]], dtype=torch.float64),
+}
+WINOGRAD_M = 4       # default output tile edge
 
 
 def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
-                  relu: bool = False, eps: float = 1e-5) -> WinogradLayer:
+                  relu: bool = False, eps: float = 1e-5, m: Optional[int] = None) -> WinogradLayer:
     """weight [Cout,Cin,3,3] -> WinogradLayer (transform in fp64, stored fp32)."""
+    m = WINOGRAD_M if m is None else m
     cout, cin, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or cin % 32 != 0 or cout % 4 != 0:
-        raise _lib.FgnHipError('pack_winograd: needs a 3x3 kernel, Cin % 32 == 0, Cout % 4 == 0')
+    if (kh, kw) != (3, 3) or cin % 32 != 0 or cout % 4 != 0 or m not in _WG_G:
+        raise _lib.FgnHipError('pack_winograd: needs a 3x3 kernel, Cin % 32 == 0, Cout % 4 == 0, m in (2, 4)')
     w = weight.detach().double()
     scale = shift = None
     if bn is not None:
@@ -286,27 +313,34 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
         w = w * scale[:, None, None, None]
     elif bias is not None:
         shift = bias.detach().double()
-    u = torch.einsum('ai,ocij,bj->aboc', _WG_G, w, _WG_G)                    # [4,4,Cout,Cin]
+    G = _WG_G[m]
+    u = torch.einsum('ai,ocij,bj->aboc', G, w, G)                            # [m+2,m+2,Cout,Cin]
     cout_pad = (cout + 127) // 128 * 128
-    up = torch.zeros(16, cout_pad, cin, dtype=torch.float32)
-    up[:, :cout] = u.reshape(16, cout, cin).float()
+    up = torch.zeros((m + 2) ** 2, cout_pad, cin, dtype=torch.float32)
+    up[:, :cout] = u.reshape((m + 2) ** 2, cout, cin).float()
     return WinogradLayer(up.contiguous(), None if shift is None else shift.float().contiguous(), cin, cout,
-                         cout_pad, relu)
+                         cout_pad, relu, m)
 
 
-def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
-    """The grouped GEMM addresses V / Mo through 32-bit buffer offsets: [16 * t_pad, C] must stay below 2 GiB."""
-    t_pad = (n_img * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64 * 64
-    rows = 16 * t_pad
+def _wg_tiles(H: int, W: int, m: int) -> int:
+    return ((H + m - 1) // m) * ((W + m - 1) // m)
+
+
+def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int, m: Optional[int] = None) -> bool:
+    """The grouped GEMM addresses V / Mo through 32-bit buffer offsets: [groups * t_pad, C] must stay below 2 GiB."""
+    m = WINOGRAD_M if m is None else m
+    t_pad = (n_img * _wg_tiles(H, W, m) + 63) // 64 * 64
+    rows = (m + 2) ** 2 * t_pad
     return rows * cin * 4 < 0x7fffff00 and rows * cout < (1 << 31)
 
 
-def winograd_pays(n_img: int, H: int, W: int, cin: int, cout: int) -> bool:
-    """Measured on MI355X (tools/wg_bench.py): the Winograd form wins from 128 input channels and a few hundred
-    tiles on (layer2/3, 100-RoI heads, the AG-RPN conv); with 64 channels the transforms cost more than the GEMM
-    saves, and below ~256 tiles the launch costs of its three kernels do."""
-    tiles = n_img * ((H + 1) // 2) * ((W + 1) // 2)
-    return cin >= 128 and tiles >= 256 and winograd_fits(n_img, H, W, cin, cout)
+def winograd_pays(n_img: int, H: int, W: int, cin: int, cout: int, m: Optional[int] = None) -> bool:
+    """Measured on MI355X (tools/wg_bench.py, direct -> F(2x2) -> F(4x4)): AG-RPN conv 2.23 -> 0.95 -> 0.57 ms,
+    shared_head 3x3 on 300 RoIs 0.65 -> 0.43 -> 0.29 ms, layer1 (64 channels, 200x334) 65 -> 70 -> 57 us; the
+    9-RoI support head (441 pixels) loses to the launch costs of the three kernels.  F(4x4) pays from 64 input
+    channels, F(2x2) from 128; both need about a thousand output pixels."""
+    m = WINOGRAD_M if m is None else m
+    return cin >= (64 if m == 4 else 128) and n_img * H * W >= 1024 and winograd_fits(n_img, H, W, cin, cout, m)
 
 
 def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[torch.Tensor] = None,
@@ -323,38 +357,42 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
             raise _lib.FgnHipError('conv3x3_winograd: in_scale must be [n_img, Cin]')
     if n_img_dev is not None:
         _chk(n_img_dev, 'n_img_dev', torch.int32)
-    tiles = ((H + 1) // 2) * ((W + 1) // 2)
+    tiles = _wg_tiles(H, W, layer.m)
     L = _lib.load()
+    f_in, f_out = (L.fgn_winograd4_input_f32, L.fgn_winograd4_output_f32) if layer.m == 4 else \
+        (L.fgn_winograd_input_f32, L.fgn_winograd_output_f32)
+    G = layer.groups
     t_pad = L.fgn_winograd_t_pad(n_img * tiles)
-    V = torch.empty((16, t_pad, cin), device=x.device, dtype=torch.float32)
-    Mo = torch.empty((16, t_pad, layer.cout), device=x.device, dtype=torch.float32)
+    V = torch.empty((G, t_pad, cin), device=x.device, dtype=torch.float32)
+    Mo = torch.empty((G, t_pad, layer.cout), device=x.device, dtype=torch.float32)
     y = torch.empty((n_img, H, W, layer.cout), device=x.device, dtype=torch.float32)
     prof = PROFILE
     st = _stream()
-    ev = [prof.event()] if prof is not None else None
-    _lib.check(L.fgn_winograd_input_f32(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W,
-                                        cin, t_pad, st), 'fgn_winograd_input_f32')
+    ev = [] if prof is not None else None
     if ev is not None:
-        ev.append(prof.event())
+        ev.append(prof.arm())
+    _lib.check(f_in(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W, cin, t_pad, st),
+               'fgn_winograd_input_f32')
+    if ev is not None:
+        ev.append(prof.arm())
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, st), 'fgn_winograd_gemm_f32')
+                                       layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_f32')
     if ev is not None:
-        ev.append(prof.event())
-    _lib.check(L.fgn_winograd_output_f32(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W,
-                                         layer.cout, t_pad, int(layer.relu), st), 'fgn_winograd_output_f32')
+        ev.append(prof.arm())
+    _lib.check(f_out(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W, layer.cout, t_pad,
+                     int(layer.relu), st), 'fgn_winograd_output_f32')
     if ev is not None:
-        ev.append(prof.event())
         # direct-convolution FLOPs of the layer (what the reference's formulation executes) are booked on the GEMM
-        # record; the MFMA work actually issued is 16 products per 2x2-output tile instead of 36: 16/36 of it on
-        # even maps, 0.58 on the 7x7 RoI maps (16 tiles cover 8x8)
+        # record; the MFMA work actually issued is (m+2)^2 products per m x m output tile instead of 9 m^2
         shape = (n_img, H, W, cin, layer.cout, 3, 1)
         common = dict(n_img=n_img, n_img_dev=n_img_dev, shape=shape)
-        prof.append(dict(kind='wg_in', kernel='wg_input_kernel', e0=ev[0], e1=ev[1], flop_direct=0.0, flop_issued=0.0,
+        kin, kout = ('wg4_input_kernel', 'wg4_output_kernel') if layer.m == 4 else ('wg_input_kernel', 'wg_output_kernel')
+        prof.append(dict(kind='wg_in', kernel=kin, e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0,
                          **common))
-        prof.append(dict(kind='wg_gemm', kernel=kernel_name(41), e0=ev[1], e1=ev[2],
+        prof.append(dict(kind='wg_gemm', kernel=kernel_name(41), e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
-                         flop_issued=2.0 * 16 * tiles * layer.cout * cin, **common))
-        prof.append(dict(kind='wg_out', kernel='wg_output_kernel', e0=ev[2], e1=ev[3], flop_direct=0.0,
+                         flop_issued=2.0 * G * tiles * layer.cout * cin, **common))
+        prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
                          flop_issued=0.0, **common))
     return y
 

@@ -33,6 +33,11 @@ extern "C" {
 
 int fgn_abi_version(void);
 
+/* Profiler hook (no reference counterpart): arm the calling thread so that the NEXT convolution-family kernel it
+ * launches stamps the two HIP events (hipEvent_t, created by the caller) with that kernel's own start and end -
+ * the duration a rocprofv3 kernel trace reports.  NULL, NULL disarms. */
+int fgn_profile_next_launch(void* start_event, void* stop_event);
+
 /* Implicit-GEMM convolution on the fp32 MFMA pipe with fused epilogue
  *   y = conv(x * in_scale?, w) * scale[c] + shift[c] (+ residual) (ReLU)
  * Replaces cuDNN conv + BN(eval) + ReLU of mmdet ResNet (fgn.py:212,215), RPNHead
@@ -74,9 +79,16 @@ int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, cons
                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
 int fgn_winograd_t_pad(int tiles_total);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, void* stream);
+                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
 int fgn_winograd_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                             int H, int W, int C, int t_pad, int relu, void* stream);
+/* F(4x4,3x3) form of the same convolutions (the default): 36 tile positions (n_groups = 36 in
+ * fgn_winograd_gemm_f32), V / Mo [36][t_pad][C], tiles per image = ceil(H/4)*ceil(W/4); interpolation points
+ * {0, 1, -1, 1/2, -2, inf} (winograd.hip).  4x fewer multiply-adds than the direct form, 1.78x fewer than F(2x2). */
+int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev, int n_img,
+                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
+int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
+                             int H, int W, int C, int t_pad, int relu, void* stream);
 
 /* NCHW [n,3,H,W] -> NHWC4 [n,H,W,4] (input side of fgn.py:212,215) */
 int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, void* stream);

@@ -1,4 +1,4 @@
-"""Winograd F(2x2,3x3) path (transforms + grouped stream-K GEMM) vs torch conv2d."""
+"""Winograd F(4x4,3x3) and F(2x2,3x3) paths (transforms + grouped GEMM) vs torch conv2d."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -14,26 +14,30 @@ def _ref(x, w, b, scale_in=None, div=1, relu=True):
     return (F.relu(y) if relu else y).float()
 
 
+@pytest.mark.parametrize('m', [4, 2])
 @pytest.mark.parametrize('n,h,w,cin,cout,div,scaled', [
     (2, 8, 10, 64, 128, 1, False),
     (1, 7, 9, 32, 8, 1, False),            # odd sizes: partial last tiles; Cout < tile
     (1, 13, 21, 128, 256, 3, True),        # AG-RPN pattern: one map, N guided passes
-    (37, 7, 7, 64, 64, 1, False),          # RoI pattern: 7x7 maps, 16 tiles per RoI
+    (37, 7, 7, 64, 64, 1, False),          # RoI pattern: 7x7 maps, 16 / 4 tiles per RoI
     (1, 50, 84, 256, 128, 3, True),
+    (3, 5, 3, 32, 32, 1, False),           # maps smaller than / not a multiple of a tile
 ])
-def test_winograd_matches_direct(n, h, w, cin, cout, div, scaled):
+def test_winograd_matches_direct(n, h, w, cin, cout, div, scaled, m):
     from fgn_amd import ops
     g = torch.Generator().manual_seed(n * h + cin)
     x = torch.randn(n, h, w, cin, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, generator=g) * 0.1
     s = (torch.rand(n * div, cin, generator=g) + 0.5) if scaled else None
-    layer = ops.pack_winograd(wt, bias=b, relu=True).to('cuda')
+    layer = ops.pack_winograd(wt, bias=b, relu=True, m=m).to('cuda')
+    assert layer.groups == (m + 2) ** 2
     got = ops.conv3x3_winograd(x.cuda(), layer, in_scale=None if s is None else s.cuda(), a_img_div=div)
     ref = _ref(x, wt, b, s, div)
     assert got.shape == (n * div, h, w, cout)
     d = (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
-    assert d <= 1e-4 * max(ref.abs().max().item(), 1.0), d      # tolerance: fp32, 1e-4 of the output range
+    # measured: F(2x2) ~5e-7, F(4x4) with the points {0, 1, -1, 1/2, -2} ~3e-6 of the output range
+    assert d <= (2e-5 if m == 4 else 5e-6) * max(ref.abs().max().item(), 1.0), d
     # and against the direct implicit-GEMM kernel of this library (same tolerance)
     direct = ops.pack_conv(wt, bias=b, pad=1, relu=True).to('cuda')
     xin = x.cuda() if s is None else ops.scale_channels(x.cuda(), s.cuda(), div)
@@ -46,7 +50,8 @@ def test_winograd_matches_direct(n, h, w, cin, cout, div, scaled):
     assert torch.equal(again, got)
 
 
-def test_winograd_bn_fold_and_device_count():
+@pytest.mark.parametrize('m', [4, 2])
+def test_winograd_bn_fold_and_device_count(m):
     from fgn_amd import ops
     g = torch.Generator().manual_seed(5)
     n, cin, cout = 40, 64, 64
@@ -54,7 +59,7 @@ def test_winograd_bn_fold_and_device_count():
     wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.06
     bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
               running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
-    layer = ops.pack_winograd(wt, bn=bn, relu=True).to('cuda')
+    layer = ops.pack_winograd(wt, bn=bn, relu=True, m=m).to('cuda')
     cnt = torch.tensor([23], dtype=torch.int32, device='cuda')
     got = ops.conv3x3_winograd(x.cuda(), layer, n_img_dev=cnt)
     y = F.conv2d(x.permute(0, 3, 1, 2), wt, padding=1)

@@ -16,7 +16,7 @@ from fgn_amd.weights import init_state_dict  # noqa: E402
 from oracle import fgn_ref_cpu as O  # noqa: E402
 
 names = [a for a in sys.argv[1:] if not a.startswith('--')] or ['cfg1', 'cfg2']
-wg = '--no-wg' not in sys.argv
+wg = False if '--no-wg' in sys.argv else 2 if '--wg2' in sys.argv else True
 for name in names:
     for seed in ((11, 12) if name != 'cfg3' else (21,)):
         if name == 'tiny':
@@ -30,7 +30,7 @@ for name in names:
         model = FGN(cfg['n_ways'], cfg['k_shots'], backbone=cfg['backbone'], rpn_head=cfg['rpn_head'],
                     roi_head=cfg['roi_head'], test_cfg=cfg['test_cfg'], state_dict=sd)
         model.use_winograd = wg
-        model.use_roi_commute = wg
+        model.use_roi_commute = bool(wg)
         model.debug_trace = {}
         got = model.simple_test(**batch, rescale=True)
         tr = model.debug_trace

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Kernel timeline of one steady-state episode of bench.py: bash tools/trace_episode.sh <tag> [bench args]
+set -euo pipefail
+TAG=${1:-tl}; shift || true
+: "${GRAFT_REPO_ROOT:?run on the GPU box}"
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/trace_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+rocprofv3 --kernel-trace --memory-copy-trace -d "$OUT/kt" --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
+python3 "$ROOT/tools/timeline.py" "$OUT/kt" > "$ROOT/gpurun_out/timeline_$TAG.txt"
+rm -rf "$OUT/kt"
+tail -1 "$OUT/bench.log" | cut -c1-200

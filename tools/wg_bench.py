@@ -14,7 +14,8 @@ for name, n, H, W, cin, cout, div in SHAPES:
     wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.02
     b = torch.randn(cout, generator=g)
     s = (torch.rand(n * div, cin, generator=g) + 0.5).cuda() if div > 1 else None
-    wg = ops.pack_winograd(wt, bias=b, relu=True).to('cuda')
+    wg = ops.pack_winograd(wt, bias=b, relu=True, m=2).to('cuda')
+    wg4 = ops.pack_winograd(wt, bias=b, relu=True, m=4).to('cuda')
     dr = ops.pack_conv(wt, bias=b, pad=1, relu=True).to('cuda')
     flop = 2.0 * n * div * H * W * cout * 9 * cin
 
@@ -24,8 +25,11 @@ for name, n, H, W, cin, cout, div in SHAPES:
 
     def wino():
         return ops.conv3x3_winograd(x, wg, in_scale=s, a_img_div=div)
+
+    def wino4():
+        return ops.conv3x3_winograd(x, wg4, in_scale=s, a_img_div=div)
     res = []
-    for fn in (direct, wino):
+    for fn in (direct, wino, wino4):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,5 +38,7 @@ for name, n, H, W, cin, cout, div in SHAPES:
             fn()
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 10)
-    err = (direct() - wino()).abs().max().item()
-    print(f'{name:8s} direct {res[0]:.3f} ms ({flop/res[0]/1e9:6.1f} TF)  winograd {res[1]:.3f} ms ({flop/res[1]/1e9:6.1f} TF eff)  maxdiff {err:.2e}', flush=True)
+    d = direct()
+    err, err4 = (d - wino()).abs().max().item(), (d - wino4()).abs().max().item()
+    print(f'{name:8s} direct {res[0]:.3f} ms ({flop/res[0]/1e9:6.1f} TF)  F(2x2) {res[1]:.3f} ms ({flop/res[1]/1e9:6.1f} TF eff) '
+          f'F(4x4) {res[2]:.3f} ms ({flop/res[2]/1e9:6.1f} TF eff)  maxdiff {err:.2e} / {err4:.2e} of {d.abs().max().item():.1f}', flush=True)
