@@ -21,6 +21,7 @@ one RCCL all-gather of fixed-size padded buffers.  Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -76,6 +77,9 @@ def parse_args():
                     help='off the timed path: compare this many episodes HIP vs the CPU oracle (matched-pair maxima, '
                          'agreement AP at IoU 0.5 / 0.75 / 0.95); 0 = reuse the CPU-baseline episodes')
     ap.add_argument('--inflight', type=int, default=1, help='episodes queued ahead of result packing per GPU')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='caller streams the steps alternate between: with 2, the low-occupancy tail of one episode '
+                         '(selection kernels, 100-RoI mask head) runs beside the backbone of the next')
     ap.add_argument('--graphs', action='store_true', help='replay one captured hipGraph per step instead of launching from Python '
                     '(same GPU time; host enqueue 0.2-0.8 ms instead of 1.4-2.4 ms)')
     ap.add_argument('--batch', type=int, default=1, help='episodes per step per GPU (the reference evaluates with '
@@ -172,15 +176,20 @@ def main():
 
     max_det = cfg['test_cfg']['rcnn']['max_per_img']
     comm_stream = torch.cuda.Stream()
+    ep_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else [None]
     gathered_last = {}
 
     def launch(i, profile=None):
         """Queue one step's device work (asynchronous): H2D of the episode, the whole path, D2H of the results."""
         e = episodes[i % n_distinct]
         ops.PROFILE = profile
+        st = ep_streams[i % len(ep_streams)]
+        ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
         try:
-            dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'],
-                                       support_code=e['code'], qry_isegmaps=e['qry_isegmaps'])
+            with ctx:
+                dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
+                                           e['img_shape'], support_code=e['code'], qry_isegmaps=e['qry_isegmaps'])
+                done = torch.cuda.current_stream().record_event()
         finally:
             ops.PROFILE = None
         if world > 1:
@@ -189,10 +198,10 @@ def main():
             # episode's kernels do not queue behind the collective, so a rank that runs a step late does not stall
             # the others' compute
             if model.use_graphs:      # replayed graphs reuse their output buffers: keep the gather in stream order
-                recs, cnts = fdist.pack_detections(dets, max_det)
-                gathered_last['g'] = fdist.gather_detections(recs, cnts)
+                with ctx:
+                    recs, cnts = fdist.pack_detections(dets, max_det)
+                    gathered_last['g'] = fdist.gather_detections(recs, cnts)
             else:
-                done = torch.cuda.current_stream().record_event()
                 comm_stream.wait_event(done)
                 with torch.cuda.stream(comm_stream):
                     recs, cnts = fdist.pack_detections(dets, max_det)
@@ -320,7 +329,7 @@ def main():
                        'h2d_in_step': not args.resident_inputs, 'h2d_bytes_per_step': h2d_bytes,
                        'gt_mask_rle_in_step': True, 'gt_masks_per_step': n_gt / args.steps,
                        'world_size_seen': world, 'collective_backend': backend if world > 1 else None,
-                       'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
+                       'caller_streams': args.streams, 'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
                        'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,
                        'avg_detections': n_d / args.steps / args.batch,

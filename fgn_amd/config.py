@@ -17,7 +17,7 @@ def fgn_r50_c4_config(n_ways: int = 3, k_shots: int = 3) -> dict:
         n_ways=n_ways,
         k_shots=k_shots,
         backbone=dict(
-            type='ResNet', depth=50,
+            type='ResNet', depth=50, block='bottleneck',
             # layer4 is deleted at run time (main.py:403-405); out_indices=(2,)
             stage_blocks=(3, 4, 6), stage_planes=(64, 128, 256),
             strides=(1, 2, 2), stem_channels=64, style='pytorch',
@@ -45,6 +45,24 @@ def fgn_r50_c4_config(n_ways: int = 3, k_shots: int = 3) -> dict:
             rcnn=dict(score_thr=0.05, nms_iou_threshold=0.5, max_per_img=100,
                       mask_thr_binary=0.5)),
     )
+
+
+def fgn_r18_c4_config(n_ways: int = 3, k_shots: int = 1) -> dict:
+    """cfg2 of BASELINE.json words the OMNIISEG case with a ResNet-18 backbone.  The reference has no such config
+    ("This file is for 50 layers ONLY", fgn_r50_c4_densecl.py:17-18; 1024 channels are hard-coded in its heads,
+    fgn_roi_head.py:210-213, 241-243), so this is a build extension without reference semantics:
+    mmdet's ResNet-18 (BasicBlock, stage_blocks (2, 2, 2), C4 = layer3 = 256 channels) with every head width taken
+    from the C4 width the way the R50 config takes it from 1024: RPN 256 -> 256, shared_head 256 -> 128 -> 256,
+    relation 512 -> 256 with GroupNorm(32, 256) (8 channels per group), box / mask heads on 256 channels."""
+    cfg = fgn_r50_c4_config(n_ways, k_shots)
+    cfg['backbone'].update(depth=18, block='basic', stage_blocks=(2, 2, 2), stage_planes=(64, 128, 256))
+    c = 256
+    cfg['rpn_head'].update(in_channels=c, feat_channels=c)
+    cfg['roi_head']['shared_head'].update(inplanes=c, planes=c // 2)
+    cfg['roi_head']['relation'].update(in_channels=2 * c, out_channels=c, gn_groups=32)
+    cfg['roi_head']['bbox_head'].update(in_channels=c)
+    cfg['roi_head']['mask_head'].update(in_channels=c, conv_out_channels=256)
+    return cfg
 
 
 def fgn_r50_c4_scratch_config(n_ways: int = 3, k_shots: int = 3) -> dict:

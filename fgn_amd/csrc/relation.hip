@@ -12,9 +12,9 @@
 // materialises the [R*N,2048,7,7] concat or the [R*N,1024,7,7] normalised tensor, and
 // writes 6 floats per (RoI, class).
 //
-// Mapping: one workgroup per RoI, 8 waves; a wave owns one GroupNorm group
-// (32 channels x 49 pixels = 1568 values = 24.5 per lane): lane = (pixel slot 0..7,
-// channel quad 0..7), 7 float4 per lane stay in registers across the N classes.
+// Mapping: one workgroup per RoI, 8 waves; a wave owns 32 consecutive channels (one GroupNorm
+// group of the reference's GN(32, 1024); 2 or 4 groups for narrower heads) x 49 pixels: lane = (pixel
+// slot 0..7, channel quad 0..7), 7 float4 per lane stay in registers across the N classes.
 // Statistics are two-pass in registers (mean, then centred sum of squares) with
 // wavefront xor-shuffle reductions.
 #include "common.h"
@@ -26,8 +26,18 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
     const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ rois,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ fcw,
     const float* __restrict__ fcb, float* __restrict__ cls_out, float* __restrict__ reg_out,
-    const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, float eps, float* __restrict__ rel_out) {
+    const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, int gw, float eps,
+    float* __restrict__ rel_out) {
     constexpr int P = 49;
+    // a wave covers 32 consecutive channels = 32 / gw GroupNorm groups (gw = channels per group: 8, 16 or 32);
+    // statistics are reduced over the lanes of one group: all 8 pixel slots (lane bits 3..5) and the channel
+    // quads of the group (lane bits below log2(gw / 4))
+    auto group_sum = [gw](float v) {
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1) v += __shfl_xor(v, off, 64);
+        for (int off = (gw >> 3); off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
     __shared__ float fc_acc[REL_WAVES][REL_MAX_N][6];
     const int r = blockIdx.x;
     int nr = n_rois;
@@ -40,8 +50,8 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
     for (int i = t; i < REL_WAVES * REL_MAX_N * 6; i += 64 * REL_WAVES) (&fc_acc[0][0][0])[i] = 0.f;
     __syncthreads();
 
-    const float inv_cnt = 1.f / (32.f * (float)P);
-    const int groups = C / 32;
+    const float inv_cnt = 1.f / ((float)gw * (float)P);
+    const int groups = C / 32;                 // 32-channel slabs, one per wave iteration
     for (int g = wv; g < groups; g += REL_WAVES) {
         const int c = g * 32 + quad * 4;
         float4 q[7];
@@ -53,9 +63,6 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
         }
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + c);
-        float4 fw[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const float4*>(fcw + (size_t)j * C + c);
 
         for (int n = 0; n < n_ways; ++n) {
             const float* Sn = S + ((size_t)(img * n_ways + n) * P) * C + c;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
                     x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            const float mean = wave_reduce_sum(sum) * inv_cnt;
+            const float mean = group_sum(sum) * inv_cnt;
             float sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
                     sq += (a * a + b * b) + (d * d + e * e);
                 }
             }
-            const float var = wave_reduce_sum(sq) * inv_cnt;
+            const float var = group_sum(sq) * inv_cnt;
             const float rstd = 1.f / sqrtf(var + eps);
             float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -111,7 +118,8 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
             pool.x *= ip; pool.y *= ip; pool.z *= ip; pool.w *= ip;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                float d = (pool.x * fw[j].x + pool.y * fw[j].y) + (pool.z * fw[j].z + pool.w * fw[j].w);
+                const float4 fwj = *reinterpret_cast<const float4*>(fcw + (size_t)j * C + c);   // 24 KB table: L1 / L2 hits
+                float d = (pool.x * fwj.x + pool.y * fwj.y) + (pool.z * fwj.z + pool.w * fwj.w);
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
                 d += __shfl_xor(d, 4, 64);
@@ -143,11 +151,13 @@ extern "C" int fgn_relation_gn_head_f32(const float* Q, const float* S, const fl
                                         float* rel_out_debug, hipStream_t stream) {
     if (!Q || !S || !rois || !gn_weight || !gn_bias || !fc_weight || !fc_bias || !cls_out || !reg_out)
         return FGN_ERR_ARG;
-    if (roi_size != 7 || gn_groups <= 0 || C != gn_groups * 32 || n_ways < 1 || n_ways > REL_MAX_N)
+    if (roi_size != 7 || gn_groups <= 0 || C % 32 != 0 || C % gn_groups != 0 || n_ways < 1 || n_ways > REL_MAX_N)
         return FGN_ERR_SHAPE;
+    const int gw = C / gn_groups;              // channels per GroupNorm group
+    if (gw != 8 && gw != 16 && gw != 32) return FGN_ERR_SHAPE;
     if (n_rois == 0) return FGN_OK;
     hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois), dim3(64 * REL_WAVES), 0, stream, Q, S, rois, gn_weight, gn_bias,
-                       fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, eps, rel_out_debug);
+                       fc_weight, fc_bias, cls_out, reg_out, n_rois_dev, n_rois, n_ways, C, gw, eps, rel_out_debug);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

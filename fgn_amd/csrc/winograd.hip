@@ -9,6 +9,7 @@
 // Tile t = (img * ty + y) * tx + x covers outputs [2y, 2y+2) x [2x, 2x+2); V / Mo are laid out
 // [16][t_pad][C] so each of the 16 positions is a contiguous row-major GEMM operand.
 #include "common.h"
+#include <cstdlib>
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -183,6 +184,7 @@ __device__ __forceinline__ void wg4_at(const float4 (&m)[6], float4 (&r)[4]) {
     r[3] = f4add(f4fma(-8.f, m[4], f4fma(0.125f, m[3], d12)), m[5]);
 }
 
+template <bool EAGER>
 __global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict__ x, const float4* __restrict__ in_scale,
                                                         float4* __restrict__ V, const int32_t* __restrict__ n_img_dev,
                                                         int n_img, int a_img_div, int H, int W, int C4, int ty, int tx,
@@ -200,20 +202,44 @@ __global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict
         const float4* src = x + (size_t)(img / a_img_div) * H * W * C4 + c;
         const int iy0 = 4 * yy - 1, ix0 = 4 * xx - 1;
         const float4 s = in_scale ? in_scale[(size_t)img * C4 + c] : make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 tt[6][6];                              // tt[a][b] = (B^T d)[a][b]
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const int ix = ix0 + b;
-            float4 d[6], rr[6];
+        float4 tt[6][6];
+        if (EAGER) {
+            // all 36 loads are issued before the first use (small layers are latency-bound: six dependent batches
+            // of six loads cost six memory round trips)
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const int iy = iy0 + a;
-                d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                           ? f4mul(src[((size_t)iy * W + ix) * C4], s) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            wg4_bt(d, rr);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) tt[a][b] = rr[a];
+                for (int b = 0; b < 6; ++b) {
+                    const int ix = ix0 + b;
+                    tt[a][b] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                                   ? src[((size_t)iy * W + ix) * C4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {             // tt[.][b] = B^T (d * s)[.][b], in place
+                float4 d[6], rr[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) d[a] = f4mul(tt[a][b], s);
+                wg4_bt(d, rr);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) tt[a][b] = rr[a];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int ix = ix0 + b;
+                float4 d[6], rr[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int iy = iy0 + a;
+                    d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                               ? f4mul(src[((size_t)iy * W + ix) * C4], s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                wg4_bt(d, rr);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) tt[a][b] = rr[a];
+            }
         }
         float4* dst = V + (size_t)t * C4 + c;
         const size_t gs = (size_t)t_pad * C4;
@@ -244,12 +270,17 @@ __global__ __launch_bounds__(256) void wg4_output_kernel(const float4* __restric
         if (img >= n_img) break;
         const float4* src = Mo + (size_t)t * C4 + c;
         const size_t gs = (size_t)t_pad * C4;
+        float4 mm[6][6];                               // all 36 loads in flight at once
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) mm[a][b] = src[(a * 6 + b) * gs];
         float4 st[4][6];                               // st[i][b] = (A^T m)[i][b]
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             float4 m[6], rr[4];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = src[(a * 6 + b) * gs];
+            for (int a = 0; a < 6; ++a) m[a] = mm[a][b];
             wg4_at(m, rr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) st[k][b] = rr[k];
@@ -281,9 +312,17 @@ extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, fl
     if (C % 4 != 0 || a_img_div < 1 || H < 1 || W < 1 || (long long)n_img * ty * tx > t_pad) return FGN_ERR_SHAPE;
     const long long total = (long long)n_img * ty * tx * (C / 4);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
-    FGN_LAUNCH_TIMED(wg4_input_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
-                     reinterpret_cast<const float4*>(in_scale), reinterpret_cast<float4*>(V), n_img_dev, n_img,
-                     a_img_div, H, W, C / 4, ty, tx, t_pad, total);
+    // small (latency-bound) layers issue all 36 loads first; large (bandwidth-bound) ones load column by column at twice
+    // the occupancy (measured, tools/wg4_ab.py: 10.3 -> 8.6 us on layer3, 39 -> 45 us on the AG-RPN map)
+    static const int eager_thr = getenv("FGN_WG4_EAGER") ? atoi(getenv("FGN_WG4_EAGER")) : 64000;
+    if (total < (long long)eager_thr)
+        FGN_LAUNCH_TIMED(wg4_input_kernel<true>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
+                         reinterpret_cast<const float4*>(in_scale), reinterpret_cast<float4*>(V), n_img_dev, n_img,
+                         a_img_div, H, W, C / 4, ty, tx, t_pad, total);
+    else
+        FGN_LAUNCH_TIMED(wg4_input_kernel<false>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
+                         reinterpret_cast<const float4*>(in_scale), reinterpret_cast<float4*>(V), n_img_dev, n_img,
+                         a_img_div, H, W, C / 4, ty, tx, t_pad, total);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

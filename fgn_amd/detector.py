@@ -44,13 +44,17 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
         if 'stage_blocks' in backbone:
             cfg['backbone'].update(backbone)
         else:   # mmdet ResNet dict (fgn_r50_c4_densecl.py:15-42); layer4 is dropped (main.py:403-405)
-            if backbone.get('depth', 50) != 50:
-                raise NotImplementedError('only ResNet-50-C4 backbones are built (both reference configs)')
+            depth = backbone.get('depth', 50)
+            if depth not in (18, 50):
+                raise NotImplementedError('ResNet-50-C4 (both reference configs) and the ResNet-18 extension are built')
             last = max(backbone.get('out_indices', (2,)))
             norm = backbone.get('norm_cfg', dict(type='BN'))
             if norm.get('type', 'BN') not in ('BN', 'GN'):
                 raise NotImplementedError(f"norm_cfg {norm.get('type')!r}")
-            cfg['backbone'].update(stage_blocks=_R50_BLOCKS[:last + 1],
+            if depth == 18 and (norm.get('type', 'BN') != 'BN' or backbone.get('deep_stem') or backbone.get('avg_down')):
+                raise NotImplementedError('ResNet-18 extension: frozen-BN BasicBlock stages only')
+            cfg['backbone'].update(depth=depth, block='basic' if depth == 18 else 'bottleneck')
+            cfg['backbone'].update(stage_blocks=((2, 2, 2, 2) if depth == 18 else _R50_BLOCKS)[:last + 1],
                                    stage_planes=(64, 128, 256, 512)[:last + 1],
                                    strides=tuple(backbone.get('strides', (1, 2, 2, 2)))[:last + 1],
                                    # fgn_r50_c4_scratch.py:16-23
@@ -130,6 +134,36 @@ class _Bottleneck:
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
+
+
+class _BasicBlock:
+    """mmdet BasicBlock of the ResNet-18 extension (config.fgn_r18_c4_config): conv3x3(stride)+BN+ReLU, conv3x3+BN,
+    + identity, ReLU.  conv1 takes the Winograd form when it has stride 1 and pays; conv2 carries the residual in
+    the epilogue of the direct kernel."""
+
+    def __init__(self, sd, prefix, stride, eps, winograd=0):
+        bn = lambda n: {k: sd[f'{prefix}.{n}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+        w1 = sd[prefix + '.conv1.weight']
+        self.conv1 = ops.pack_conv(w1, bn=bn('bn1'), stride=stride, pad=1, relu=True, eps=eps)
+        self.conv1_wg = ops.pack_winograd(w1, bn=bn('bn1'), relu=True, eps=eps, m=winograd) \
+            if winograd and stride == 1 and w1.shape[1] % 32 == 0 and w1.shape[0] % 4 == 0 else None
+        self.conv2 = ops.pack_conv(sd[prefix + '.conv2.weight'], bn=bn('bn2'), pad=1, relu=True, eps=eps)
+        self.down = None
+        if (prefix + '.downsample.0.weight') in sd:
+            dbn = {k: sd[f'{prefix}.downsample.1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+            self.down = ops.pack_conv(sd[prefix + '.downsample.0.weight'], bn=dbn, stride=stride, eps=eps)
+
+    def layers(self):
+        return [l for l in (self.conv1, self.conv1_wg, self.conv2, self.down) if l is not None]
+
+    def __call__(self, x, n_img_dev=None):
+        idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
+        wg = self.conv1_wg
+        if wg is not None and ops.winograd_pays(x.shape[0], x.shape[1], x.shape[2], wg.cin, wg.cout, wg.m):
+            y = ops.conv3x3_winograd(x, wg, n_img_dev=n_img_dev)
+        else:
+            y = ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
+        return ops.conv2d(y, self.conv2, residual=idt, n_img_dev=n_img_dev)   # relu(bn2(conv2) + identity)
 
 
 class _BottleneckGN:
@@ -319,8 +353,9 @@ class FGN(torch.nn.Module):
             P['stages'].append([
                 _BottleneckGN(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, bb.get('gn_groups', 32),
                               eps, bb.get('avg_down', False)) if gn else
-                _Bottleneck(sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps,
-                            winograd=self.use_winograd) for b in range(nblk)])
+                (_BasicBlock if bb.get('block', 'bottleneck') == 'basic' else _Bottleneck)(
+                    sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps, winograd=self.use_winograd)
+                for b in range(nblk)])
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
         wr = sd['rpn_head.rpn_conv.weight']
@@ -374,7 +409,7 @@ class FGN(torch.nn.Module):
                 return o.float().contiguous().to(device)
             if isinstance(o, (ops.ConvLayer, ops.WinogradLayer)):
                 return o.to(device)
-            if isinstance(o, _Bottleneck):
+            if isinstance(o, (_Bottleneck, _BasicBlock)):
                 for l in o.layers():
                     l.to(device)
                 return o

@@ -82,6 +82,17 @@ def _bottleneck(sd, g, prefix, cin, planes, cout, downsample):
         _bn(sd, g, prefix + '.downsample.1', cout, gamma_scale=0.7)
 
 
+def _basic_block(sd, g, prefix, cin, planes, downsample):
+    """mmdet BasicBlock (ResNet-18/34): two 3x3 convs, expansion 1."""
+    sd[prefix + '.conv1.weight'] = _kaiming(g, planes, cin, 3, 3)
+    _bn(sd, g, prefix + '.bn1', planes)
+    sd[prefix + '.conv2.weight'] = _kaiming(g, planes, planes, 3, 3)
+    _bn(sd, g, prefix + '.bn2', planes, gamma_scale=0.35)
+    if downsample:
+        sd[prefix + '.downsample.0.weight'] = _kaiming(g, planes, cin, 1, 1)
+        _bn(sd, g, prefix + '.downsample.1', planes, gamma_scale=0.7)
+
+
 def init_state_dict(cfg: dict, seed: int = 0) -> 'OrderedDict[str, torch.Tensor]':
     """Build a seeded fp32 state_dict for the model described by ``cfg``."""
     g = torch.Generator().manual_seed(seed)
@@ -97,10 +108,14 @@ def init_state_dict(cfg: dict, seed: int = 0) -> 'OrderedDict[str, torch.Tensor]
         sd['backbone.conv1.weight'] = _kaiming(g, stem, 3, 7, 7)
         (_gn if scratch else _bn)(sd, g, 'backbone.gn1' if scratch else 'backbone.bn1', stem)
     cin = stem
+    basic = bb.get('block', 'bottleneck') == 'basic'
     for li, (nblk, planes, stride) in enumerate(zip(bb['stage_blocks'], bb['stage_planes'], bb['strides'])):
-        cout = planes * 4
+        cout = planes if basic else planes * 4
         for b in range(nblk):
-            if scratch:
+            if basic:
+                _basic_block(sd, g, f'backbone.layer{li + 1}.{b}', cin, planes,
+                             downsample=(b == 0 and (stride != 1 or cin != planes)))
+            elif scratch:
                 _bottleneck_gn(sd, g, f'backbone.layer{li + 1}.{b}', cin, planes, cout, downsample=(b == 0),
                                pooled=bool(bb.get('avg_down')) and stride != 1)
             else:

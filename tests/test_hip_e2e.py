@@ -156,6 +156,22 @@ def test_e2e_full_width_reference_configs(name):
     assert agree['bbox_mAP50'] >= 0.9 and agree['segm_mAP50'] >= 0.9, agree
 
 
+def test_e2e_resnet18_extension_of_cfg2():
+    """cfg2 as BASELINE.json words it: OMNIISEG 3-way 1-shot, 256x256, ResNet-18 backbone.  A build extension (the
+    reference has no R18 config and hard-codes 1024-channel heads): BasicBlock stages, 256-channel
+    C4, heads at 256 channels, GroupNorm(32, 256) = 8 channels per group in the relation head; oracle and HIP path
+    share the definition (config.fgn_r18_c4_config), parity at north_star's tolerance."""
+    from fgn_amd.config import fgn_r18_c4_config
+    from fgn_amd.episodes import CONFIGS, make_batch
+    cfg = fgn_r18_c4_config(3, 1)
+    batch = make_batch(11, 2, **CONFIGS['cfg2'])
+    ref, tr_ref, got, tr = _run(cfg, batch)
+    r = tr_ref['qry_fmap']
+    assert tuple(r.shape[1:]) == (256, 16, 16)
+    assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg2 ResNet-18')
+
+
 def test_rccl_gather_single_rank():
     """The collective of the multi-GPU path (one all_gather_into_tensor of padded detection records) on
     the RCCL backend; one rank is all a 1-GPU box can host, the N>1 layout is covered by the gloo test."""

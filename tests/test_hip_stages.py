@@ -115,7 +115,10 @@ def test_ag_rpn_merge_matches_reference_golden(golden_dir):
 
 
 # ---------------------------------------------------------------- relation head
-def test_relation_head_matches_oracle():
+@pytest.mark.parametrize('gw', [32, 16, 8])
+def test_relation_head_matches_oracle(gw):
+    """gw = channels per GroupNorm group: 32 is the reference's GN(32, 1024); 16 / 8 are narrower heads (the
+    ResNet-18 variant of cfg2: GN(32, 256))."""
     from fgn_amd import ops
     from oracle import fgn_ref_cpu as O
     g = torch.Generator().manual_seed(5)
@@ -132,7 +135,7 @@ def test_relation_head_matches_oracle():
           'roi_head.bbox_head.fc_cls.bias': torch.randn(2, generator=g) * 0.1,
           'roi_head.bbox_head.fc_reg.weight': torch.randn(4, c, generator=g) * 0.1,
           'roi_head.bbox_head.fc_reg.bias': torch.randn(4, generator=g) * 0.1}
-    cfg = {'roi_head': {'relation': {'gn_groups': c // 32, 'gn_eps': 1e-5}}}
+    cfg = {'roi_head': {'relation': {'gn_groups': c // gw, 'gn_eps': 1e-5}}}
     rel = O.relation(feats, rois.numpy(), cat_mean, sd, cfg, n)
     ref_cls, ref_reg = O.bbox_head_forward(rel, sd)
     wq = ops.pack_conv(sd['roi_head.cls_reg_shared_conv.weight'][:, :c].contiguous()).to('cuda')
@@ -143,7 +146,7 @@ def test_relation_head_matches_oracle():
     fc_w = torch.cat([sd['roi_head.bbox_head.fc_cls.weight'], sd['roi_head.bbox_head.fc_reg.weight']]).cuda()
     fc_b = torch.cat([sd['roi_head.bbox_head.fc_cls.bias'], sd['roi_head.bbox_head.fc_reg.bias']]).cuda()
     cls, reg = ops.relation_gn_head(Q, S, rois.cuda(), sd['roi_head.cls_reg_shared_conv_norm.weight'].cuda(),
-                                    sd['roi_head.cls_reg_shared_conv_norm.bias'].cuda(), fc_w, fc_b, n, c // 32, 1e-5)
+                                    sd['roi_head.cls_reg_shared_conv_norm.bias'].cuda(), fc_w, fc_b, n, c // gw, 1e-5)
     _close(cls.cpu(), ref_cls, 2e-5)
     _close(reg.cpu(), ref_reg, 2e-5)
 

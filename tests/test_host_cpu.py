@@ -322,3 +322,25 @@ def test_ar_grouped_batching():
     for c in range(0, len(order), 2):            # every chunk holds one aspect-ratio group
         assert rounded[order[c]] == rounded[order[c + 1]] and groups[c] == groups[c + 1]
     assert (hws % 16 == 0).all() and hws.min() >= 800 - 8 and hws.max() <= 1344
+
+
+def test_resnet18_extension_config_weights_and_reference_style_dict():
+    """The R18 variant of cfg2 (BASELINE.json; no reference config exists): flat config, seeded weights in mmdet's
+    BasicBlock layout, the mmcv-style backbone dict (depth=18) normalises to the same flat config, and the oracle
+    runs it end to end."""
+    from fgn_amd.config import fgn_r18_c4_config
+    from fgn_amd.detector import normalise_config
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    from oracle import fgn_ref_cpu as O
+    cfg = fgn_r18_c4_config(3, 1)
+    sd = init_state_dict(cfg, 0)
+    assert sd['backbone.layer1.0.conv1.weight'].shape == (64, 64, 3, 3) and 'backbone.layer1.0.downsample.0.weight' not in sd
+    assert sd['backbone.layer3.0.downsample.0.weight'].shape == (256, 128, 1, 1) and 'backbone.layer3.2.conv1.weight' not in sd
+    assert sd['roi_head.cls_reg_shared_conv.weight'].shape == (256, 512, 1, 1)
+    assert sd['roi_head.shared_head.0.conv2.weight'].shape == (128, 128, 3, 3)
+    n = normalise_config(3, 1, backbone=dict(type='ResNet', depth=18, num_stages=4, out_indices=(2,), strides=(1, 2, 2, 2),
+                                             norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch'))
+    assert n['backbone']['block'] == 'basic' and n['backbone']['stage_blocks'] == (2, 2, 2)
+    out = O.simple_test(sd, cfg, **make_batch(2, 1, 3, 1, 96, 128, 64))
+    assert set(out[0]) >= {'dt_scores', 'dt_bboxes', 'dt_cat_ids', 'dt_isegmaps_rle', 'qry_isegmaps_rle'}
