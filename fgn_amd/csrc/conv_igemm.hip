@@ -732,6 +732,184 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent point-wise kernel: the 64x64 LDS-DMA kernel in MODE 1 (1x1 / stride 1 convolutions and the grouped
+// Winograd GEMM) with a workgroup that walks several output tiles (tile, tile + grid, ...).  These launches have
+// K of 256..1024, i.e. 8..32 K-tiles per output tile: in the one-tile-per-workgroup kernel every workgroup of a
+// round runs its prologue (index math, first DMA, its latency) and its epilogue (accumulators -> LDS -> 16 B
+// stores) at the same time as its neighbours, so the matrix pipe idles ~20 % of a launch.  Here the first K-tile of
+// the NEXT output tile is in flight (LDS stage 0) while the epilogue of the current one drains through stage 1, and
+// workgroups drift out of phase after their first tile.
+// LDS: [stage 0: 16 KB][stage 1: 16 KB][1 KB], the C tile of the epilogue (64 x 68 floats) lives in stage 1 + 1 KB.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
+    constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
+    constexpr int A_LD = 2, B_LD = 2;
+    constexpr int STAGE = (BM + BN) * BK;          // floats
+    constexpr int PITCH = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
+    int grp_valid = p.grp_valid;
+    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+
+    const int col4 = t & 7, row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const int KT = p.K / BK;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    // tile -> (m0, n0): XCD-contiguous runs of logical tiles (the grid is a multiple of 8), optional banded raster
+    const int nq = total_tiles >> 3, nr = total_tiles & 7;
+    auto coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
+        int tile_m = bid / p.n_tiles_n;
+        int tile_n = bid - tile_m * p.n_tiles_n;
+        if (p.band_nt > 0) {
+            const int per_grp = p.band_mt * p.n_tiles_n;
+            const int grp = bid / per_grp;
+            int r = bid - grp * per_grp;
+            const int per_band = p.band_mt * p.band_nt;
+            const int band = r / per_band;
+            r -= band * per_band;
+            const int mi = r / p.band_nt;
+            tile_m = grp * p.band_mt + mi;
+            tile_n = band * p.band_nt + (r - mi * p.band_nt);
+        }
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        if (m0 >= M) return false;
+        if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
+        return true;
+    };
+    // first tile of this workgroup that has work; the xcd/idx form needs tile < total_tiles
+    auto next_active = [&](int tile, int& m0, int& n0) -> int {
+        for (; tile < total_tiles; tile += gridDim.x)
+            if (coords(tile, m0, n0)) return tile;
+        return -1;
+    };
+
+    unsigned a_voff[A_LD], b_voff[B_LD];
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+        }
+        int b0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+        if (p.grp_rows) b0 += (m0 / p.grp_rows) * p.grp_w_stride * 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * 32 * p.K * 4);
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+        const unsigned ko = (unsigned)(kt * BK * 4);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * 32 * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        const unsigned sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * 32 * 128, b_voff[i] + ko);
+    };
+
+    const int frag_row = lane & 31, half = lane >> 5;
+    const int rswz = (frag_row >> 1) & 7;
+    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+    float* const cbase = smem + STAGE;              // stage 1 (+ 1 KB behind it)
+
+    int m0, n0;
+    int tile = next_active(blockIdx.x, m0, n0);
+    if (tile < 0) return;
+    set_offsets(m0, n0);
+    issue_tile(0, 0);
+
+    while (true) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves'); the same
+        // barrier orders the previous epilogue's reads of the C tile before this tile's DMA into stage 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int pc = ((kk * 2 + half) ^ rswz) * 4;
+                const float4 af = *reinterpret_cast<const float4*>(As + pc);
+                const float4 bf = *reinterpret_cast<const float4*>(Bs + pc);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+            }
+            // see conv_igemm_dma_kernel: reads of stage `cur` must have returned before the barrier is signalled
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        // both stages are free now.  Next output tile: its first K-tile goes to stage 0 while the epilogue below
+        // drains this tile through stage 1.
+        const int em0 = m0, en0 = n0;
+        int nm0 = 0, nn0 = 0;
+        const int next = next_active(tile + gridDim.x, nm0, nn0);
+        if (next >= 0) {
+            set_offsets(nm0, nn0);
+            issue_tile(0, 0);
+        }
+        {
+            float* cw = cbase + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
+        }
+        __syncthreads();
+        {
+            constexpr int C4 = BN / 4, RPP = 256 / C4;       // 16 float4 per row, 16 rows per pass
+            const int c4 = t % C4, rr = t / C4;
+            const int n = en0 + c4 * 4;
+            if (n < p.Cout) {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+                float4 res[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = em0 + rr + RPP * k;
+                    res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.residual && m < M) res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = rr + RPP * k;
+                    const int m = em0 + row;
+                    if (m >= M) continue;
+                    float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+                }
+            }
+        }
+        if (next < 0) break;
+        tile = next; m0 = nm0; n0 = nn0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
     int n_img = p.n_img;
@@ -764,6 +942,13 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
         }
         reinterpret_cast<float4*>(p.y)[i] = a;
     }
+}
+
+// persistent grid of conv_pw_persist_kernel: 4 workgroups per CU (the kernel's occupancy), a multiple of 8 (XCDs);
+// FGN_PW_PERSIST=0 turns the persistent kernel off (tuning aid, tools/)
+static int persist_blocks() {
+    static const int n = getenv("FGN_PW_PERSIST") ? atoi(getenv("FGN_PW_PERSIST")) : 1024;
+    return n / 8 * 8;
 }
 
 template <int BM, int BN, int WM, int WN, int MW>
@@ -802,7 +987,15 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
         if (cin4)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
-        else if (pw)
+        else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && persist_blocks() > 0 &&
+                 (int)grid.x > persist_blocks()) {
+            // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel)
+            static unsigned long long pk_ok = 0ull;
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
+            if (attr != hipSuccess) return (int)attr;
+            const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float) + 1024;
+            FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
+        } else if (pw)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 0>), grid, dim3(256), dlds, stream, p);

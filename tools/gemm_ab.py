@@ -13,16 +13,17 @@ def t(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 print('FGN_BAND_KB', os.environ.get('FGN_BAND_KB'))
-for name, n, tiles, cin, cout in (('agrpn', 3, 1050, 1024, 1024), ('sh300', 300, 16, 512, 512), ('sh100', 100, 16, 512, 512),
-                                  ('mask0', 100, 16, 1024, 256), ('mask1', 100, 16, 256, 256)):
+G = 36
+for name, n, tiles, cin, cout in (('agrpn', 3, 273, 1024, 1024), ('sh300', 300, 4, 512, 512), ('sh100', 100, 4, 512, 512),
+                                  ('mask0', 100, 4, 1024, 256), ('mask1', 100, 4, 256, 256)):
     t_pad = L.fgn_winograd_t_pad(n * tiles)
-    V = torch.randn(16, t_pad, cin, generator=g).cuda()
-    U = (torch.randn(16, (cout + 127) // 128 * 128, cin, generator=g) * 0.03).cuda()
-    Mo = torch.empty(16, t_pad, cout, device='cuda')
+    V = torch.randn(G, t_pad, cin, generator=g).cuda()
+    U = (torch.randn(G, (cout + 127) // 128 * 128, cin, generator=g) * 0.03).cuda()
+    Mo = torch.empty(G, t_pad, cout, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
-    fn = lambda: lib.check(L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], 16, st), 'g')
+    fn = lambda: lib.check(L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], G, st), 'g')
     ms = t(fn)
-    fl = 2.0 * 16 * n * tiles * cin * cout
+    fl = 2.0 * G * n * tiles * cin * cout
     print(f'wino gemm {name:6s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TF/s', flush=True)
 for name, n, cin, cout, res in (('relQ 1024>1024 R300', 300, 1024, 1024, False), ('conv3 512>1024 R300', 300, 512, 1024, True),
                                 ('conv1 1024>512 R300', 300, 1024, 512, False), ('conv3 R100', 100, 512, 1024, True),
