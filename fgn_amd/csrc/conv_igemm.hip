@@ -741,13 +741,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
 // stores) at the same time as its neighbours, so the matrix pipe idles ~20 % of a launch.  Here the first K-tile of
 // the NEXT output tile is in flight (LDS stage 0) while the epilogue of the current one drains through stage 1, and
 // workgroups drift out of phase after their first tile.
-// LDS: [stage 0: 16 KB][stage 1: 16 KB][1 KB], the C tile of the epilogue (64 x 68 floats) lives in stage 1 + 1 KB.
+// LDS: [stage 0: 16 KB][stage 1: 16 KB]; the C tile of the epilogue (64 x 64 floats) lives in stage 1: 32 KB per
+// workgroup, five workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
     constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
     constexpr int A_LD = 2, B_LD = 2;
     constexpr int STAGE = (BM + BN) * BK;          // floats
-    constexpr int PITCH = BN + 4;
+    constexpr int PITCH = BN;       // unpadded: ds_write_b32 halves and the 16-lane groups of ds_read_b128 hit distinct banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(256, 4) void conv_pw_persist_kernel(const ConvParam
     const int rswz = (frag_row >> 1) & 7;
     const float* const rd_a = smem + (wm * WM + frag_row) * BK;
     const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
-    float* const cbase = smem + STAGE;              // stage 1 (+ 1 KB behind it)
+    float* const cbase = smem + STAGE;              // stage 1
 
     int m0, n0;
     int tile = next_active(blockIdx.x, m0, n0);
@@ -944,7 +945,7 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
     }
 }
 
-// persistent grid of conv_pw_persist_kernel: 4 workgroups per CU (the kernel's occupancy), a multiple of 8 (XCDs);
+// persistent grid of conv_pw_persist_kernel: 4 workgroups per CU (measured best: 768 / 1024 / 1280 below), a multiple of 8 (XCDs);
 // FGN_PW_PERSIST=0 turns the persistent kernel off (tuning aid, tools/)
 static int persist_blocks() {
     static const int n = getenv("FGN_PW_PERSIST") ? atoi(getenv("FGN_PW_PERSIST")) : 1024;
@@ -993,7 +994,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
             static unsigned long long pk_ok = 0ull;
             attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
             if (attr != hipSuccess) return (int)attr;
-            const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float) + 1024;
+            const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float);
             FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
         } else if (pw)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
