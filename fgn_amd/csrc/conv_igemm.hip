@@ -744,6 +744,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
 // LDS: [stage 0: 16 KB][stage 1: 16 KB]; the C tile of the epilogue (64 x 64 floats) lives in stage 1: 32 KB per
 // workgroup, five workgroups per CU.
 // ------------------------------------------------------------------------------------------------
+// M16: the 32x32 wave tile as 2x2 tiles of v_mfma_f32_16x16x4_f32 (lane group g = lane>>4 reads the 16-byte chunk
+// 4*kk+g of its row: MFMA j contracts k in {j, 4+j, 8+j, 12+j} of the 16-deep step) instead of one
+// v_mfma_f32_32x32x2_f32 tile - same cycles per FLOP, a different power / clock point of the chip.
+template <bool M16>
 __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
     constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
     constexpr int A_LD = 2, B_LD = 2;
@@ -833,8 +837,13 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
 
     while (true) {
         f32x16 acc;
+        f32x4 acc4[2][2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves'); the same
         // barrier orders the previous epilogue's reads of the C tile before this tile's DMA into stage 1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -845,6 +854,29 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
             asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
+            if (M16) {
+                const int r16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float4 af[2], bf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = r16 + 16 * i;                       // row within the wave's 32
+                        const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
+                        af[i] = *reinterpret_cast<const float4*>(As + (row - frag_row) * BK + pc);
+                        bf[i] = *reinterpret_cast<const float4*>(Bs + (row - frag_row) * BK + pc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc4[i][j], 0, 0, 0);
+                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc4[i][j], 0, 0, 0);
+                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc4[i][j], 0, 0, 0);
+                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int pc = ((kk * 2 + half) ^ rswz) * 4;
@@ -854,6 +886,7 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+            }
             }
             // see conv_igemm_dma_kernel: reads of stage `cur` must have returned before the barrier is signalled
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -869,7 +902,18 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
             set_offsets(nm0, nn0);
             issue_tile(0, 0);
         }
-        {
+        if (M16) {
+            // 16x16 C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+            const int r16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* cw = cbase + (wm * WM + 16 * i + 4 * g16) * PITCH + wn * WN + 16 * j + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
+                }
+        } else {
             float* cw = cbase + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
@@ -952,6 +996,20 @@ static int persist_blocks() {
     return n / 8 * 8;
 }
 
+// split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
+static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
+    if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
+    if (Cout % 4) return 1;
+    const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
+    static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
+    if (forced > 0) return std::max(1, std::min(forced, KT / 2));
+    if (blocks >= 512 || KT < 8) return 1;
+    int s = (int)((1024 + blocks - 1) / blocks);
+    s = std::min(s, KT / 4);
+    s = std::min(s, 16);
+    return s < 2 ? 1 : s;
+}
+
 template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
@@ -992,10 +1050,16 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
                  (int)grid.x > persist_blocks()) {
             // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel)
             static unsigned long long pk_ok = 0ull;
-            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
+            static unsigned long long pk16_ok = 0ull;
+            static const int m16 = getenv("FGN_PW_M16") ? atoi(getenv("FGN_PW_M16")) : 1;   // measured: +3..5 % on the large GEMMs
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel<false>), &pk_ok);
+            if (attr == hipSuccess) attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel<true>), &pk16_ok);
             if (attr != hipSuccess) return (int)attr;
             const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float);
-            FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
+            if (m16)
+                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<true>, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
+            else
+                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<false>, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
         } else if (pw)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
@@ -1016,20 +1080,6 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     return FGN_OK;
 }
 
-// split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
-static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
-    if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
-    if (Cout % 4) return 1;
-    const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
-    static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
-    if (forced > 0) return std::max(1, std::min(forced, KT / 2));
-    if (blocks >= 512 || KT < 8) return 1;
-    int s = (int)((1024 + blocks - 1) / blocks);
-    s = std::min(s, KT / 4);
-    s = std::min(s, 16);
-    return s < 2 ? 1 : s;
-}
-
 // tile choice (measured on MI355X, tools/conv_bench.py): 64x64 everywhere, except when the 128x128 grid is one nearly
 // full round of 2 workgroups per CU (the 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per
 // MAC is worth ~8 %.  1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (tile_hint forces one; tests).
@@ -1045,8 +1095,8 @@ static int pick_tile(long long M, int Cout, bool has_residual, int tile_hint) {
 
 // Which kernel the dispatcher launches for a layer: tile * 10 + mode, mode 0 = LDS-DMA generic, 1 = LDS-DMA
 // point-wise, 2 = LDS-DMA stem, 3 = register-staged (fused input scale, or operands beyond the 2 GiB buffer
-// descriptors).  Lets a profiler attribute a launch to the kernel name rocprofv3 reports, e.g. 41 =
-// conv_igemm_dma_kernel<64, 64, 32, 32, 2, 4, 1>.
+// descriptors), 4 = conv_pw_persist_kernel (point-wise, more output tiles than resident workgroups).  Lets a profiler
+// attribute a launch to the kernel name rocprofv3 reports, e.g. 41 = conv_igemm_dma_kernel<64, 64, 32, 32, 2, 4, 1>.
 extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
                                     int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint) {
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -1061,6 +1111,10 @@ extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, 
     int mode = 3;
     if (use_dma && !has_in_scale)
         mode = cin4 ? 2 : (KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1) ? 1 : 0;
+    // point-wise launches with more 64x64 output tiles than resident workgroups run on conv_pw_persist_kernel
+    if (mode == 1 && tile == 4 && (Cout & 3) == 0 && persist_blocks() > 0 &&
+        ((M + 63) / 64) * cdiv(Cout, 64) > persist_blocks() && plan_splits(M, Cout, K / BK, tile_hint) == 1)
+        mode = 4;
     return tile * 10 + mode;
 }
 

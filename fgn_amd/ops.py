@@ -33,6 +33,8 @@ def kernel_name(kid: int) -> str:
     """fgn_conv2d_kernel_id -> the kernel name in a rocprofv3 kernel trace."""
     bm, bn, wm, wn, mw = _TILES[kid // 10]
     mode = kid % 10
+    if mode == 4:
+        return 'conv_pw_persist_kernel'
     if mode == 3:
         return f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, *, {mw}>'
     return f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, 2, {mw}, {mode}>'
@@ -387,9 +389,13 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
         shape = (n_img, H, W, cin, layer.cout, 3, 1)
         common = dict(n_img=n_img, n_img_dev=n_img_dev, shape=shape)
         kin, kout = ('wg4_input_kernel', 'wg4_output_kernel') if layer.m == 4 else ('wg_input_kernel', 'wg_output_kernel')
+        if layer.m == 4:     # the two template instances of the F(4x4) input transform (csrc/winograd.hip)
+            kin = 'wg4_input_kernel<true>' if n_img * tiles * (cin // 4) < 64000 else 'wg4_input_kernel<false>'
         prof.append(dict(kind='wg_in', kernel=kin, e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0,
                          **common))
-        prof.append(dict(kind='wg_gemm', kernel=kernel_name(41), e0=ev[1][0], e1=ev[1][1],
+        # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
+        gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 0)
+        prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, **common))
         prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
