@@ -402,6 +402,9 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
               f'flips {len(ma)}/{len(mb)}, max|d score| {ds:.2e}')
         assert ds <= TOL and len(ma) <= 2 and len(mb) <= 2      # tile partition differs with the batch: fp32 order
     del model
+    # ---- cfg4 against the oracle: a batch of two 800x1328 episodes, every matched pair within north_star's tolerance
+    ref, tr_ref, got, tr = _run(cfg, make_batch(40, 2, **CONFIGS['cfg4']))
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg4 batch 2')
     # ---- cfg5
     shape = CONFIGS['cfg5']
     cfg5 = with_caps(fgn_r50_c4_config(5, 5), rpn_max=RPN_MAX_PER_IMG['cfg5'])

@@ -1,4 +1,6 @@
 #!/bin/bash
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 # usage: tools_pmc.sh <letter> <tile> ; writes gpurun_out/pmc_<letter>_<tile>.txt
 L=$1; T=$2
 cd /tmp && export TMPDIR=/tmp
