@@ -409,6 +409,8 @@ def cpu_and_accuracy(args, cfg, sd, shape, model) -> dict:
         r = O.simple_test(sd, cfg, **b, trace=tr)
         if j < n_timed:
             cdt += time.perf_counter() - t0
+        if n_acc > n_timed:          # a long leg: show progress (a silent run looks hung to a job scheduler)
+            print(f'[accuracy] oracle episode {j + 1}/{n_acc}', file=sys.stderr, flush=True)
         batches.append(b)
         cpu_res.extend(r)
         cpu_tr.append({k: tr[k] for k in ('mask_prob',) if k in tr})

@@ -19,6 +19,8 @@ struct DetParams {
     float4* cand_boxes;      // scratch [cap] decoded boxes, candidate order (r*N+n)
     float4* sorted_nms_boxes;  // scratch [cap] offset boxes in score order
     float* det_bboxes;       // out [max_out][5]
+    float* mask_rois;        // optional out [max_out][5] = (img_index, x1, y1, x2, y2): the mask branch's bbox2roi (fgn_roi_head.py:654)
+    float img_index;
     int64_t* det_labels;     // out [max_out]
     int32_t* n_dets;         // out [1]
     float* dbg_scores;       // optional out [R][N+1] softmax scores, or null
@@ -157,6 +159,10 @@ __global__ __launch_bounds__(POST_THREADS) void det_post_kernel(const DetParams 
         p.det_bboxes[i * 5 + 2] = b.z; p.det_bboxes[i * 5 + 3] = b.w;
         p.det_bboxes[i * 5 + 4] = s;
         p.det_labels[i] = lab;
+        if (p.mask_rois) {
+            float* r = p.mask_rois + (size_t)i * 5;
+            r[0] = p.img_index; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+        }
     }
     if (t == 0) *p.n_dets = n_keep;
 }
@@ -168,7 +174,8 @@ extern "C" size_t fgn_det_post_scratch_bytes(int max_rois, int n_ways) {
 }
 
 extern "C" int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_raw,
-                                const int32_t* n_rois_dev, void* scratch, float* det_bboxes, int64_t* det_labels,
+                                const int32_t* n_rois_dev, void* scratch, float* det_bboxes, float* mask_rois_out, int img_index,
+                                int64_t* det_labels,
                                 int32_t* n_dets, float* dbg_scores, int n_rois, int n_ways, float img_h, float img_w,
                                 const float* means4, const float* stds4, float max_ratio, float score_thr,
                                 float iou_thr, int max_per_img, hipStream_t stream) {
@@ -182,7 +189,8 @@ extern "C" int fgn_det_post_f32(const float* rois, const float* cls_raw, const f
     p.rois = rois; p.cls_raw = cls_raw; p.reg_raw = reg_raw; p.n_rois_dev = n_rois_dev;
     p.cand_boxes = reinterpret_cast<float4*>(scratch);
     p.sorted_nms_boxes = p.cand_boxes + cap;
-    p.det_bboxes = det_bboxes; p.det_labels = det_labels; p.n_dets = n_dets; p.dbg_scores = dbg_scores;
+    p.det_bboxes = det_bboxes; p.mask_rois = mask_rois_out; p.img_index = (float)img_index;
+    p.det_labels = det_labels; p.n_dets = n_dets; p.dbg_scores = dbg_scores;
     p.n_rois = n_rois; p.N = n_ways; p.cap = cap; p.img_h = img_h; p.img_w = img_w;
     for (int i = 0; i < 4; ++i) { p.mean[i] = means4[i]; p.stdv[i] = stds4[i]; }
     p.max_ratio = max_ratio; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_per_img;

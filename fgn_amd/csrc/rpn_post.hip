@@ -65,6 +65,7 @@ struct ProposalParams {
     float4* sorted_boxes;    // scratch [B][cap]  decoded + filtered boxes in score order
     float* sorted_scores;    // scratch [B][cap]
     float* proposals;        // out [B][max_out][5]
+    float* rois;             // optional out [B*max_out][5] = (image index, x1, y1, x2, y2): bbox2roi (fgn_roi_head.py:556)
     int32_t* n_props;        // out [B]
     int32_t* dbg_topk_idx;   // optional out [B][cap] (selected anchor indices, sorted) or null
     int n_total, A, feat_w, stride;
@@ -112,15 +113,16 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
     // cap at 128 VGPRs).  h = high word of the composite key (= ~ordered(score)), the low word is
     // the anchor index i.  All digit passes are 32-bit: passes 7..4 walk h, passes 3..0 walk the
     // index among elements whose h equals the threshold.
+#define RPN_SWEEP_N 16    /* independent loads in flight per thread and batch: 4 memory round trips per sweep of 63 000 */
 #define RPN_SWEEP(BODY)                                                      \
-    for (int j0 = 0; j0 < RPN_EPT; j0 += 8) {                                \
+    for (int j0 = 0; j0 < RPN_EPT; j0 += RPN_SWEEP_N) {                      \
         if (j0 * POST_THREADS >= p.n_total) break;                           \
-        float sv[8];                                                         \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                   \
+        float sv[RPN_SWEEP_N];                                               \
+        _Pragma("unroll") for (int jj = 0; jj < RPN_SWEEP_N; ++jj) {         \
             const int ii = (j0 + jj) * POST_THREADS + t;                     \
             sv[jj] = ii < p.n_total ? scores[ii] : 0.f;                      \
         }                                                                    \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                   \
+        _Pragma("unroll") for (int jj = 0; jj < RPN_SWEEP_N; ++jj) {         \
             const uint32_t i = (uint32_t)((j0 + jj) * POST_THREADS + t);     \
             const bool in_range = i < (uint32_t)p.n_total;                   \
             const uint32_t h = ~f32_ordered(sv[jj]);                         \
@@ -336,6 +338,10 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
                 props[i * 5 + 0] = 0.f; props[i * 5 + 1] = 0.f; props[i * 5 + 2] = 0.f; props[i * 5 + 3] = 0.f;
                 props[i * 5 + 4] = 0.f;
             }
+            if (p.rois) {
+                float* r = p.rois + ((size_t)b * p.max_out + i) * 5;
+                r[0] = (float)b; r[1] = props[i * 5 + 0]; r[2] = props[i * 5 + 1]; r[3] = props[i * 5 + 2]; r[4] = props[i * 5 + 3];
+            }
         }
 
         __syncthreads();
@@ -353,7 +359,7 @@ extern "C" size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nm
 }
 
 extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float* base_anchors,
-                                     void* scratch, float* proposals, int32_t* n_props, int32_t* dbg_topk_idx,
+                                     void* scratch, float* proposals, float* rois_out, int32_t* n_props, int32_t* dbg_topk_idx,
                                      int batch, int feat_h, int feat_w, int n_anchors, int stride, float img_h,
                                      float img_w, const float* means4, const float* stds4, float max_ratio,
                                      int nms_pre, float min_bbox_size, float iou_thr, int max_per_img,
@@ -372,7 +378,7 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     p.base_anchors = reinterpret_cast<const float4*>(base_anchors);
     p.sorted_boxes = reinterpret_cast<float4*>(scratch);
     p.sorted_scores = reinterpret_cast<float*>(p.sorted_boxes + (size_t)batch * cap);
-    p.proposals = proposals; p.n_props = n_props; p.dbg_topk_idx = dbg_topk_idx;
+    p.proposals = proposals; p.rois = rois_out; p.n_props = n_props; p.dbg_topk_idx = dbg_topk_idx;
     p.A = n_anchors; p.feat_w = feat_w; p.stride = stride;
     p.nms_pre = n_sel; p.cap = cap;
     p.img_h = img_h; p.img_w = img_w;

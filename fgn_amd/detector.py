@@ -362,9 +362,15 @@ class FGN(torch.nn.Module):
         P['rpn_conv_wg'] = ops.pack_winograd(wr, bias=sd['rpn_head.rpn_conv.bias'], relu=True, m=self.use_winograd) \
             if self.use_winograd and wr.shape[1] % 32 == 0 and wr.shape[0] % 4 == 0 else None
         # objectness and delta 1x1 convs fused into one launch: channels [0,A) | [A,5A)
-        P['rpn_head'] = ops.pack_conv(
-            torch.cat([sd['rpn_head.rpn_cls.weight'], sd['rpn_head.rpn_reg.weight']], 0),
-            bias=torch.cat([sd['rpn_head.rpn_cls.bias'], sd['rpn_head.rpn_reg.bias']], 0))
+        # (zero rows pad the 5A = 75 channels to a multiple of 4: 16-byte epilogue stores and split-K become
+        # available to the launch; rpn_merge reads the first 5A channels of each pixel)
+        wh = torch.cat([sd['rpn_head.rpn_cls.weight'], sd['rpn_head.rpn_reg.weight']], 0)
+        bh = torch.cat([sd['rpn_head.rpn_cls.bias'], sd['rpn_head.rpn_reg.bias']], 0)
+        padc = (-wh.shape[0]) % 4
+        if padc:
+            wh = torch.cat([wh, wh.new_zeros((padc,) + tuple(wh.shape[1:]))], 0)
+            bh = torch.cat([bh, bh.new_zeros(padc)], 0)
+        P['rpn_head'] = ops.pack_conv(wh, bias=bh)
         P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
                        for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
         # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
@@ -436,17 +442,6 @@ class FGN(torch.nn.Module):
             for blk in stage:
                 x = blk(x)
         return x
-
-    @staticmethod
-    def _rois_of(boxes4, batch: int, dev):
-        """bbox2roi (fgn_roi_head.py:556, 654): boxes [B,n,4] -> RoIs [B*n,5] with the image index in column 0."""
-        n = boxes4.shape[1]
-        rois = ops.zeros((batch * n, 5), dev)
-        v = rois.view(batch, n, 5)
-        v[:, :, 1:] = boxes4
-        if batch > 1:
-            v[:, :, 0] = torch.arange(batch, device=dev, dtype=torch.float32)[:, None]
-        return rois
 
     def _shared_head(self, x, n_img_dev=None, y1=None):
         for bi, blk in enumerate(self._P['shared']):
@@ -720,10 +715,10 @@ class FGN(torch.nn.Module):
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
         if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
             raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
-        props, n_props = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
-                                           rp['target_means'], rp['target_stds'], tc['rpn']['nms_pre'],
-                                           tc['rpn']['min_bbox_size'], tc['rpn']['nms_iou_threshold'],
-                                           tc['rpn']['max_per_img'])
+        props, n_props, rois_all = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
+                                                     rp['target_means'], rp['target_stds'], tc['rpn']['nms_pre'],
+                                                     tc['rpn']['min_bbox_size'], tc['rpn']['nms_iou_threshold'],
+                                                     tc['rpn']['max_per_img'], with_rois=True)   # [B*R,5] = bbox2roi
         if not cached:
             main.wait_event(spp_ready)
         if tr is not None:
@@ -737,7 +732,6 @@ class FGN(torch.nn.Module):
         # computed too and dropped per image by det_post.
         rel, bh = rh['relation'], rh['bbox_head']
         R, D = props.shape[1], tc['rcnn']['max_per_img']
-        rois_all = self._rois_of(props[:, :, :4], B, dev)                         # [B*R,5]
         cnt_all = n_props[0:1] if B == 1 else None
         if g_map is None and P['sh0_lin'] is not None:
             g_map = ops.conv2d(qry_fmap, P['sh0_lin'])                                # [B,h,w,planes]
@@ -745,18 +739,18 @@ class FGN(torch.nn.Module):
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'], cnt_all)
-        dets, labs, n_dets = [], [], []
+        dets, labs, n_dets, mrois = [], [], [], []
         for i in range(B):                                                         # one selection workgroup per image
-            det, lab, n_det = ops.det_post(rois_all[i * R:(i + 1) * R], cls_raw[i * R * N:(i + 1) * R * N],
-                                           reg_raw[i * R * N:(i + 1) * R * N], N, ih, iw, bh['target_means'],
-                                           bh['target_stds'], tc['rcnn']['score_thr'],
-                                           tc['rcnn']['nms_iou_threshold'], D, n_props[i:i + 1])
-            dets.append(det); labs.append(lab); n_dets.append(n_det)
+            det, lab, n_det, mr = ops.det_post(rois_all[i * R:(i + 1) * R], cls_raw[i * R * N:(i + 1) * R * N],
+                                               reg_raw[i * R * N:(i + 1) * R * N], N, ih, iw, bh['target_means'],
+                                               bh['target_stds'], tc['rcnn']['score_thr'],
+                                               tc['rcnn']['nms_iou_threshold'], D, n_props[i:i + 1], img_index=i)
+            dets.append(det); labs.append(lab); n_dets.append(n_det); mrois.append(mr)
         # ---- mask head on the detections of all images at once (fgn_roi_head.py:704-718, 360-382)
         det_all = dets[0] if B == 1 else torch.cat(dets)
         lab_all = labs[0] if B == 1 else torch.cat(labs)
         nd_all = n_dets[0] if B == 1 else None
-        mrois_all = self._rois_of(det_all[:, :4].reshape(B, D, 4), B, dev)         # [B*D,5]
+        mrois_all = mrois[0] if B == 1 else torch.cat(mrois)                       # [B*D,5] = bbox2roi of the detections
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
         _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
         mlog, mprob = self._mask_head(mf, vmask, nd_all)

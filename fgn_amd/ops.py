@@ -616,7 +616,9 @@ def rpn_merge(head: torch.Tensor, batch: int, n_ways: int, n_anchors: int):
 
 def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torch.Tensor, feat_h: int, feat_w: int,
                   stride: int, img_h: int, img_w: int, means, stds, nms_pre: int, min_bbox_size: float,
-                  iou_thr: float, max_per_img: int, debug_topk: bool = False):
+                  iou_thr: float, max_per_img: int, debug_topk: bool = False, with_rois: bool = False):
+    """-> proposals [B,max_per_img,5] (x1,y1,x2,y2,score), n_props [B] int32 (+ with_rois: the same boxes as
+    [B*max_per_img,5] RoIs (image index, box) = bbox2roi, fgn_roi_head.py:556)."""
     _chk(scores, 'scores')
     _chk(deltas, 'deltas')
     _chk(anchors_base, 'anchors_base')
@@ -628,23 +630,28 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
     scratch = torch.empty(L.fgn_rpn_proposals_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
                           dtype=torch.uint8)
     props = torch.empty((batch, max_per_img, 5), device=scores.device, dtype=torch.float32)
+    rois = torch.empty((batch * max_per_img, 5), device=scores.device, dtype=torch.float32)   # bbox2roi of the proposals
     n_props = zeros((batch,), scores.device, torch.int32)
     dbg = None
     if debug_topk:
         dbg = torch.full((batch, 8192), -1, device=scores.device, dtype=torch.int32)
     rc = L.fgn_rpn_proposals_f32(_ptr(scores), _ptr(deltas), _ptr(anchors_base), _ptr(scratch), _ptr(props),
-                                 _ptr(n_props), _ptr(dbg), batch, feat_h, feat_w, a, stride, float(img_h),
+                                 _ptr(rois), _ptr(n_props), _ptr(dbg), batch, feat_h, feat_w, a, stride, float(img_h),
                                  float(img_w), _f4(means), _f4(stds), MAX_RATIO, nms_pre, float(min_bbox_size),
                                  float(iou_thr), max_per_img, _stream())
     _lib.check(rc, 'fgn_rpn_proposals_f32')
     if debug_topk:
         return props, n_props, dbg
+    if with_rois:
+        return props, n_props, rois
     return props, n_props
 
 
 def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n_ways: int, img_h: int, img_w: int,
              means, stds, score_thr: float, iou_thr: float, max_per_img: int,
-             n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False):
+             n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False, img_index: Optional[int] = None):
+    """-> det [max_per_img,5], labels, n_det (+ with ``img_index``: mask RoIs [max_per_img,5] = (img_index, box), the
+    mask branch's bbox2roi, fgn_roi_head.py:654)."""
     for t, nm in ((rois, 'rois'), (cls_raw, 'cls_raw'), (reg_raw, 'reg_raw')):
         _chk(t, nm)
     r = rois.shape[0]
@@ -655,13 +662,17 @@ def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n
     det = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32)
     lab = torch.empty((max_per_img,), device=rois.device, dtype=torch.int64)
     n_det = zeros((1,), rois.device, torch.int32)
+    mrois = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32) if img_index is not None else None
     dbg = torch.zeros((r, n_ways + 1), device=rois.device, dtype=torch.float32) if debug_scores else None
     rc = L.fgn_det_post_f32(_ptr(rois), _ptr(cls_raw), _ptr(reg_raw), _ptr(n_rois_dev), _ptr(scratch), _ptr(det),
-                            _ptr(lab), _ptr(n_det), _ptr(dbg), r, n_ways, float(img_h), float(img_w), _f4(means),
+                            _ptr(mrois), int(img_index or 0), _ptr(lab), _ptr(n_det), _ptr(dbg), r, n_ways,
+                            float(img_h), float(img_w), _f4(means),
                             _f4(stds), MAX_RATIO, float(score_thr), float(iou_thr), max_per_img, _stream())
     _lib.check(rc, 'fgn_det_post_f32')
     if debug_scores:
         return det, lab, n_det, dbg
+    if img_index is not None:
+        return det, lab, n_det, mrois
     return det, lab, n_det
 
 

@@ -156,8 +156,9 @@ int fgn_rpn_merge_f32(const float* head, float* logits, float* scores, float* de
  * top nms_pre -> delta2bbox -> min size -> NMS -> max_per_img.  proposals [B,max_per_img,5],
  * n_props [B]. scratch: fgn_rpn_proposals_scratch_bytes(). dbg_topk_idx optional [B,cap]. */
 size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre);
+/* rois_out (optional) [B*max_per_img,5]: the same boxes as (image index, x1, y1, x2, y2) = bbox2roi (fgn_roi_head.py:556) */
 int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float* base_anchors, void* scratch,
-                          float* proposals, int32_t* n_props, int32_t* dbg_topk_idx, int batch, int feat_h,
+                          float* proposals, float* rois_out, int32_t* n_props, int32_t* dbg_topk_idx, int batch, int feat_h,
                           int feat_w, int n_anchors, int stride, float img_h, float img_w,
                           const float* host_means4, const float* host_stds4, float max_ratio, int nms_pre,
                           float min_bbox_size, float iou_thr, int max_per_img, void* stream);
@@ -166,7 +167,9 @@ int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float*
  * (fgn_roi_head.py:302-326, 606-613). det_bboxes [max_per_img,5], det_labels int64 [max_per_img]. */
 size_t fgn_det_post_scratch_bytes(int max_rois, int n_ways);
 int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_raw, const int32_t* n_rois_dev,
-                     void* scratch, float* det_bboxes, int64_t* det_labels, int32_t* n_dets, float* dbg_scores,
+                     void* scratch, float* det_bboxes, float* mask_rois_out /* optional [max_per_img,5]: (img_index, box),
+                     the mask branch's bbox2roi, fgn_roi_head.py:654 */, int img_index, int64_t* det_labels, int32_t* n_dets,
+                     float* dbg_scores,
                      int n_rois, int n_ways, float img_h, float img_w, const float* host_means4,
                      const float* host_stds4, float max_ratio, float score_thr, float iou_thr, int max_per_img,
                      void* stream);
