@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -33,8 +34,8 @@ def kernel_name(kid: int) -> str:
     """fgn_conv2d_kernel_id -> the kernel name in a rocprofv3 kernel trace."""
     bm, bn, wm, wn, mw = _TILES[kid // 10]
     mode = kid % 10
-    if mode == 4:
-        return 'conv_pw_persist_kernel'
+    if mode == 4:      # template argument = MFMA shape (16x16x4 unless the tuning knob FGN_PW_M16=0 selects 32x32x2)
+        return 'conv_pw_persist_kernel<%s>' % ('false' if os.environ.get('FGN_PW_M16') == '0' else 'true')
     if mode == 3:
         return f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, *, {mw}>'
     return f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, 2, {mw}, {mode}>'
@@ -394,7 +395,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
         prof.append(dict(kind='wg_in', kernel=kin, e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0,
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
-        gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 0)
+        gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
         prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, **common))

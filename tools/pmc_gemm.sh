@@ -38,8 +38,10 @@ if d and 'flop_per_launch' in res: res['tflops_under_pmc'] = res['flop_per_launc
 if 'SQ_BUSY_CU_CYCLES' in res and res.get('SQ_VALU_MFMA_BUSY_CYCLES'):
     res['mfma_busy_over_busy_cu_cycles'] = res['SQ_VALU_MFMA_BUSY_CYCLES'] / res['SQ_BUSY_CU_CYCLES']
 if res.get('SQ_INSTS_MFMA') and d:
-    # 4 SIMDs x 256 CUs, 64 cycles per v_mfma_f32_32x32x2_f32
-    res['mfma_issue_cycles_per_simd'] = res['SQ_INSTS_MFMA'] * 64 / (256 * 4)
+    # 4 SIMDs x 256 CUs; 64 cycles per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32 (conv_pw_persist_kernel<true>)
+    cyc = 32 if '<true>' in res.get('kernel', '') else 64
+    res['mfma_cycles_per_instruction'] = cyc
+    res['mfma_issue_cycles_per_simd'] = res['SQ_INSTS_MFMA'] * cyc / (256 * 4)
     if 'GRBM_GUI_ACTIVE' in res:
         clk = res['GRBM_GUI_ACTIVE'] / 8 / (res.get('duration_us_p3', 0) * 1e-6) if res.get('duration_us_p3') else 0
         res['effective_clock_ghz_from_GRBM_GUI_ACTIVE'] = clk / 1e9
