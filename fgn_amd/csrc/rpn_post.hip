@@ -8,6 +8,7 @@
 // never leaves the GPU and never synchronises with the host: counts stay in device memory.
 // Compiled with -ffp-contract=off: fp32 op order is the oracle's.
 #include "post_common.h"
+#include <cstdlib>
 
 // head : [B*N][HW][CH] NHWC output of the fused 1x1 conv; channels [0,A) = objectness
 // logits, channels [A, 5A) = deltas (a*4+d).
@@ -68,6 +69,10 @@ struct ProposalParams {
     float* rois;             // optional out [B*max_out][5] = (image index, x1, y1, x2, y2): bbox2roi (fgn_roi_head.py:556)
     int32_t* n_props;        // out [B]
     int32_t* dbg_topk_idx;   // optional out [B][cap] (selected anchor indices, sorted) or null
+    // multi-workgroup pre-selection (rpn_hist16 / rpn_thresh / rpn_compact / rpn_ranksort kernels): the best
+    // pre_info[b][3] <= RPN_FAST_CAP keys of image b, sorted, in pre_sorted[b]; pre_info[b][4] = 1 when valid
+    const uint64_t* pre_sorted;   // [B][RPN_FAST_CAP] or null
+    const int32_t* pre_info;      // [B][8]: b1, count before b1, b2, candidate count, ok flag
     int n_total, A, feat_w, stride;
     int nms_pre, cap;        // cap = pow2 >= min(nms_pre, n_total)
     float img_h, img_w;
@@ -139,10 +144,13 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = attempt == 0 && n_sel_full > RPN_FAST_SEL;
         if (attempt == 1 && !(n_sel_full > RPN_FAST_SEL)) break;
-        const int n_sel = fast ? RPN_FAST_SEL : n_sel_full;
+        int n_sel = fast ? RPN_FAST_SEL : n_sel_full;
         const int cap = fast ? RPN_FAST_CAP : p.cap;
+        // attempt 0 from the multi-workgroup pre-selection: the keys arrive ranked, steps 1-2 and the sort are skipped
+        const bool pre = fast && p.pre_sorted && p.pre_info[b * 8 + 4] == 1;
+        if (pre) n_sel = min(p.pre_info[b * 8 + 3], n_sel_full);
         uint32_t kth_hi = 0xffffffffu, kth_lo = 0xffffffffu, kth_mask_hi = 0xffffffffu, kth_mask_lo = 0xffffffffu;
-        if (n_sel < p.n_total) {
+        if (!pre && n_sel < p.n_total) {
             uint32_t pre_hi = 0, msk_hi = 0, pre_lo = 0, msk_lo = 0;
             int k = n_sel;   // 1-based rank wanted
             for (int pass = 7; pass >= 0; --pass) {
@@ -223,8 +231,9 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         }
         // ---- 2. compaction of the selected keys into LDS (wave-aggregated), pad, sort ----------
         RPN_STAMP(2);
-        for (int i = t; i < cap; i += POST_THREADS) keys[i] = ~0ull;
-        {
+        for (int i = t; i < cap; i += POST_THREADS)
+            keys[i] = (pre && i < n_sel) ? p.pre_sorted[(size_t)b * RPN_FAST_CAP + i] : ~0ull;
+        if (!pre) {
             // each thread owns a contiguous output range found by one block scan: no atomics
             int mine = 0;
             RPN_SWEEP({
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         }
         __syncthreads();
         RPN_STAMP(3);
-        block_bitonic_sort(keys, cap);
+        if (!pre) block_bitonic_sort(keys, cap);
         RPN_STAMP(4);
 
         // ---- 3. decode (delta2bbox), min-size filter, order-preserving compaction --------------
@@ -351,15 +360,166 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
     RPN_STAMP(6);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Multi-workgroup pre-selection for attempt 0 of rpn_proposals_kernel (the single-workgroup radix select,
+// compaction and bitonic sort of ~63 000 scores were 90 us of that kernel's 170 us).  Two histogram levels over the
+// descending key h = ~ordered(score): bits [31:20], then bits [19:8] inside the level-1 threshold bin (sigmoid
+// scores saturate: at cfg3 2 855 keys share the 16 high bits at rank 1536, 83 share the 22 high bits):
+//   rpn_hist1    4096-bin histogram of h >> 20, privatised in LDS per workgroup, non-empty bins flushed with atomics
+//   rpn_hist2    every workgroup scans level 1 (first bin b1 whose cumulative count reaches RPN_FAST_SEL, count
+//                before it), then histograms (h >> 8) & 4095 of the keys in bin b1
+//   rpn_compact  every workgroup scans level 2 (first bin b2 that reaches the target); candidates = ALL keys with
+//                h >> 20 < b1, or == b1 and (h >> 8) & 4095 <= b2: a prefix of the ranking with >= RPN_FAST_SEL keys;
+//                more than RPN_FAST_CAP (ties / saturation inside 24 equal bits) -> not valid, the proposal kernel
+//                runs its own select; keys appended through a counter (order arbitrary)
+//   rpn_ranksort rank of every candidate = number of smaller keys (keys are unique: the anchor index is the low
+//                word) -> written at its rank: the exact sorted prefix the greedy NMS consumes
+// Integer work only: the same set and order the in-kernel path produces (tests/test_hip_stages.py, bit-exact).
+// ----------------------------------------------------------------------------------------------
+constexpr int RPN_BINS = 4096;
+constexpr int RPN_HIST_EPT = 1;                    // anchors per thread of the histogram / compaction kernels
+
+// first bin whose inclusive cumulative count reaches `want` (-1: none) and the count before it; whole workgroup
+__device__ inline void rpn_find_bin(const uint32_t* __restrict__ hist, int want, int base, int* wave_sums, int* out) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int PER = RPN_BINS / POST_THREADS;   // 4 consecutive bins per thread
+    const uint4 v = *reinterpret_cast<const uint4*>(hist + t * PER);
+    const int c[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    const int mine = c[0] + c[1] + c[2] + c[3];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (t == 0) { out[0] = -1; out[1] = 0; }
+    __syncthreads();
+    if (lane == 63) wave_sums[wv] = incl;
+    __syncthreads();
+    int before = base + incl - mine;
+    for (int w = 0; w < wv; ++w) before += wave_sums[w];
+    if (before < want && want <= before + mine) {   // exactly one thread holds the crossing
+        int cum = before;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (cum < want && want <= cum + c[j]) { out[0] = t * PER + j; out[1] = cum; }
+            cum += c[j];
+        }
+    }
+    __syncthreads();
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(POST_THREADS) void rpn_hist_kernel(const float* __restrict__ scores, uint32_t* __restrict__ hist1,
+                                                                uint32_t* __restrict__ hist2, int32_t* __restrict__ info,
+                                                                int n_total, int want) {
+    __shared__ uint32_t lh[RPN_BINS];
+    __shared__ int wave_sums[POST_WAVES];
+    __shared__ int found[2];
+    const int b = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < RPN_BINS; i += POST_THREADS) lh[i] = 0u;
+    int b1 = 0;
+    if (LEVEL == 2) {
+        rpn_find_bin(hist1 + (size_t)b * RPN_BINS, want, 0, wave_sums, found);
+        b1 = found[0];
+        if (blockIdx.x == 0 && t == 0) { info[b * 8 + 0] = found[0]; info[b * 8 + 1] = found[1]; }
+        if (b1 < 0) return;
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * (POST_THREADS * RPN_HIST_EPT) + t;
+#pragma unroll
+    for (int j = 0; j < RPN_HIST_EPT; ++j) {
+        const int i = i0 + j * POST_THREADS;
+        if (i < n_total) {
+            const uint32_t h = ~f32_ordered(scores[(size_t)b * n_total + i]);
+            if (LEVEL == 1) atomicAdd(&lh[h >> 20], 1u);
+            else if ((int)(h >> 20) == b1) atomicAdd(&lh[(h >> 8) & 4095u], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = (LEVEL == 1 ? hist1 : hist2) + (size_t)b * RPN_BINS;
+    for (int i = t; i < RPN_BINS; i += POST_THREADS)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+__global__ __launch_bounds__(POST_THREADS) void rpn_compact_kernel(const float* __restrict__ scores,
+                                                                   const uint32_t* __restrict__ hist2,
+                                                                   int32_t* __restrict__ info, int32_t* __restrict__ counter,
+                                                                   uint64_t* __restrict__ cand, int n_total, int want, int cap) {
+    __shared__ int wave_sums[POST_WAVES];
+    __shared__ int found[2];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int b1 = info[b * 8 + 0], before1 = info[b * 8 + 1];
+    if (b1 < 0) return;
+    rpn_find_bin(hist2 + (size_t)b * RPN_BINS, want, before1, wave_sums, found);
+    const int b2 = found[0];
+    if (b2 < 0) return;
+    // candidates = everything up to and including bin (b1, b2)
+    const int n_cand = found[1] + (int)hist2[(size_t)b * RPN_BINS + b2];
+    const bool ok = n_cand <= cap;
+    if (blockIdx.x == 0 && t == 0) { info[b * 8 + 2] = b2; info[b * 8 + 3] = n_cand; info[b * 8 + 4] = ok ? 1 : 0; }
+    if (!ok) return;
+    const int i0 = blockIdx.x * (POST_THREADS * RPN_HIST_EPT) + t;
+#pragma unroll
+    for (int j = 0; j < RPN_HIST_EPT; ++j) {
+        const int i = i0 + j * POST_THREADS;
+        if (i < n_total) {
+            const uint32_t h = ~f32_ordered(scores[(size_t)b * n_total + i]);
+            const int k1 = (int)(h >> 20), k2 = (int)((h >> 8) & 4095u);
+            if (k1 < b1 || (k1 == b1 && k2 <= b2)) {
+                const int pos = atomicAdd(&counter[b], 1);
+                if (pos < cap) cand[(size_t)b * cap + pos] = ((uint64_t)h << 32) | (uint32_t)i;
+            }
+        }
+    }
+}
+
+// 8 threads per candidate, each counting the smaller keys in its eighth of the list (n^2 = 2.5 M comparisons spread
+// over 64 workgroups; one thread per candidate took 68 us)
+constexpr int RANK_SPLIT = 8;
+__global__ __launch_bounds__(256) void rpn_ranksort_kernel(const uint64_t* __restrict__ cand, const int32_t* __restrict__ info,
+                                                           uint64_t* __restrict__ sorted, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);
+    const int b = blockIdx.y;
+    if (info[b * 8 + 4] != 1) return;
+    const int n = info[b * 8 + 3];
+    const int n4 = (n + 3) & ~3;
+    for (int j = threadIdx.x; j < n4; j += blockDim.x) keys[j] = j < n ? cand[(size_t)b * cap + j] : ~0ull;
+    __syncthreads();
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / RANK_SPLIT;      // candidate
+    const int part = threadIdx.x & (RANK_SPLIT - 1);
+    const uint64_t k = i < n ? keys[i] : 0ull;
+    int rank = 0;
+    // part p scans the 4-key groups p, p + 8, ...: the 8 lanes of a candidate read 8 different groups, the 8
+    // candidates of a wave read the same ones (broadcast)
+    for (int j = part * 4; j < n4; j += RANK_SPLIT * 4) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(keys + j);
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(keys + j + 2);
+        rank += (a.x < k) + (a.y < k) + (c.x < k) + (c.y < k);
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    rank += __shfl_xor(rank, 4, 64);
+    if (part == 0 && i < n) sorted[(size_t)b * cap + rank] = k;
+}
+
 extern "C" size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre) {
     int n_sel = nms_pre < n_total ? nms_pre : n_total;
     int cap = POST_THREADS;
     while (cap < n_sel) cap <<= 1;
-    return (size_t)batch * cap * (sizeof(float4) + sizeof(float));
+    const size_t base = ((size_t)batch * cap * (sizeof(float4) + sizeof(float)) + 255) / 256 * 256;
+    // pre-selection: candidate keys + sorted keys (the zeroed histograms / counters come in `pre_zeroed`)
+    return base + (size_t)batch * (2 * RPN_FAST_CAP * 8);
 }
 
+// zero-initialised workspace of the pre-selection per call: two 4096-bin histograms + info + counter per image
+extern "C" size_t fgn_rpn_proposals_zeroed_bytes(int batch) { return (size_t)batch * (2 * RPN_BINS * 4 + 64); }
+
 extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float* base_anchors,
-                                     void* scratch, float* proposals, float* rois_out, int32_t* n_props, int32_t* dbg_topk_idx,
+                                     void* scratch, void* pre_zeroed, float* proposals, float* rois_out, int32_t* n_props,
+                                     int32_t* dbg_topk_idx,
                                      int batch, int feat_h, int feat_w, int n_anchors, int stride, float img_h,
                                      float img_w, const float* means4, const float* stds4, float max_ratio,
                                      int nms_pre, float min_bbox_size, float iou_thr, int max_per_img,
@@ -389,6 +549,30 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     static unsigned long long lds_ok = 0ull;
     const hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(rpn_proposals_kernel), &lds_ok);
     if (attr != hipSuccess) return (int)attr;
+    p.pre_sorted = nullptr; p.pre_info = nullptr;
+    static const int multi = getenv("FGN_RPN_MULTI") ? atoi(getenv("FGN_RPN_MULTI")) : 1;   // 0: single-workgroup path only
+    if (multi && pre_zeroed && n_sel > RPN_FAST_SEL && p.n_total > RPN_FAST_CAP) {
+        unsigned char* z = reinterpret_cast<unsigned char*>(pre_zeroed);
+        uint32_t* hist1 = reinterpret_cast<uint32_t*>(z);
+        uint32_t* hist2 = hist1 + (size_t)batch * RPN_BINS;
+        int32_t* info = reinterpret_cast<int32_t*>(hist2 + (size_t)batch * RPN_BINS);
+        int32_t* counter = info + batch * 8;
+        unsigned char* base = reinterpret_cast<unsigned char*>(scratch) +
+                              ((size_t)batch * cap * (sizeof(float4) + sizeof(float)) + 255) / 256 * 256;
+        uint64_t* candk = reinterpret_cast<uint64_t*>(base);
+        uint64_t* sortedk = candk + (size_t)batch * RPN_FAST_CAP;
+        const dim3 ga(cdiv(p.n_total, POST_THREADS * RPN_HIST_EPT), batch);
+        hipLaunchKernelGGL(rpn_hist_kernel<1>, ga, dim3(POST_THREADS), 0, stream, scores, hist1, hist2, info, p.n_total,
+                           RPN_FAST_SEL);
+        hipLaunchKernelGGL(rpn_hist_kernel<2>, ga, dim3(POST_THREADS), 0, stream, scores, hist1, hist2, info, p.n_total,
+                           RPN_FAST_SEL);
+        hipLaunchKernelGGL(rpn_compact_kernel, ga, dim3(POST_THREADS), 0, stream, scores, hist2, info, counter, candk,
+                           p.n_total, RPN_FAST_SEL, RPN_FAST_CAP);
+        hipLaunchKernelGGL(rpn_ranksort_kernel, dim3(RPN_FAST_CAP * RANK_SPLIT / 256, batch), dim3(256), RPN_FAST_CAP * 8, stream,
+                           candk, info, sortedk, RPN_FAST_CAP);
+        FGN_LAUNCH_CHECK();
+        p.pre_sorted = sortedk; p.pre_info = info;
+    }
     hipLaunchKernelGGL(rpn_proposals_kernel, dim3(batch), dim3(POST_THREADS), lds, stream, p);
     FGN_LAUNCH_CHECK();
     return FGN_OK;

@@ -667,6 +667,10 @@ class FGN(torch.nn.Module):
             with torch.cuda.stream(side):
                 sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, side)
                 vec_ready = side.record_event()
+                # count_spp (fgn_roi_head.py:419-449) follows at once: its ~30 tiny 9-RoI launches run beside the
+                # second half of the query backbone.  (Released later, at the AG-RPN conv, they were starved by that
+                # conv's persistent workgroups and the RoI head waited ~0.1 ms for them.)
+                self._support_back(sc, B, dev)
         vec = sc['vec']
 
         qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
@@ -690,18 +694,13 @@ class FGN(torch.nn.Module):
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)
 
-        # ---- count_spp (fgn_roi_head.py:419-449) on the side stream, released when the AG-RPN conv
-        # starts: its ~30 tiny 9-RoI launches (0.3 ms end to end, a handful of CUs each) hide under
-        # the 2 ms stream-K conv and the single-workgroup proposal kernel instead of delaying the
-        # query backbone or the RoI head
+        # ---- shared_head conv1 on the query map (see _roi_feats): independent of the proposals, so it runs on the
+        # side stream beside the AG-RPN transforms and the proposal kernels instead of after them
         g_map = None
         if not cached:
             with torch.cuda.stream(side):
-                side.wait_event(rpn_start)
-                self._support_back(sc, B, dev)
                 if P['sh0_lin'] is not None and side is not main:
-                    # shared_head conv1 on the query map (see _roi_feats): independent of the proposals, so it
-                    # runs here, beside the single-workgroup proposal kernel, instead of after it
+                    side.wait_event(rpn_start)
                     g_map = ops.conv2d(qry_fmap, P['sh0_lin'])
                 spp_ready = side.record_event()
             if not torch.cuda.is_current_stream_capturing():

@@ -42,7 +42,8 @@ SIGNATURES = {
     'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p, _p]),
     'fgn_rpn_merge_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'fgn_rpn_proposals_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
-    'fgn_rpn_proposals_f32': (_i, [_p] * 8 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
+    'fgn_rpn_proposals_zeroed_bytes': (C.c_size_t, [_i]),
+    'fgn_rpn_proposals_f32': (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
                                             _f, _i, _f, _f, _i, _p]),
     'fgn_det_post_scratch_bytes': (C.c_size_t, [_i, _i]),
     'fgn_det_post_f32': (_i, [_p] * 7 + [_i] + [_p] * 3 + [_i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f), _f, _f, _f, _i, _p]),
@@ -53,7 +54,7 @@ SIGNATURES = {
     'fgn_dense_mask_rle': (_i, [_p, _p, C.c_size_t, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

@@ -636,8 +636,11 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
     dbg = None
     if debug_topk:
         dbg = torch.full((batch, 8192), -1, device=scores.device, dtype=torch.int32)
-    rc = L.fgn_rpn_proposals_f32(_ptr(scores), _ptr(deltas), _ptr(anchors_base), _ptr(scratch), _ptr(props),
-                                 _ptr(rois), _ptr(n_props), _ptr(dbg), batch, feat_h, feat_w, a, stride, float(img_h),
+    # zero-filled workspace of the multi-workgroup pre-selection (histograms, counters): from the episode's zero arena
+    pre_zeroed = zeros((L.fgn_rpn_proposals_zeroed_bytes(batch),), scores.device, torch.uint8)
+    rc = L.fgn_rpn_proposals_f32(_ptr(scores), _ptr(deltas), _ptr(anchors_base), _ptr(scratch), _ptr(pre_zeroed),
+                                 _ptr(props), _ptr(rois), _ptr(n_props), _ptr(dbg), batch, feat_h, feat_w, a, stride,
+                                 float(img_h),
                                  float(img_w), _f4(means), _f4(stds), MAX_RATIO, nms_pre, float(min_bbox_size),
                                  float(iou_thr), max_per_img, _stream())
     _lib.check(rc, 'fgn_rpn_proposals_f32')

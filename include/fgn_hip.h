@@ -157,8 +157,12 @@ int fgn_rpn_merge_f32(const float* head, float* logits, float* scores, float* de
  * n_props [B]. scratch: fgn_rpn_proposals_scratch_bytes(). dbg_topk_idx optional [B,cap]. */
 size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre);
 /* rois_out (optional) [B*max_per_img,5]: the same boxes as (image index, x1, y1, x2, y2) = bbox2roi (fgn_roi_head.py:556) */
+/* pre_zeroed (optional): fgn_rpn_proposals_zeroed_bytes(batch) bytes of ZERO-FILLED device memory (fresh per call);
+ * when given, the top-k selection of the ~63 000 scores runs as multi-workgroup kernels in front of the proposal
+ * kernel (same result, bit for bit) */
+size_t fgn_rpn_proposals_zeroed_bytes(int batch);
 int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float* base_anchors, void* scratch,
-                          float* proposals, float* rois_out, int32_t* n_props, int32_t* dbg_topk_idx, int batch, int feat_h,
+                          void* pre_zeroed, float* proposals, float* rois_out, int32_t* n_props, int32_t* dbg_topk_idx, int batch, int feat_h,
                           int feat_w, int n_anchors, int stride, float img_h, float img_w,
                           const float* host_means4, const float* host_stds4, float max_ratio, int nms_pre,
                           float min_bbox_size, float iou_thr, int max_per_img, void* stream);
