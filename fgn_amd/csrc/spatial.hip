@@ -361,7 +361,7 @@ extern "C" int fgn_gather_support_vectors_f32(const float* table, const int64_t*
 }
 
 // out[n][p][c] = x[n / div][p][c] * v[n][c]: the AG-RPN guidance multiply materialised
-// (fgn_ag_rpn_head.py:44-46) so that the 3x3 RPN conv can run on the LDS-DMA stream-K kernel,
+// (fgn_ag_rpn_head.py:44-46) so that the 3x3 RPN conv can run on the LDS-DMA kernel when it does not take the Winograd form,
 // which has no register stage to scale in.  HBM-bound: 1 read of x per class + 1 write.
 __global__ void scale_channels_kernel(const float4* __restrict__ x, const float4* __restrict__ v,
                                       float4* __restrict__ out, int div, long long PC4, int C4, long long total) {

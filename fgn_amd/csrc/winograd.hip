@@ -2,7 +2,7 @@
 // enough to be MFMA-bound (AG-RPN conv, fgn_ag_rpn_head.py:48; the 3x3 of the shared_head bottlenecks,
 // fgn_roi_head.py:236).  The convolution becomes
 //     V = B^T d B   (input transform,  this file: HBM-bound, 16 B per lane)
-//     Mo[g] = V[g] U[g]^T, g = 0..15   (one grouped stream-K GEMM launch, conv_igemm.hip)
+//     Mo[g] = V[g] U[g]^T, g = 0..15 / 0..35   (one grouped GEMM launch, conv_igemm.hip)
 //     y = A^T Mo A + shift, ReLU       (output transform, this file)
 // with 2.25x fewer multiply-adds than the direct form.  fp32 throughout; F(2x2,3x3) uses only
 // +-1 and 1/2 coefficients, its rounding error stays within a few ulp of the direct sum.

@@ -135,7 +135,7 @@ int fgn_gather_support_vectors_f32(const float* table, const int64_t* labels, co
                                    const int32_t* n_dev, int n, int n_ways, int C, void* stream);
 
 /* out[n][p][c] = x[n / div][p][c] * v[n][c]  (guidance multiply, fgn_ag_rpn_head.py:44-46, materialised
- * for the stream-K conv kernel); x [n_out/div, P, C], v [n_out, C], out [n_out, P, C] */
+ * for the LDS-DMA conv kernel where a layer does not take the Winograd form); x [n_out/div, P, C], v [n_out, C], out [n_out, P, C] */
 int fgn_scale_channels_f32(const float* x, const float* v, float* out, int n_out, int div, int P, int C,
                            void* stream);
 

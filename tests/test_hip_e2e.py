@@ -218,7 +218,7 @@ def test_cfg3_full_size_parity_and_invariants():
     model.debug_trace = None
     again = model.simple_test(**batch, rescale=True)
     g = got[0]
-    # --- determinism: bit-identical results run to run (split-K / stream-K sums are order-fixed)
+    # --- determinism: bit-identical results run to run (split-K sums are order-fixed)
     for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
         assert np.array_equal(g[key], again[0][key]), key
     assert g['dt_isegmaps_rle'] == again[0]['dt_isegmaps_rle']
