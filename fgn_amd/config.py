@@ -2,8 +2,9 @@
 
 Plain-dict restatement of the constants the reference keeps in its mmcv config
 (reference: subprojects/sp02_omniiseg_fgn_mmdet/fgn_r50_c4_densecl.py:13-186).
-Only the fields the inference path reads are kept; training-only fields
-(assigners, samplers, losses) are out of scope.
+``train_cfg`` flattens the assigner / sampler dicts of fgn_r50_c4_densecl.py:131-171 (MaxIoUAssigner +
+RandomSampler for both stages); the loss types are the config's (sigmoid CE + SmoothL1(beta 1) for the
+AG-RPN, softmax CE + SmoothL1 for the box head, per-pixel BCE for the class-agnostic mask head).
 """
 from __future__ import annotations
 
@@ -44,6 +45,14 @@ def fgn_r50_c4_config(n_ways: int = 3, k_shots: int = 3) -> dict:
                      min_bbox_size=0),
             rcnn=dict(score_thr=0.05, nms_iou_threshold=0.5, max_per_img=100,
                       mask_thr_binary=0.5)),
+        train_cfg=dict(
+            rpn=dict(pos_iou_thr=0.5, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True,
+                     num=64, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False,
+                     allowed_border=0, pos_weight=-1),
+            rpn_proposal=dict(nms_pre=12000, max_per_img=2000, nms_iou_threshold=0.7, min_bbox_size=0),
+            rcnn=dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=True,
+                      num=128, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True,
+                      mask_size=14, pos_weight=-1)),
     )
 
 
