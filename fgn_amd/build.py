@@ -22,6 +22,7 @@ SOURCES = [
     ('rpn_post.hip', ['-ffp-contract=off']),
     ('det_post.hip', ['-ffp-contract=off']),
     ('mask.hip', ['-ffp-contract=off']),
+    ('train.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

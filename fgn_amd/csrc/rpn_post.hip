@@ -81,6 +81,59 @@ struct ProposalParams {
     int max_out;
 };
 
+
+// delta2bbox of anchor `idx` (mmdet 2.18 DeltaXYWHBBoxCoder.decode, fp32 op by op, clipped to the image) and the
+// min-size test of RPNHead._bbox_post_process
+__device__ __forceinline__ float4 rpn_decode_box(const ProposalParams& p, uint32_t idx, const float4* __restrict__ deltas,
+                                                 bool* ok) {
+    const int a = idx % p.A;
+    const int px = idx / p.A;
+    const int gx = px % p.feat_w, gy = px / p.feat_w;
+    const float4 ba = p.base_anchors[a];
+    const float sx = (float)(gx * p.stride), sy = (float)(gy * p.stride);
+    const float ax1 = ba.x + sx, ay1 = ba.y + sy, ax2 = ba.z + sx, ay2 = ba.w + sy;
+    const float4 d = deltas[idx];
+    const float dx = d.x * p.stdv[0] + p.mean[0];
+    const float dy = d.y * p.stdv[1] + p.mean[1];
+    float dw = d.z * p.stdv[2] + p.mean[2];
+    float dh = d.w * p.stdv[3] + p.mean[3];
+    const float pcx = (ax1 + ax2) * 0.5f, pcy = (ay1 + ay2) * 0.5f;
+    const float pw = ax2 - ax1, ph = ay2 - ay1;
+    const float dxw = pw * dx, dyh = ph * dy;
+    dw = fminf(fmaxf(dw, -p.max_ratio), p.max_ratio);
+    dh = fminf(fmaxf(dh, -p.max_ratio), p.max_ratio);
+    const float gcx = pcx + dxw, gcy = pcy + dyh;
+    const float gw = pw * exp32(dw), gh = ph * exp32(dh);
+    const float hw = gw * 0.5f, hh = gh * 0.5f;
+    float x1 = gcx - hw, y1 = gcy - hh, x2 = gcx + hw, y2 = gcy + hh;
+    x1 = fminf(fmaxf(x1, 0.f), p.img_w); x2 = fminf(fmaxf(x2, 0.f), p.img_w);
+    y1 = fminf(fmaxf(y1, 0.f), p.img_h); y2 = fminf(fmaxf(y2, 0.f), p.img_h);
+    *ok = p.min_size >= 0.f ? ((x2 - x1) > p.min_size) && ((y2 - y1) > p.min_size) : true;
+    return make_float4(x1, y1, x2, y2);
+}
+
+// proposals [max_out][5] (zero rows after the kept ones) and their bbox2roi form; whole workgroup
+__device__ __forceinline__ void rpn_write_outputs(const ProposalParams& p, int b, int n_keep, const int* keep,
+                                                  const float4* __restrict__ out_boxes,
+                                                  const float* __restrict__ out_scores) {
+    float* props = p.proposals + (size_t)b * p.max_out * 5;
+    for (int i = threadIdx.x; i < p.max_out; i += POST_THREADS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f;
+        if (i < n_keep) {
+            const int s = keep[i];
+            v = out_boxes[s];
+            sc = out_scores[s];
+        }
+        props[i * 5 + 0] = v.x; props[i * 5 + 1] = v.y; props[i * 5 + 2] = v.z; props[i * 5 + 3] = v.w;
+        props[i * 5 + 4] = sc;
+        if (p.rois) {
+            float* r = p.rois + ((size_t)b * p.max_out + i) * 5;
+            r[0] = (float)b; r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w;
+        }
+    }
+}
+
 // diagnostic phase stamps (100 MHz realtime counter) written behind the top-k debug buffer
 #define RPN_STAMP(slot)                                                                         \
     do {                                                                                        \
@@ -276,32 +329,9 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
             const uint64_t key = keys[i];
             const uint32_t idx = key_index(key);
             if (p.dbg_topk_idx) p.dbg_topk_idx[(size_t)b * 8192 + i] = (int32_t)idx;
-            const int a = idx % p.A;
-            const int px = idx / p.A;
-            const int gx = px % p.feat_w, gy = px / p.feat_w;
-            const float4 ba = p.base_anchors[a];
-            const float sx = (float)(gx * p.stride), sy = (float)(gy * p.stride);
-            const float ax1 = ba.x + sx, ay1 = ba.y + sy, ax2 = ba.z + sx, ay2 = ba.w + sy;
-            const float4 d = deltas[idx];
-            const float dx = d.x * p.stdv[0] + p.mean[0];
-            const float dy = d.y * p.stdv[1] + p.mean[1];
-            float dw = d.z * p.stdv[2] + p.mean[2];
-            float dh = d.w * p.stdv[3] + p.mean[3];
-            const float pcx = (ax1 + ax2) * 0.5f, pcy = (ay1 + ay2) * 0.5f;
-            const float pw = ax2 - ax1, ph = ay2 - ay1;
-            const float dxw = pw * dx, dyh = ph * dy;
-            dw = fminf(fmaxf(dw, -p.max_ratio), p.max_ratio);
-            dh = fminf(fmaxf(dh, -p.max_ratio), p.max_ratio);
-            const float gcx = pcx + dxw, gcy = pcy + dyh;
-            const float gw = pw * exp32(dw), gh = ph * exp32(dh);
-            const float hw = gw * 0.5f, hh = gh * 0.5f;
-            float x1 = gcx - hw, y1 = gcy - hh, x2 = gcx + hw, y2 = gcy + hh;
-            x1 = fminf(fmaxf(x1, 0.f), p.img_w); x2 = fminf(fmaxf(x2, 0.f), p.img_w);
-            y1 = fminf(fmaxf(y1, 0.f), p.img_h); y2 = fminf(fmaxf(y2, 0.f), p.img_h);
-            bx[j] = make_float4(x1, y1, x2, y2);
+            bool ok = false;
+            bx[j] = rpn_decode_box(p, idx, deltas, &ok);
             sc[j] = key_score(key);
-            bool ok = true;
-            if (p.min_size >= 0.f) ok = ((x2 - x1) > p.min_size) && ((y2 - y1) > p.min_size);
             if (ok) {
                 valid_bits |= 1 << j;
                 ++cnt;
@@ -336,22 +366,7 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
         RPN_STAMP(5);
         // ---- 4. greedy NMS, keep the first max_out -------------------------------------------------
         n_keep = nms_sorted_block(out_boxes, total_valid, p.iou_thr, p.max_out, keep, kept, cand, sup, flags);
-        float* props = p.proposals + (size_t)b * p.max_out * 5;
-        for (int i = t; i < p.max_out; i += POST_THREADS) {
-            if (i < n_keep) {
-                const int s = keep[i];
-                const float4 v = out_boxes[s];
-                props[i * 5 + 0] = v.x; props[i * 5 + 1] = v.y; props[i * 5 + 2] = v.z; props[i * 5 + 3] = v.w;
-                props[i * 5 + 4] = out_scores[s];
-            } else {
-                props[i * 5 + 0] = 0.f; props[i * 5 + 1] = 0.f; props[i * 5 + 2] = 0.f; props[i * 5 + 3] = 0.f;
-                props[i * 5 + 4] = 0.f;
-            }
-            if (p.rois) {
-                float* r = p.rois + ((size_t)b * p.max_out + i) * 5;
-                r[0] = (float)b; r[1] = props[i * 5 + 0]; r[2] = props[i * 5 + 1]; r[3] = props[i * 5 + 2]; r[4] = props[i * 5 + 3];
-            }
-        }
+        rpn_write_outputs(p, b, n_keep, keep, out_boxes, out_scores);
 
         __syncthreads();
         if (!fast || n_keep >= p.max_out) break;
@@ -574,6 +589,168 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
         p.pre_sorted = sortedk; p.pre_info = info;
     }
     hipLaunchKernelGGL(rpn_proposals_kernel, dim3(batch), dim3(POST_THREADS), lds, stream, p);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Proposal stage at TRAINING sizes (fgn.py:161-167 with train_cfg.rpn_proposal: nms_pre 12000, 2000 kept,
+// fgn_r50_c4_densecl.py:153-157): the candidate list no longer fits the LDS of one workgroup, so the ranking is a
+// global bitonic sort of all composite keys over many workgroups, and one workgroup per image then decodes the
+// first nms_pre of them chunk by chunk and runs the same greedy NMS with its kept list (<= 4096 boxes) in LDS.
+// Same keys, same decode arithmetic, same NMS routine as rpn_proposals_kernel: identical selections.
+//   rpn_keys_kernel        keys[b][i] = (~ordered(score) << 32) | i, padded with ~0 to n_pow2
+//   rpn_sort_local_kernel  FIRST: sorts each chunk of SORT_CH keys (all stages k <= SORT_CH);
+//                          otherwise finishes stage k with the strides j < SORT_CH in LDS
+//   rpn_sort_global_kernel one compare-exchange pass of stride j >= SORT_CH
+//   rpn_sorted_nms_kernel  decode + min-size filter + order-preserving compaction + greedy NMS + outputs
+// ----------------------------------------------------------------------------------------------
+constexpr int SORT_CH = 4096;
+
+__global__ __launch_bounds__(256) void rpn_keys_kernel(const float* __restrict__ scores, uint64_t* __restrict__ keys,
+                                                       int n_total, int n_pow2) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    keys[(size_t)b * n_pow2 + i] = i < n_total ? sort_key(scores[(size_t)b * n_total + i], (uint32_t)i) : ~0ull;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(POST_THREADS) void rpn_sort_local_kernel(uint64_t* __restrict__ keys, int n_pow2, int ch,
+                                                                     int k_stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(lds_raw);
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * n_pow2 + (size_t)blockIdx.x * ch;
+    const int g0 = blockIdx.x * ch;                       // global position of s[0]: decides the direction bits
+    for (int i = t; i < ch; i += POST_THREADS) s[i] = keys[base + i];
+    __syncthreads();
+    const int half = ch >> 1;
+    for (int k = FIRST ? 2 : k_stage; k <= (FIRST ? ch : k_stage); k <<= 1) {
+        for (int j = min(k >> 1, half); j >= 1; j >>= 1) {
+            for (int c = t; c < half; c += POST_THREADS) {
+                const int i = ((c / j) * (j << 1)) + (c % j);
+                const uint64_t a = s[i], bb = s[i + j];
+                const bool up = ((g0 + i) & k) == 0;
+                if ((a > bb) == up) { s[i] = bb; s[i + j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < ch; i += POST_THREADS) keys[base + i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void rpn_sort_global_kernel(uint64_t* __restrict__ keys, int n_pow2, int j, int k) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (n_pow2 >> 1)) return;
+    uint64_t* kb = keys + (size_t)blockIdx.y * n_pow2;
+    const int i = ((c / j) * (j << 1)) + (c % j);
+    const uint64_t a = kb[i], b = kb[i + j];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) { kb[i] = b; kb[i + j] = a; }
+}
+
+__global__ __launch_bounds__(POST_THREADS) void rpn_sorted_nms_kernel(const ProposalParams p, const uint64_t* __restrict__ sorted,
+                                                                     int n_pow2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int* misc = reinterpret_cast<int*>(lds_raw);                                   // [64]: wave sums, running offset
+    unsigned long long* sup = reinterpret_cast<unsigned long long*>(misc + 64);
+    NmsBox* kept = reinterpret_cast<NmsBox*>(sup + NMS_ROUND * NMS_WORDS);
+    NmsBox* cand = kept + p.max_out;
+    int* flags = reinterpret_cast<int*>(cand + NMS_ROUND);
+    int* keep = flags + NMS_ROUND + 2;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float4* deltas = p.deltas + (size_t)b * p.n_total;
+    const uint64_t* keys = sorted + (size_t)b * n_pow2;
+    const int n_sel = min(p.nms_pre, p.n_total);
+    float4* out_boxes = p.sorted_boxes + (size_t)b * p.cap;
+    float* out_scores = p.sorted_scores + (size_t)b * p.cap;
+    int total_valid = 0;
+    for (int c0 = 0; c0 < n_sel; c0 += POST_THREADS) {
+        const int i = c0 + t;
+        bool ok = false;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f;
+        if (i < n_sel) {
+            const uint64_t key = keys[i];
+            bx = rpn_decode_box(p, key_index(key), deltas, &ok);
+            sc = key_score(key);
+        }
+        const unsigned long long m = __ballot(ok);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) misc[wv] = __popcll(m);
+        __syncthreads();
+        int off = total_valid, chunk = 0;
+        for (int w = 0; w < POST_WAVES; ++w) {
+            const int sN = misc[w];
+            if (w < wv) off += sN;
+            chunk += sN;
+        }
+        if (ok) {
+            out_boxes[off + before] = bx;
+            out_scores[off + before] = sc;
+        }
+        total_valid += chunk;
+        __syncthreads();
+    }
+    const int n_keep = nms_sorted_block(out_boxes, total_valid, p.iou_thr, p.max_out, keep, kept, cand, sup, flags);
+    rpn_write_outputs(p, b, n_keep, keep, out_boxes, out_scores);
+    if (t == 0) p.n_props[b] = n_keep;
+}
+
+extern "C" size_t fgn_rpn_proposals_large_scratch_bytes(int batch, int n_total, int nms_pre) {
+    int n_pow2 = 2048;
+    while (n_pow2 < n_total) n_pow2 <<= 1;
+    const int n_sel = nms_pre > 0 && nms_pre < n_total ? nms_pre : n_total;
+    return (size_t)batch * ((size_t)n_pow2 * 8 + (size_t)n_sel * (sizeof(float4) + sizeof(float))) + 256;
+}
+
+extern "C" int fgn_rpn_proposals_large_f32(const float* scores, const float* deltas, const float* base_anchors,
+                                           void* scratch, float* proposals, float* rois_out, int32_t* n_props,
+                                           int batch, int feat_h, int feat_w, int n_anchors, int stride, float img_h,
+                                           float img_w, const float* means4, const float* stds4, float max_ratio,
+                                           int nms_pre, float min_bbox_size, float iou_thr, int max_per_img,
+                                           hipStream_t stream) {
+    if (!scores || !deltas || !base_anchors || !scratch || !proposals || !n_props || !means4 || !stds4)
+        return FGN_ERR_ARG;
+    ProposalParams p;
+    p.n_total = feat_h * feat_w * n_anchors;
+    if (p.n_total <= 0 || batch <= 0) return FGN_OK;
+    if (max_per_img < 1 || max_per_img > 4096) return FGN_ERR_SHAPE;     // kept list lives in LDS
+    const int n_sel = nms_pre > 0 && nms_pre < p.n_total ? nms_pre : p.n_total;
+    int n_pow2 = 2048;
+    while (n_pow2 < p.n_total) n_pow2 <<= 1;
+    const int ch = n_pow2 < SORT_CH ? n_pow2 : SORT_CH;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(scratch);
+    p.scores = scores; p.deltas = reinterpret_cast<const float4*>(deltas);
+    p.base_anchors = reinterpret_cast<const float4*>(base_anchors);
+    p.sorted_boxes = reinterpret_cast<float4*>(keys + (size_t)batch * n_pow2);
+    p.sorted_scores = reinterpret_cast<float*>(p.sorted_boxes + (size_t)batch * n_sel);
+    p.proposals = proposals; p.rois = rois_out; p.n_props = n_props; p.dbg_topk_idx = nullptr;
+    p.pre_sorted = nullptr; p.pre_info = nullptr;
+    p.A = n_anchors; p.feat_w = feat_w; p.stride = stride;
+    p.nms_pre = n_sel; p.cap = n_sel;
+    p.img_h = img_h; p.img_w = img_w;
+    for (int i = 0; i < 4; ++i) { p.mean[i] = means4[i]; p.stdv[i] = stds4[i]; }
+    p.max_ratio = max_ratio; p.min_size = min_bbox_size; p.iou_thr = iou_thr; p.max_out = max_per_img;
+    hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv(n_pow2, 256), batch), dim3(256), 0, stream, scores, keys, p.n_total,
+                       n_pow2);
+    const dim3 gl(n_pow2 / ch, batch);
+    hipLaunchKernelGGL(rpn_sort_local_kernel<true>, gl, dim3(POST_THREADS), (size_t)ch * 8, stream, keys, n_pow2, ch, 0);
+    for (int k = ch << 1; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j >= ch; j >>= 1)
+            hipLaunchKernelGGL(rpn_sort_global_kernel, dim3(cdiv(n_pow2 >> 1, 256), batch), dim3(256), 0, stream, keys,
+                               n_pow2, j, k);
+        hipLaunchKernelGGL(rpn_sort_local_kernel<false>, gl, dim3(POST_THREADS), (size_t)ch * 8, stream, keys, n_pow2,
+                           ch, k);
+    }
+    FGN_LAUNCH_CHECK();
+    const size_t lds = 64 * 4 + NMS_ROUND * NMS_WORDS * 8 + (size_t)max_per_img * sizeof(NmsBox) +
+                       NMS_ROUND * sizeof(NmsBox) + (NMS_ROUND + 2) * 4 + (size_t)max_per_img * 4;
+    static unsigned long long lds_ok = 0ull;
+    const hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(rpn_sorted_nms_kernel), &lds_ok);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(rpn_sorted_nms_kernel, dim3(batch), dim3(POST_THREADS), lds, stream, p, keys, n_pow2);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -37,7 +37,8 @@ from .weights import init_state_dict
 _R50_BLOCKS = (3, 4, 6, 3)
 
 
-def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=None, test_cfg=None) -> dict:
+def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=None, test_cfg=None,
+                     train_cfg=None) -> dict:
     """Accept either this package's flat dicts or the reference's mmcv config dicts."""
     cfg = _config.fgn_r50_c4_config(n_ways, k_shots)
     if backbone:
@@ -99,6 +100,21 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
             src = dict(test_cfg.get(part, {}))
             if 'nms' in src:
                 src['nms_iou_threshold'] = src.pop('nms')['iou_threshold']
+            t[part].update(src)
+    if train_cfg:
+        # mmdet layout (fgn_r50_c4_densecl.py:131-171): assigner / sampler sub-dicts are flattened
+        t = cfg['train_cfg']
+        for part in ('rpn', 'rcnn', 'rpn_proposal'):
+            src = dict(train_cfg.get(part, {}))
+            for sub, typ in (('assigner', 'MaxIoUAssigner'), ('sampler', 'RandomSampler')):
+                d = dict(src.pop(sub, {}))
+                if d.pop('type', typ) != typ:
+                    raise NotImplementedError(f'train_cfg.{part}.{sub}: only {typ} (both reference configs)')
+                d.pop('ignore_iof_thr', None)
+                src.update(d)
+            if 'nms' in src:
+                src['nms_iou_threshold'] = src.pop('nms')['iou_threshold']
+            src.pop('debug', None)
             t[part].update(src)
     return cfg
 
@@ -268,12 +284,13 @@ class FGN(torch.nn.Module):
         if type not in (None, 'FGN'):
             raise ValueError(f'cannot build detector type {type!r}')
         self.n_ways, self.k_shots = int(n_ways), int(k_shots)
-        self.cfg = normalise_config(self.n_ways, self.k_shots, backbone, rpn_head, roi_head, test_cfg)
+        self.cfg = normalise_config(self.n_ways, self.k_shots, backbone, rpn_head, roi_head, test_cfg, train_cfg)
         self.train_cfg = train_cfg
         self.test_cfg = self.cfg['test_cfg']
         self._sd = OrderedDict((k, v.detach().float().cpu()) for k, v in
                                (state_dict if state_dict is not None else init_state_dict(self.cfg, seed)).items())
         self._packed_device = None
+        self._PT = None                           # train-mode layers of the shared head (fgn_amd.train.pack_train)
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
         self.use_side_stream = True               # support branch on a second HIP stream
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
@@ -297,6 +314,7 @@ class FGN(torch.nn.Module):
         if m != self._use_winograd:               # the packed layers (and any captured graph) depend on it
             self._use_winograd = m
             self._packed_device = None
+            self._PT = None
             self._graphs = {}
 
     @classmethod
@@ -322,6 +340,7 @@ class FGN(torch.nn.Module):
                     raise ValueError(f'shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._sd[k].shape)}')
                 self._sd[k] = sd[k].detach().float().cpu()
         self._packed_device = None
+        self._PT = None
         self._graphs = {}
 
     def _pack(self, device):
@@ -481,9 +500,16 @@ class FGN(torch.nn.Module):
             return self.forward_train(**kwargs)
         return self.simple_test(**kwargs)
 
-    def forward_train(self, **kwargs):
-        raise NotImplementedError('training (fgn.py:125-185) is outside the accelerated path; '
-                                  'train with the reference and load the checkpoint here')
+    @torch.no_grad()
+    def forward_train(self, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bboxes_ignore=None, proposals=None,
+                      spp_imgs=None, spp_bboxes=None, spp_isegmaps=None, img_shape=None, **kwargs) -> Dict:
+        """The loss dict of one training step (fgn.py:125-185) as forward values - see ``fgn_amd.train``.  Keys and
+        container types are the reference's: ``loss_rpn_cls`` / ``loss_rpn_bbox`` (lists of one tensor),
+        ``loss_cls``, ``ACC-Unbalanced``, ``ACC-Balanced``, ``loss_bbox``, ``loss_mask``."""
+        from . import train
+        return train.forward_train(self, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps,
+                                   qry_bboxes_ignore=qry_bboxes_ignore, proposals=proposals, spp_imgs=spp_imgs,
+                                   spp_bboxes=spp_bboxes, spp_isegmaps=spp_isegmaps, img_shape=img_shape, **kwargs)
 
     @torch.no_grad()
     def simple_test(self, qry_img, qry_bboxes=None, qry_cat_ids=None, qry_isegmaps=None, qry_bboxes_ignore=None,
@@ -513,8 +539,9 @@ class FGN(torch.nn.Module):
         vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
         return dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp_fmaps=spp_fmaps, vec=vec)
 
-    def _support_back(self, sc: dict, B, dev) -> None:
-        """count_spp (fgn_roi_head.py:419-449) and the support half of the relation conv."""
+    def _support_back(self, sc: dict, B, dev, shared=None) -> None:
+        """count_spp (fgn_roi_head.py:419-449) and the support half of the relation conv.  ``shared``: the shared-head
+        callable (forward_train passes the train-mode BatchNorm variant)."""
         P, rh = self._P, self.cfg['roi_head']
         N, K, PS = self.n_ways, self.k_shots, rh['roi_out_size']
         bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
@@ -522,7 +549,7 @@ class FGN(torch.nn.Module):
         sc['masks7'] = ops.roi_align_mask(sc['spp_masks'], spp_rois, PS, 1.0, -1, False)
         # `spp_bboxes /= 16` then roi_align(scale=1) == roi_align(scale=1/16): /16 is exact in fp32
         sfeat = ops.roi_align(sc['spp_fmaps'], spp_rois, PS, 1.0 / rh['featmap_stride'], -1, False)
-        sfeat = self._shared_head(sfeat)
+        sfeat = self._shared_head(sfeat) if shared is None else shared(sfeat)
         sc['cat_mean'] = ops.support_kmean(sfeat, B * N, K)                           # [B*N,7,7,C]
         sc['cat_mean_mp'] = ops.support_class_vectors(sfeat, sc['masks7'], B * N, K)  # [B*N,C]
         sc['S'] = ops.conv2d(sc['cat_mean'], P['rel_s'])                              # Ws*support + bias

@@ -52,9 +52,20 @@ SIGNATURES = {
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_dense_rle_scratch_bytes': (C.c_size_t, [_i, _i, _i, _i]),
     'fgn_dense_mask_rle': (_i, [_p, _p, C.c_size_t, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'fgn_rpn_proposals_large_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_rpn_proposals_large_f32': (_i, [_p] * 7 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
+                                                  _f, _i, _f, _f, _i, _p]),
+    'fgn_box_assign_scratch_bytes': (C.c_size_t, [_i, _i]),
+    'fgn_box_assign_f32': (_i, [_p, _i, _p, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p]),
+    'fgn_bbox2delta_f32': (_i, [_p, _p, _p, _i, C.POINTER(_f), C.POINTER(_f), _p]),
+    'fgn_bce_logits_sum_f32': (_i, [_p, _p, _p, C.c_longlong, _f, C.c_double, _p, _p]),
+    'fgn_smooth_l1_sum_f32': (_i, [_p, _p, _p, C.c_longlong, _f, C.c_double, _p, _p]),
+    'fgn_softmax_ce_sum_f32': (_i, [_p, _p, _p, _i, _i, C.c_double, _p, _p]),
+    'fgn_bn_train_scratch_bytes': (C.c_size_t, [_i]),
+    'fgn_bn_train_f32': (_i, [_p, _i, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 

@@ -628,11 +628,22 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
     if n_total != feat_h * feat_w * a or tuple(deltas.shape) != (batch, n_total, 4):
         raise _lib.FgnHipError('rpn_proposals: operand shapes inconsistent')
     L = _lib.load()
-    scratch = torch.empty(L.fgn_rpn_proposals_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
-                          dtype=torch.uint8)
     props = torch.empty((batch, max_per_img, 5), device=scores.device, dtype=torch.float32)
     rois = torch.empty((batch * max_per_img, 5), device=scores.device, dtype=torch.float32)   # bbox2roi of the proposals
     n_props = zeros((batch,), scores.device, torch.int32)
+    n_sel = nms_pre if 0 < nms_pre < n_total else n_total
+    if (n_sel > 8192 or max_per_img > 1024) and not debug_topk:
+        # training sizes (train_cfg.rpn_proposal: 12000 -> 2000): the ranking runs as a global sort over many workgroups
+        scratch = torch.empty(L.fgn_rpn_proposals_large_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
+                              dtype=torch.uint8)
+        rc = L.fgn_rpn_proposals_large_f32(_ptr(scores), _ptr(deltas), _ptr(anchors_base), _ptr(scratch), _ptr(props),
+                                           _ptr(rois), _ptr(n_props), batch, feat_h, feat_w, a, stride, float(img_h),
+                                           float(img_w), _f4(means), _f4(stds), MAX_RATIO, nms_pre,
+                                           float(min_bbox_size), float(iou_thr), max_per_img, _stream())
+        _lib.check(rc, 'fgn_rpn_proposals_large_f32')
+        return (props, n_props, rois) if with_rois else (props, n_props)
+    scratch = torch.empty(L.fgn_rpn_proposals_scratch_bytes(batch, n_total, nms_pre), device=scores.device,
+                          dtype=torch.uint8)
     dbg = None
     if debug_topk:
         dbg = torch.full((batch, 8192), -1, device=scores.device, dtype=torch.int32)
@@ -758,3 +769,109 @@ def dense_mask_rle(masks: torch.Tensor):
     _lib.check(L.fgn_dense_mask_rle(_ptr(masks), _ptr(scratch), nbytes, _ptr(out), _ptr(lens), _ptr(ovf), n, h, w,
                                     RLE_TRANS_CAP, RLE_BYTE_CAP, _stream()), 'fgn_dense_mask_rle')
     return out, lens, ovf
+
+
+# --------------------------------------------------------------------------------------
+# forward_train pieces (csrc/train.hip)
+# --------------------------------------------------------------------------------------
+def box_assign(boxes: torch.Tensor, gts: torch.Tensor, pos_iou_thr: float, neg_iou_thr: float, min_pos_iou: float,
+               match_low_quality: bool = True, inside: Optional[torch.Tensor] = None, with_overlaps: bool = False):
+    """MaxIoUAssigner: boxes [n, >=4], gts [k,4] -> gt_inds [n] int32 (-2 not a candidate, -1 ignored, 0 negative,
+    i+1 positive of GT i) (+ max_overlaps [n])."""
+    _chk(boxes, 'boxes')
+    n, k = boxes.shape[0], gts.shape[0]
+    if k:
+        _chk(gts, 'gts')
+    if inside is not None:
+        _chk(inside, 'inside', torch.uint8)
+    L = _lib.load()
+    gt_inds = torch.empty((n,), device=boxes.device, dtype=torch.int32)
+    mo = torch.zeros((n,), device=boxes.device, dtype=torch.float32) if with_overlaps else None
+    scratch = torch.empty(L.fgn_box_assign_scratch_bytes(n, k), device=boxes.device, dtype=torch.uint8)
+    rc = L.fgn_box_assign_f32(_ptr(boxes), boxes.shape[1], _ptr(inside), _ptr(gts) if k else None, n, k,
+                              float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou), int(match_low_quality),
+                              _ptr(scratch), _ptr(gt_inds), _ptr(mo), _stream())
+    _lib.check(rc, 'fgn_box_assign_f32')
+    return (gt_inds, mo) if with_overlaps else gt_inds
+
+
+def bbox2delta(proposals: torch.Tensor, gts: torch.Tensor, means, stds) -> torch.Tensor:
+    _chk(proposals, 'proposals')
+    _chk(gts, 'gts')
+    n = proposals.shape[0]
+    if tuple(proposals.shape) != (n, 4) or tuple(gts.shape) != (n, 4):
+        raise _lib.FgnHipError('bbox2delta: operands must be [n,4]')
+    out = torch.empty((n, 4), device=proposals.device, dtype=torch.float32)
+    rc = _lib.load().fgn_bbox2delta_f32(_ptr(proposals), _ptr(gts), _ptr(out), n, _f4(means), _f4(stds), _stream())
+    _lib.check(rc, 'fgn_bbox2delta_f32')
+    return out
+
+
+def _loss_args(x, y, w):
+    _chk(x, 'pred')
+    _chk(y, 'target')
+    if x.numel() != y.numel():
+        raise _lib.FgnHipError('loss: pred / target sizes differ')
+    if w is not None:
+        _chk(w, 'weight')
+        if w.numel() != x.numel():
+            raise _lib.FgnHipError('loss: weight size differs')
+
+
+def bce_logits_sum(x, y, w, avg_factor: float, y_threshold: float = -1.0) -> torch.Tensor:
+    """sum_i w_i * BCEWithLogits(x_i, y_i) / avg_factor -> [1] (y binarised at y_threshold when >= 0)."""
+    _loss_args(x, y, w)
+    out = torch.empty((1,), device=x.device, dtype=torch.float32)
+    rc = _lib.load().fgn_bce_logits_sum_f32(_ptr(x), _ptr(y), _ptr(w), x.numel(), float(y_threshold),
+                                            float(avg_factor), _ptr(out), _stream())
+    _lib.check(rc, 'fgn_bce_logits_sum_f32')
+    return out
+
+
+def smooth_l1_sum(pred, target, w, avg_factor: float, beta: float = 1.0) -> torch.Tensor:
+    _loss_args(pred, target, w)
+    out = torch.empty((1,), device=pred.device, dtype=torch.float32)
+    rc = _lib.load().fgn_smooth_l1_sum_f32(_ptr(pred), _ptr(target), _ptr(w), pred.numel(), float(beta),
+                                           float(avg_factor), _ptr(out), _stream())
+    _lib.check(rc, 'fgn_smooth_l1_sum_f32')
+    return out
+
+
+def softmax_ce_sum(logits, labels, w, avg_factor: float) -> torch.Tensor:
+    _chk(logits, 'logits')
+    _chk(labels, 'labels', torch.int64)
+    n, c = logits.shape
+    if labels.numel() != n or (w is not None and w.numel() != n):
+        raise _lib.FgnHipError('softmax_ce_sum: operand sizes differ')
+    if w is not None:
+        _chk(w, 'weight')
+    out = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    rc = _lib.load().fgn_softmax_ce_sum_f32(_ptr(logits), _ptr(labels), _ptr(w), n, c, float(avg_factor), _ptr(out),
+                                            _stream())
+    _lib.check(rc, 'fgn_softmax_ce_sum_f32')
+    return out
+
+
+def bn_train(x: torch.Tensor, gamma, beta, eps: float, momentum: float, running_mean=None, running_var=None,
+             residual=None, relu: bool = False, inplace: bool = True):
+    """BatchNorm2d in training mode on NHWC x [..., C]: -> (y, batch mean [C], biased batch variance [C]); the
+    running estimates (optional) are updated in place."""
+    _chk(x, 'x')
+    c = x.shape[-1]
+    p = x.numel() // c
+    for t, nm in ((gamma, 'gamma'), (beta, 'beta'), (running_mean, 'running_mean'), (running_var, 'running_var'),
+                  (residual, 'residual')):
+        if t is not None:
+            _chk(t, nm)
+    if residual is not None and residual.numel() != x.numel():
+        raise _lib.FgnHipError('bn_train: residual shape differs')
+    L = _lib.load()
+    mean = torch.empty((c,), device=x.device, dtype=torch.float32)
+    var = torch.empty((c,), device=x.device, dtype=torch.float32)
+    out = x if inplace else torch.empty_like(x)
+    scratch = torch.empty(L.fgn_bn_train_scratch_bytes(c), device=x.device, dtype=torch.uint8)
+    rc = L.fgn_bn_train_f32(_ptr(x), p, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
+                            _ptr(running_var), _ptr(residual), int(relu), _ptr(scratch), _ptr(mean), _ptr(var),
+                            _ptr(out), _stream())
+    _lib.check(rc, 'fgn_bn_train_f32')
+    return out, mean, var

@@ -204,6 +204,49 @@ int fgn_dense_mask_rle(const uint8_t* masks, void* scratch, size_t scratch_bytes
                        int32_t* out_len, int32_t* overflow, int n_masks, int img_h, int img_w, int trans_cap,
                        int byte_cap, void* stream);
 
+/* ---- forward_train (fgn.py:125-185) ----------------------------------------------------- */
+
+/* The proposal stage at training sizes (train_cfg.rpn_proposal, fgn_r50_c4_densecl.py:153-157: nms_pre 12000,
+ * max_per_img 2000 - any nms_pre, max_per_img <= 4096): global bitonic sort of all anchor keys, then one workgroup
+ * per image decodes the best nms_pre and runs the greedy NMS.  Same outputs as fgn_rpn_proposals_f32. */
+size_t fgn_rpn_proposals_large_scratch_bytes(int batch, int n_total, int nms_pre);
+int fgn_rpn_proposals_large_f32(const float* scores, const float* deltas, const float* base_anchors, void* scratch,
+                                float* proposals, float* rois_out, int32_t* n_props, int batch, int feat_h, int feat_w,
+                                int n_anchors, int stride, float img_h, float img_w, const float* host_means4,
+                                const float* host_stds4, float max_ratio, int nms_pre, float min_bbox_size,
+                                float iou_thr, int max_per_img, void* stream);
+
+/* MaxIoUAssigner.assign (my_max_iou_assigner.py:60-213 on mmdet's bbox_overlaps): boxes [n, box_stride >= 4],
+ * inside (optional) [n] bytes: 0 = not a candidate (anchor outside the image, my_anchor_head.py:233-239),
+ * gts [k,4], k <= 256.  gt_inds [n] int32: -2 not a candidate, -1 ignored, 0 negative, i+1 = positive of GT i;
+ * max_overlaps (optional) [n].  scratch: fgn_box_assign_scratch_bytes(n, k), uninitialised. */
+size_t fgn_box_assign_scratch_bytes(int n, int k);
+int fgn_box_assign_f32(const float* boxes, int box_stride, const uint8_t* inside, const float* gts, int n, int k,
+                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality, void* scratch,
+                       int32_t* gt_inds, float* max_overlaps, void* stream);
+
+/* DeltaXYWHBBoxCoder.encode (bbox_coder.encode at my_anchor_head.py:256, fgn_roi_head.py:141): [n,4] x [n,4] -> [n,4] */
+int fgn_bbox2delta_f32(const float* proposals, const float* gts, float* out, int n, const float* host_means4,
+                       const float* host_stds4, void* stream);
+
+/* Weighted loss sums, out[0] = sum_i w_i * loss_i / avg_factor (mmdet weight_reduce_loss; w optional):
+ * sigmoid CE (F.binary_cross_entropy_with_logits; y >= y_threshold is the target when y_threshold >= 0 - the mask
+ * targets of mask_target_single), smooth L1, softmax CE (labels int64, outside [0, n_classes) ignored). */
+int fgn_bce_logits_sum_f32(const float* x, const float* y, const float* w, long long n, float y_threshold,
+                           double avg_factor, float* out, void* stream);
+int fgn_smooth_l1_sum_f32(const float* pred, const float* target, const float* w, long long n, float beta,
+                          double avg_factor, float* out, void* stream);
+int fgn_softmax_ce_sum_f32(const float* logits, const int64_t* labels, const float* w, int n, int n_classes,
+                           double avg_factor, float* out, void* stream);
+
+/* BatchNorm2d in training mode (the shared head's BN layers during forward_train, fgn_roi_head.py:202-238) on
+ * NHWC rows x [P,C]: batch mean / biased variance -> mean, var; y = (x-mean)/sqrt(var+eps)*gamma+beta (+residual)
+ * (ReLU) -> out (may alias x); running_mean / running_var (optional) updated with `momentum` (unbiased variance). */
+size_t fgn_bn_train_scratch_bytes(int C);
+int fgn_bn_train_f32(const float* x, int P, int C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, const float* residual, int relu, void* scratch,
+                     float* mean, float* var, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,281 @@
+"""``forward_train``: the HIP kernels of the training path against the training oracle.
+Selection (assignment, sampling, proposal ranking / NMS) is bit-exact; losses carry an fp32 tolerance stated per test."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(g, n, span=300.0):
+    ctr = torch.rand(n, 2, generator=g) * span
+    wh = torch.rand(n, 2, generator=g) * 80 + 4
+    return torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+
+
+# ---------------------------------------------------------------- assigner: bit-exact
+@pytest.mark.parametrize('k,n,thr', [(5, 4000, (0.5, 0.3, 0.3)), (7, 2000, (0.5, 0.5, 0.5)), (1, 300, (0.7, 0.3, 0.3)),
+                                     (0, 100, (0.5, 0.3, 0.3)), (3, 500, (0.5, 0.5, 0.0)), (40, 3000, (0.5, 0.5, 0.5))])
+def test_box_assign_matches_oracle_bitwise(k, n, thr):
+    from fgn_amd import ops
+    from oracle import fgn_train_cpu as T
+    g = torch.Generator().manual_seed(k * 31 + n)
+    boxes = _boxes(g, n)
+    gts = boxes[torch.randperm(n, generator=g)[:k]] + torch.randn(k, 4, generator=g) * 4 if k else boxes[:0]
+    boxes[10:30] = boxes[40:60]                       # duplicated boxes: tied IoUs
+    if k >= 2:
+        gts[1] = gts[0]                                 # duplicated GT: arg-max takes the first, low-quality the last
+    inside = (torch.rand(n, generator=g) > 0.2)
+    ref_all, mo_all = T.max_iou_assign(T.bbox_overlaps(gts, boxes), *thr, True)
+    got, mo = ops.box_assign(boxes.cuda(), gts.cuda(), *thr, True, with_overlaps=True)
+    assert np.array_equal(got.cpu().numpy(), ref_all.numpy().astype(np.int32))
+    if k:
+        assert np.array_equal(mo.cpu().numpy(), mo_all.numpy())        # IoU itself bit for bit
+    # with inside flags: the reference assigns on the compacted list (my_anchor_head.py:239-243)
+    ref_in, _ = T.max_iou_assign(T.bbox_overlaps(gts, boxes[inside]), *thr, True)
+    got = ops.box_assign(boxes.cuda(), gts.cuda(), *thr, True, inside=inside.to(torch.uint8).cuda()).cpu()
+    assert np.array_equal(got[inside].numpy(), ref_in.numpy().astype(np.int32))
+    assert bool((got[~inside] == -2).all())
+    # [n,5] proposals (score column ignored)
+    b5 = torch.cat([boxes, torch.rand(n, 1, generator=g)], 1)
+    got = ops.box_assign(b5.cuda(), gts.cuda(), *thr, True).cpu()
+    assert np.array_equal(got.numpy(), ref_all.numpy().astype(np.int32))
+
+
+def test_box_assign_on_the_anchor_grid():
+    """63 000 anchors of the cfg3 grid against GT boxes with integer corners (ties between anchors are common)."""
+    from fgn_amd import ops
+    from oracle import fgn_ref_cpu as O, fgn_train_cpu as T
+    base = O.base_anchors((2, 4, 8, 16, 32), (0.5, 1.0, 2.0), 16)
+    anchors = torch.from_numpy(O.grid_anchors(base, 50, 84, 16))
+    gts = torch.tensor([[100., 120., 420., 380.], [16., 16., 80., 48.], [600., 300., 1300., 790.],
+                        [601., 301., 1301., 791.], [0., 0., 32., 32.]])
+    valid = T.valid_flags(50, 84, 800, 1333, 16, 15)
+    inside = T.anchor_inside_flags(anchors, valid, 800., 1333., 0)
+    ref, _ = T.max_iou_assign(T.bbox_overlaps(gts, anchors[inside]), 0.5, 0.3, 0.3, True)
+    got = ops.box_assign(anchors.cuda(), gts.cuda(), 0.5, 0.3, 0.3, True, inside=inside.to(torch.uint8).cuda()).cpu()
+    assert np.array_equal(got[inside].numpy(), ref.numpy().astype(np.int32))
+    assert int((ref > 0).sum()) > 0
+
+
+def test_bbox2delta_matches_oracle():
+    from fgn_amd import ops
+    from oracle import fgn_train_cpu as T
+    g = torch.Generator().manual_seed(3)
+    p, q = _boxes(g, 500), _boxes(g, 500)
+    for means, stds in (((0., 0., 0., 0.), (1., 1., 1., 1.)), ((0., 0., 0., 0.), (.1, .1, .2, .2))):
+        ref = T.bbox2delta(p, q, means, stds)
+        got = ops.bbox2delta(p.cuda(), q.cuda(), means, stds).cpu()
+        # torch.log (vectorised, <= 1 ulp) vs the correctly rounded log here, then / std
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+# ---------------------------------------------------------------- loss reductions
+def test_loss_sums_match_torch():
+    from fgn_amd import ops
+    from oracle import fgn_train_cpu as T
+    g = torch.Generator().manual_seed(4)
+    n = 5000
+    x, w = torch.randn(n, generator=g) * 4, torch.rand(n, generator=g)
+    y = (torch.rand(n, generator=g) > 0.7).float()
+    ref = (F.binary_cross_entropy_with_logits(x, y, reduction='none') * w).sum() / 77.0
+    got = ops.bce_logits_sum(x.cuda(), y.cuda(), w.cuda(), 77.0).cpu()
+    assert float(got) == pytest.approx(float(ref), rel=2e-6)
+    soft = torch.rand(n, generator=g)                                   # mask-target form: binarised at 0.5, mean
+    ref = F.binary_cross_entropy_with_logits(x, (soft >= 0.5).float(), reduction='mean')
+    got = ops.bce_logits_sum(x.cuda(), soft.cuda(), None, float(n), y_threshold=0.5).cpu()
+    assert float(got) == pytest.approx(float(ref), rel=2e-6)
+    p, t, w4 = torch.randn(n, 4, generator=g) * 2, torch.randn(n, 4, generator=g), torch.rand(n, 4, generator=g)
+    ref = T.smooth_l1_weighted(p, t, w4, 128.0)
+    got = ops.smooth_l1_sum(p.cuda(), t.cuda(), w4.cuda(), 128.0).cpu()
+    assert float(got) == pytest.approx(float(ref), rel=2e-6)
+    logits = torch.randn(700, 4, generator=g) * 3
+    labels = torch.randint(0, 4, (700,), generator=g)
+    lw = torch.rand(700, generator=g)
+    ref = T.softmax_ce_weighted(logits, labels, lw, 300.0)
+    got = ops.softmax_ce_sum(logits.cuda(), labels.cuda(), lw.cuda(), 300.0).cpu()
+    assert float(got) == pytest.approx(float(ref), rel=2e-6)
+    assert float(ops.bce_logits_sum(x[:0].cuda(), y[:0].cuda(), None, 1.0).cpu()) == 0.0
+
+
+# ---------------------------------------------------------------- BatchNorm, training mode
+@pytest.mark.parametrize('P,C', [(128 * 49, 512), (9 * 49, 1024), (3, 64), (6272, 128)])
+def test_bn_train_matches_torch(P, C):
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(P + C)
+    x = torch.randn(P, C, generator=g) * 2 + torch.randn(C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    res = torch.randn(P, C, generator=g)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(x.t()[None].contiguous(), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)[0].t()
+    ref = F.relu(ref + res)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    y, mean, var = ops.bn_train(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, 0.1, rm_d, rv_d, residual=res.cuda(),
+                                relu=True, inplace=False)
+    assert float((y.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((mean.cpu() - x.mean(0)).abs().max()) <= 1e-6
+    assert float((var.cpu() - x.var(0, unbiased=False)).abs().max()) <= 1e-5 * float(x.var(0).max())
+    assert float((rm_d.cpu() - rm_ref).abs().max()) <= 1e-6
+    assert float((rv_d.cpu() - rv_ref).abs().max()) <= 1e-5 * float(rv_ref.max())
+
+
+# ---------------------------------------------------------------- proposals at training sizes: bit-exact
+def _train_proposal_case(seed, fh, fw, nms_pre, max_out, ties, img):
+    from fgn_amd import ops
+    from fgn_amd.config import fgn_r50_c4_config
+    from oracle import fgn_ref_cpu as O, fgn_train_cpu as T
+    cfg = fgn_r50_c4_config(3, 3)
+    pc = dict(nms_pre=nms_pre, max_per_img=max_out, nms_iou_threshold=0.7, min_bbox_size=0)
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randn(15, fh, fw, generator=g) * 3
+    if ties:
+        cls = (cls * 2).round() / 2
+        cls[:, : fh // 2] += 20
+    reg = torch.randn(60, fh, fw, generator=g) * 0.5
+    ref = T.rpn_get_bboxes_cfg(cls.numpy(), reg.numpy(), np.array([img[0], img[1], 3]), cfg, pc)
+    logits = cls.permute(1, 2, 0).reshape(1, -1).contiguous()
+    scores = torch.from_numpy(O.sigmoid32(logits.numpy()))
+    deltas = reg.permute(1, 2, 0).reshape(1, -1, 4).contiguous()
+    rp = cfg['rpn_head']
+    anchors = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'], rp['anchor_stride']))
+    # two images in one call: the second is the first with its scores reversed in sign
+    sc2 = torch.cat([scores, torch.from_numpy(O.sigmoid32(-logits.numpy()))]).cuda()
+    props, n, rois = ops.rpn_proposals(sc2, torch.cat([deltas, deltas]).cuda(), anchors.cuda(), fh, fw, 16, img[0], img[1],
+                                       rp['target_means'], rp['target_stds'], nms_pre, 0, 0.7, max_out, with_rois=True)
+    n0 = int(n[0].item())
+    assert n0 == len(ref), (n0, len(ref))
+    assert np.array_equal(props[0, :n0].cpu().numpy(), ref)              # boxes AND scores bitwise
+    assert float(props[0, n0:].abs().sum()) == 0.0
+    ref1 = T.rpn_get_bboxes_cfg(-cls.numpy(), reg.numpy(), np.array([img[0], img[1], 3]), cfg, pc)
+    n1 = int(n[1].item())
+    assert n1 == len(ref1) and np.array_equal(props[1, :n1].cpu().numpy(), ref1)
+    assert np.array_equal(rois[max_out:max_out + n1, 1:].cpu().numpy(), ref1[:, :4])
+    assert bool((rois[max_out:, 0] == 1).all())
+
+
+@pytest.mark.parametrize('ties', [False, True])
+def test_train_proposals_bit_exact_cfg3_size(ties):
+    _train_proposal_case(11, 50, 84, 12000, 2000, ties, (800, 1333))     # 63 000 anchors -> 12 000 -> 2000
+
+
+def test_train_proposals_bit_exact_small_maps():
+    _train_proposal_case(12, 10, 14, 12000, 2000, False, (160, 224))     # 2100 anchors: fewer than nms_pre
+    _train_proposal_case(13, 24, 30, 9000, 1500, True, (380, 470))       # 10 800 anchors -> 9000
+
+
+# ---------------------------------------------------------------- forward_train end to end
+def _models(cfg, seed=0):
+    from fgn_amd.detector import FGN
+    from fgn_amd.weights import init_state_dict
+    sd = init_state_dict(cfg, seed)
+    # non-trivial BatchNorm parameters for the shared head so that the train-mode statistics matter
+    g = torch.Generator().manual_seed(99)
+    for k in sd:
+        if k.startswith('roi_head.shared_head') and k.endswith('.weight') and sd[k].dim() == 1:
+            sd[k] = 0.75 + 0.5 * torch.rand(sd[k].shape, generator=g)
+        if k.startswith('roi_head.shared_head') and k.endswith('.bias') and sd[k].dim() == 1:
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    m = FGN(cfg['n_ways'], cfg['k_shots'], backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+            test_cfg=cfg['test_cfg'], state_dict=sd)
+    return m, sd
+
+
+def _compare_losses(got, ref, rel):
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
+        assert isinstance(got[k], list) and len(got[k]) == 1
+        assert float(got[k][0]) == pytest.approx(float(ref[k][0]), rel=rel, abs=1e-7), k
+    for k in ('loss_cls', 'loss_bbox', 'loss_mask'):
+        assert float(got[k]) == pytest.approx(float(ref[k]), rel=rel, abs=1e-7), k
+    for k in ('ACC-Unbalanced', 'ACC-Balanced'):
+        assert float(got[k]) == pytest.approx(float(ref[k]), abs=1e-6), k
+    assert set(got) == set(ref)
+
+
+@pytest.mark.parametrize('n_ways,k_shots,batch', [(3, 3, 2), (1, 1, 1)])
+def test_forward_train_matches_oracle_small(n_ways, k_shots, batch):
+    """Half-width model, 160x224 queries: every stage compared - sampled sets and labels bit-exact, losses to 1e-4."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    from fgn_amd import train as TR
+    from oracle import fgn_train_cpu as T
+    cfg = tiny_config(n_ways, k_shots, width_div=2)
+    m, sd = _models(cfg)
+    b = make_batch(0, batch, n_ways, k_shots, 160, 224, 64)
+    sd_ref = copy.deepcopy(sd)
+    tr_ref = {}
+    torch.manual_seed(5)
+    ref = T.forward_train(sd_ref, cfg, trace=tr_ref, **b)
+    m.debug_trace = {}
+    torch.manual_seed(5)
+    got = m.forward(return_loss=True, **b)
+    tr = m.debug_trace
+    # the same anchors sampled for every guided pass
+    for (pos, neg), t in zip(tr['rpn_sets'], tr_ref['rpn_targets']):
+        full = torch.nonzero(t['inside']).view(-1)
+        assert np.array_equal(pos.cpu().numpy(), full[t['pos_inds']].numpy())
+        assert np.array_equal(neg.cpu().numpy(), full[t['neg_inds']].numpy())
+    assert tr['rpn_num_total_samples'] == tr_ref['rpn_num_total_samples']
+    # the same proposals kept (count) and the same RoIs sampled
+    for p, q in zip(tr['proposals'], tr_ref['proposals']):
+        assert p.shape[0] == len(q)
+        assert float((p.cpu() - torch.from_numpy(q)).abs().max()) < 1e-2
+    for s, r in zip(tr['samples'], tr_ref['samples']):
+        assert np.array_equal(s['pos_inds'].cpu().numpy(), r['pos_inds'].numpy())
+        assert np.array_equal(s['neg_inds'].cpu().numpy(), r['neg_inds'].numpy())
+        assert np.array_equal(s['pos_gt_labels'].cpu().numpy(), r['pos_gt_labels'].numpy())
+    assert np.array_equal(tr['labels'].cpu().numpy(), tr_ref['bbox_targets'][0].numpy())
+    # train-mode shared head output and box head outputs
+    bf = tr['bbox_feats'].permute(0, 3, 1, 2).cpu()
+    assert float((bf - tr_ref['bbox_feats']).abs().max()) <= 2e-4 * float(tr_ref['bbox_feats'].abs().max())
+    assert float((tr['cls_score'].cpu() - tr_ref['cls_score']).abs().max()) <= 1e-4 * \
+        max(1.0, float(tr_ref['cls_score'].abs().max()))
+    # mask targets: identical except pixels whose pooled value sits on the 0.5 threshold
+    soft = tr['mask_targets_soft'].cpu()
+    flips = ((soft >= 0.5).float() != tr_ref['mask_targets'])
+    assert bool(((soft - 0.5).abs()[flips] < 1e-5).all())
+    assert int(flips.sum()) <= 2
+    _compare_losses(got, ref, 1e-4)
+    # running BatchNorm statistics of the shared head were updated like the module's buffers
+    for k, v in TR.bn_buffers(m).items():
+        assert float((v - sd_ref[k]).abs().max()) <= 1e-4 * max(1.0, float(sd_ref[k].abs().max())), k
+        assert float((v - sd[k]).abs().max()) > 0
+
+
+def test_forward_train_full_width_given_proposals():
+    """R50 widths at 256x320: the oracle's proposals are handed to both sides so that the RoI stage is compared at
+    full width without depending on near-tie NMS decisions of random weights."""
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.episodes import make_batch
+    from oracle import fgn_train_cpu as T
+    cfg = fgn_r50_c4_config(3, 2)
+    m, sd = _models(cfg)
+    b = make_batch(3, 1, 3, 2, 256, 320, 128)
+    tr_ref = {}
+    torch.manual_seed(8)
+    ref = T.forward_train(copy.deepcopy(sd), cfg, trace=tr_ref, **b)
+    torch.manual_seed(8)
+    got = m.forward_train(proposals=tr_ref['proposals'], **b)
+    _compare_losses(got, ref, 2e-4)
+
+
+def test_forward_train_cfg3_size_runs_and_is_reproducible():
+    """800x1333 queries, 63 000 anchors, 12 000 -> 2000 proposals: finite losses, bit-identical under the same seed."""
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.episodes import CONFIGS, make_batch
+    cfg = fgn_r50_c4_config(3, 3)
+    m, _ = _models(cfg)
+    b = make_batch(0, 1, **CONFIGS['cfg3'])
+    torch.manual_seed(1)
+    a = m.forward_train(**b)
+    m._PT = None                                    # fresh running statistics: same inputs, same outputs
+    torch.manual_seed(1)
+    c = m.forward_train(**b)
+    for k in a:
+        va = float(a[k][0]) if isinstance(a[k], list) else float(a[k])
+        vc = float(c[k][0]) if isinstance(c[k], list) else float(c[k])
+        assert np.isfinite(va) and va == vc, k
+    assert float(a['loss_rpn_cls'][0]) > 0 and float(a['loss_cls']) > 0 and float(a['loss_mask']) > 0

@@ -123,8 +123,11 @@ def test_state_dict_layout_and_loading():
     bad['rpn_head.rpn_cls.weight'] = torch.zeros(3, 3)
     with pytest.raises(ValueError):
         m.load_state_dict(bad)
-    with pytest.raises(NotImplementedError):
-        m(return_loss=True)
+    if not torch.cuda.is_available():                           # the training path has no CPU fallback either
+        from fgn_amd.episodes import make_batch
+        from fgn_amd.lib import FgnHipError
+        with pytest.raises(FgnHipError):
+            m(return_loss=True, **make_batch(0, 1, 3, 3, 64, 64, 32))
 
 
 def test_collate_matches_reference_layout():
