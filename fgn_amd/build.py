@@ -23,6 +23,7 @@ SOURCES = [
     ('det_post.hip', ['-ffp-contract=off']),
     ('mask.hip', ['-ffp-contract=off']),
     ('train.hip', ['-ffp-contract=off']),
+    ('train_bwd.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -375,6 +375,42 @@ class FGN(torch.nn.Module):
                 (_BasicBlock if bb.get('block', 'bottleneck') == 'basic' else _Bottleneck)(
                     sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps, winograd=self.use_winograd)
                 for b in range(nblk)])
+        P.update(self._pack_heads(sd))
+        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
+                       for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
+        # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
+        # (RoIAlign commutes with it); the shift is added after the pooling
+        c1 = P['shared'][0].conv1
+        P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
+                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
+            if self.use_roi_commute else None
+        P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
+        rp = cfg['rpn_head']
+        P['anchors'] = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'],
+                                                         rp['anchor_stride']))
+
+        def mv(o):
+            if isinstance(o, torch.Tensor):
+                return o.float().contiguous().to(device)
+            if isinstance(o, (ops.ConvLayer, ops.WinogradLayer)):
+                return o.to(device)
+            if isinstance(o, (_Bottleneck, _BasicBlock)):
+                for l in o.layers():
+                    l.to(device)
+                return o
+            if isinstance(o, _BottleneckGN):
+                return o.to(device)
+            if isinstance(o, (list, tuple)):
+                return [mv(x) for x in o]
+            return o
+        self._P = {k: mv(v) for k, v in P.items()}
+        self._packed_device = torch.device(device)
+
+    def _pack_heads(self, sd) -> dict:
+        """The packed AG-RPN / relation / box / mask head layers from torch-layout weights ``sd`` (CPU tensors of the
+        state dict, or the device-resident master weights of ``fgn_amd.train.Trainer``: packing is torch ops only)."""
+        cfg = self.cfg
+        P = {}
         P['rpn_conv'] = ops.pack_conv(sd['rpn_head.rpn_conv.weight'], bias=sd['rpn_head.rpn_conv.bias'], pad=1,
                                       relu=True)
         wr = sd['rpn_head.rpn_conv.weight']
@@ -390,15 +426,6 @@ class FGN(torch.nn.Module):
             wh = torch.cat([wh, wh.new_zeros((padc,) + tuple(wh.shape[1:]))], 0)
             bh = torch.cat([bh, bh.new_zeros(padc)], 0)
         P['rpn_head'] = ops.pack_conv(wh, bias=bh)
-        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
-                       for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
-        # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
-        # (RoIAlign commutes with it); the shift is added after the pooling
-        c1 = P['shared'][0].conv1
-        P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
-                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
-            if self.use_roi_commute else None
-        P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
         # relation conv split along its input channels: [Wq | Ws] (fgn_roi_head.py:270)
         wrel = sd['roi_head.cls_reg_shared_conv.weight']
         c = wrel.shape[1] // 2
@@ -425,26 +452,7 @@ class FGN(torch.nn.Module):
         P['upsample'] = ops.pack_conv(w4, bias=sd['roi_head.mask_head.upsample.bias'].repeat(4), relu=True)
         P['logit_w'] = sd['roi_head.mask_head.conv_logits.weight'].reshape(-1).clone()
         P['logit_b'] = float(sd['roi_head.mask_head.conv_logits.bias'][0])
-        rp = cfg['rpn_head']
-        P['anchors'] = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'],
-                                                         rp['anchor_stride']))
-
-        def mv(o):
-            if isinstance(o, torch.Tensor):
-                return o.float().contiguous().to(device)
-            if isinstance(o, (ops.ConvLayer, ops.WinogradLayer)):
-                return o.to(device)
-            if isinstance(o, (_Bottleneck, _BasicBlock)):
-                for l in o.layers():
-                    l.to(device)
-                return o
-            if isinstance(o, _BottleneckGN):
-                return o.to(device)
-            if isinstance(o, (list, tuple)):
-                return [mv(x) for x in o]
-            return o
-        self._P = {k: mv(v) for k, v in P.items()}
-        self._packed_device = torch.device(device)
+        return P
 
     # --- stages ---------------------------------------------------------------------------
     def extract_feat(self, img_nchw: torch.Tensor) -> torch.Tensor:

@@ -63,9 +63,20 @@ SIGNATURES = {
     'fgn_softmax_ce_sum_f32': (_i, [_p, _p, _p, _i, _i, C.c_double, _p, _p]),
     'fgn_bn_train_scratch_bytes': (C.c_size_t, [_i]),
     'fgn_bn_train_f32': (_i, [_p, _i, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    'fgn_bce_logits_grad_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _p, _p]),
+    'fgn_smooth_l1_grad_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _p, _p]),
+    'fgn_softmax_ce_grad_f32': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
+    'fgn_colsum_scratch_bytes': (C.c_size_t, [_i]),
+    'fgn_colsum_f32': (_i, [_p, C.c_longlong, _i, _p, _p, _i, _p]),
+    'fgn_bn_train_backward_scratch_bytes': (C.c_size_t, [_i]),
+    'fgn_bn_train_backward_f32': (_i, [_p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'fgn_relation_gn_head_backward_f32': (_i, [_p] * 12 + [_i, _i, _i, _i, _i, _f, _p]),
+    'fgn_mask_logits_backward_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'fgn_im2col3x3_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

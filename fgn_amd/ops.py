@@ -316,10 +316,10 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
         w = w * scale[:, None, None, None]
     elif bias is not None:
         shift = bias.detach().double()
-    G = _WG_G[m]
+    G = _WG_G[m].to(w.device)
     u = torch.einsum('ai,ocij,bj->aboc', G, w, G)                            # [m+2,m+2,Cout,Cin]
     cout_pad = (cout + 127) // 128 * 128
-    up = torch.zeros((m + 2) ** 2, cout_pad, cin, dtype=torch.float32)
+    up = torch.zeros((m + 2) ** 2, cout_pad, cin, dtype=torch.float32, device=w.device)
     up[:, :cout] = u.reshape((m + 2) ** 2, cout, cin).float()
     return WinogradLayer(up.contiguous(), None if shift is None else shift.float().contiguous(), cin, cout,
                          cout_pad, relu, m)
@@ -875,3 +875,131 @@ def bn_train(x: torch.Tensor, gamma, beta, eps: float, momentum: float, running_
                             _ptr(out), _stream())
     _lib.check(rc, 'fgn_bn_train_f32')
     return out, mean, var
+
+
+# --------------------------------------------------------------------------------------
+# backward pieces of the trainable heads (csrc/train_bwd.hip)
+# --------------------------------------------------------------------------------------
+def bce_logits_grad(x, y, w, scale: float, y_threshold: float = -1.0) -> torch.Tensor:
+    _loss_args(x, y, w)
+    dx = torch.empty_like(x)
+    rc = _lib.load().fgn_bce_logits_grad_f32(_ptr(x), _ptr(y), _ptr(w), x.numel(), float(y_threshold), float(scale),
+                                             _ptr(dx), _stream())
+    _lib.check(rc, 'fgn_bce_logits_grad_f32')
+    return dx
+
+
+def smooth_l1_grad(pred, target, w, scale: float, beta: float = 1.0) -> torch.Tensor:
+    _loss_args(pred, target, w)
+    d = torch.empty_like(pred)
+    rc = _lib.load().fgn_smooth_l1_grad_f32(_ptr(pred), _ptr(target), _ptr(w), pred.numel(), float(beta), float(scale),
+                                            _ptr(d), _stream())
+    _lib.check(rc, 'fgn_smooth_l1_grad_f32')
+    return d
+
+
+def softmax_ce_grad(logits, labels, w, scale: float) -> torch.Tensor:
+    _chk(logits, 'logits')
+    _chk(labels, 'labels', torch.int64)
+    if w is not None:
+        _chk(w, 'weight')
+    n, c = logits.shape
+    d = torch.empty_like(logits)
+    rc = _lib.load().fgn_softmax_ce_grad_f32(_ptr(logits), _ptr(labels), _ptr(w), n, c, float(scale), _ptr(d), _stream())
+    _lib.check(rc, 'fgn_softmax_ce_grad_f32')
+    return d
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """x [..., C] -> [C] = sum over all leading dims (fp64 partials, fixed order)."""
+    _chk(x, 'x')
+    c = x.shape[-1]
+    r = x.numel() // c if c else 0
+    L = _lib.load()
+    if out is None:
+        out = torch.empty((c,), device=x.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        _chk(out, 'out')
+    scratch = torch.empty(L.fgn_colsum_scratch_bytes(c), device=x.device, dtype=torch.uint8)
+    rc = L.fgn_colsum_f32(_ptr(x), r, c, _ptr(scratch), _ptr(out), int(accumulate), _stream())
+    _lib.check(rc, 'fgn_colsum_f32')
+    return out
+
+
+def bn_train_backward(x_pre, y_post, dy, mean, var, gamma, eps: float, want_g: bool = False):
+    """-> dx, dgamma, dbeta (+ g = dy masked by the ReLU, when ``want_g``)."""
+    for t, nm in ((x_pre, 'x_pre'), (dy, 'dy'), (mean, 'mean'), (var, 'var'), (gamma, 'gamma')):
+        _chk(t, nm)
+    if y_post is not None:
+        _chk(y_post, 'y_post')
+    c = x_pre.shape[-1]
+    p = x_pre.numel() // c
+    if dy.numel() != x_pre.numel() or (y_post is not None and y_post.numel() != x_pre.numel()):
+        raise _lib.FgnHipError('bn_train_backward: operand sizes differ')
+    L = _lib.load()
+    dx = torch.empty_like(x_pre)
+    g = torch.empty_like(x_pre) if want_g else None
+    dgamma = torch.empty((c,), device=x_pre.device, dtype=torch.float32)
+    dbeta = torch.empty((c,), device=x_pre.device, dtype=torch.float32)
+    scratch = torch.empty(L.fgn_bn_train_backward_scratch_bytes(c), device=x_pre.device, dtype=torch.uint8)
+    rc = L.fgn_bn_train_backward_f32(_ptr(x_pre), _ptr(y_post), _ptr(dy), _ptr(mean), _ptr(var), _ptr(gamma), float(eps),
+                                     p, c, _ptr(scratch), _ptr(dx), _ptr(g), _ptr(dgamma), _ptr(dbeta), _stream())
+    _lib.check(rc, 'fgn_bn_train_backward_f32')
+    return (dx, dgamma, dbeta, g) if want_g else (dx, dgamma, dbeta)
+
+
+def relation_gn_head_backward(q, s, rois, gn_w, gn_b, fc_w, d_out6, n_ways: int, gn_groups: int, eps: float):
+    """-> dQ [R,7,7,C], dZ [R*N,7,7,C], pooled [R*N,C], dgamma [C], dbeta [C]."""
+    for t, nm in ((q, 'Q'), (s, 'S'), (rois, 'rois'), (gn_w, 'gn_w'), (gn_b, 'gn_b'), (fc_w, 'fc_w'), (d_out6, 'd_out6')):
+        _chk(t, nm)
+    r, ps, _, c = q.shape
+    if tuple(d_out6.shape) != (r * n_ways, 6) or tuple(fc_w.shape) != (6, c):
+        raise _lib.FgnHipError('relation_gn_head_backward: operand shapes inconsistent')
+    dq = torch.empty_like(q)
+    dz = torch.empty((r * n_ways, ps, ps, c), device=q.device, dtype=torch.float32)
+    pooled = torch.empty((r * n_ways, c), device=q.device, dtype=torch.float32)
+    dga = torch.empty((r, c), device=q.device, dtype=torch.float32)
+    dbe = torch.empty((r, c), device=q.device, dtype=torch.float32)
+    rc = _lib.load().fgn_relation_gn_head_backward_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
+                                                       _ptr(d_out6), _ptr(dq), _ptr(dz), _ptr(pooled), _ptr(dga),
+                                                       _ptr(dbe), r, n_ways, c, gn_groups, ps, float(eps), _stream())
+    _lib.check(rc, 'fgn_relation_gn_head_backward_f32')
+    return dq, dz, pooled, colsum(dga), colsum(dbe)
+
+
+def mask_logits_backward(up: torch.Tensor, dlogit: torch.Tensor, w: torch.Tensor, roi_size: int):
+    """up [D,P,P,4*C], dlogit [D,2P,2P], w [C] -> d_up [D,P,P,4*C], dw [C]."""
+    _chk(up, 'up')
+    _chk(dlogit, 'dlogit')
+    _chk(w, 'w')
+    d, c = up.shape[0], w.numel()
+    if up[0].numel() != roi_size * roi_size * 4 * c or tuple(dlogit.shape) != (d, 2 * roi_size, 2 * roi_size):
+        raise _lib.FgnHipError('mask_logits_backward: operand shapes inconsistent')
+    d_up = torch.empty_like(up)
+    part = torch.empty((d, c), device=up.device, dtype=torch.float32)
+    rc = _lib.load().fgn_mask_logits_backward_f32(_ptr(up), _ptr(dlogit), _ptr(w), _ptr(d_up), _ptr(part), d, roi_size, c,
+                                                  _stream())
+    _lib.check(rc, 'fgn_mask_logits_backward_f32')
+    return d_up, colsum(part)
+
+
+def im2col3x3(x: torch.Tensor) -> torch.Tensor:
+    """x [n,H,W,C] -> [n*H*W, 9*C] (3x3, stride 1, pad 1; column = tap*C + ci)."""
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty((n * h * w, 9 * c), device=x.device, dtype=torch.float32)
+    rc = _lib.load().fgn_im2col3x3_f32(_ptr(x), _ptr(out), n, h, w, c, _stream())
+    _lib.check(rc, 'fgn_im2col3x3_f32')
+    return out
+
+
+def adagrad_step(param: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, lr: float, weight_decay: float,
+                 eps: float = 1e-10) -> None:
+    for t, nm in ((param, 'param'), (grad, 'grad'), (state, 'state')):
+        _chk(t, nm)
+    if grad.numel() != param.numel() or state.numel() != param.numel():
+        raise _lib.FgnHipError('adagrad_step: operand sizes differ')
+    rc = _lib.load().fgn_adagrad_step_f32(_ptr(param), _ptr(grad), _ptr(state), param.numel(), float(lr),
+                                          float(weight_decay), float(eps), _stream())
+    _lib.check(rc, 'fgn_adagrad_step_f32')

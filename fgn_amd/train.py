@@ -28,9 +28,11 @@ from . import ops
 
 class _SharedBlockTrain:
     """One Bottleneck of the shared head with train-mode BatchNorm: conv -> bn_train(+ReLU) x3, identity shortcut
-    (stride 1, inplanes == planes * expansion: no downsample, fgn_roi_head.py:207-225)."""
+    (stride 1, inplanes == planes * expansion: no downsample, fgn_roi_head.py:207-225).  ``sd`` maps state-dict names
+    to torch-layout tensors (CPU state dict, or the trainer's device-resident master weights, which the BatchNorm
+    affine parameters then alias); ``buffers`` (optional) holds the running statistics across re-packs."""
 
-    def __init__(self, sd: dict, prefix: str, winograd: int):
+    def __init__(self, sd: dict, prefix: str, winograd: int, buffers: Optional[dict] = None):
         self.conv1 = ops.pack_conv(sd[prefix + '.conv1.weight'])
         w2 = sd[prefix + '.conv2.weight']
         self.conv2 = ops.pack_conv(w2, pad=1)
@@ -38,8 +40,13 @@ class _SharedBlockTrain:
             if winograd and w2.shape[1] % 32 == 0 and w2.shape[0] % 4 == 0 else None
         self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'])
         self.prefix = prefix
-        self.bn = [{k: sd[f'{prefix}.bn{i}.{k}'].detach().float().clone() for k in
-                    ('weight', 'bias', 'running_mean', 'running_var')} for i in (1, 2, 3)]
+        self.bn = []
+        for i in (1, 2, 3):
+            b = {k: sd[f'{prefix}.bn{i}.{k}'].detach().float() for k in ('weight', 'bias')}
+            for k in ('running_mean', 'running_var'):
+                name = f'{prefix}.bn{i}.{k}'
+                b[k] = buffers[name] if buffers is not None else sd[name].detach().float().clone()
+            self.bn.append(b)
 
     def to(self, device):
         for l in (self.conv1, self.conv2, self.conv3, self.conv2_wg):
@@ -48,34 +55,44 @@ class _SharedBlockTrain:
         self.bn = [{k: v.contiguous().to(device) for k, v in b.items()} for b in self.bn]
         return self
 
-    def _bn(self, i, y, eps, momentum, relu, residual=None):
+    def _bn(self, i, y, eps, momentum, relu, residual=None, keep=False):
         b = self.bn[i]
         return ops.bn_train(y, b['weight'], b['bias'], eps, momentum, b['running_mean'], b['running_var'],
-                            residual=residual, relu=relu)[0]
+                            residual=residual, relu=relu, inplace=not keep)
 
-    def __call__(self, x, eps, momentum):
-        y = self._bn(0, ops.conv2d(x, self.conv1), eps, momentum, True)
+    def __call__(self, x, eps, momentum, tape: Optional[list] = None):
+        """``tape`` (a list) receives what the backward pass needs: the input, the three pre-norm convolution outputs
+        with their batch statistics, and the post-ReLU activations."""
+        keep = tape is not None
+        c1 = ops.conv2d(x, self.conv1)
+        y1, m1, v1 = self._bn(0, c1, eps, momentum, True, keep=keep)
         wg = self.conv2_wg
-        if wg is not None and ops.winograd_pays(y.shape[0], y.shape[1], y.shape[2], wg.cin, wg.cout, wg.m):
-            y = ops.conv3x3_winograd(y, wg)
+        if wg is not None and ops.winograd_pays(y1.shape[0], y1.shape[1], y1.shape[2], wg.cin, wg.cout, wg.m):
+            c2 = ops.conv3x3_winograd(y1, wg)
         else:
-            y = ops.conv2d(y, self.conv2)
-        y = self._bn(1, y, eps, momentum, True)
-        return self._bn(2, ops.conv2d(y, self.conv3), eps, momentum, True, residual=x)   # relu(bn3(conv3) + identity)
+            c2 = ops.conv2d(y1, self.conv2)
+        y2, m2, v2 = self._bn(1, c2, eps, momentum, True, keep=keep)
+        c3 = ops.conv2d(y2, self.conv3)
+        out, m3, v3 = self._bn(2, c3, eps, momentum, True, residual=x, keep=keep)    # relu(bn3(conv3) + identity)
+        if keep:
+            tape.append(dict(x=x, c1=c1, y1=y1, c2=c2, y2=y2, c3=c3, out=out, stats=((m1, v1), (m2, v2), (m3, v3))))
+        return out
 
 
-def pack_train(model, device) -> None:
+def pack_train(model, device, weights: Optional[dict] = None, buffers: Optional[dict] = None) -> None:
     """Raw (un-folded) shared-head layers and their BatchNorm parameters / running buffers on ``device``."""
     nb = model.cfg['roi_head']['shared_head']['num_blocks']
-    model._PT = {'shared': [_SharedBlockTrain(model._sd, f'roi_head.shared_head.{b}', model.use_winograd).to(device)
+    src = model._sd if weights is None else weights
+    anchors = model._PT['anchors'] if getattr(model, '_PT', None) else {}
+    model._PT = {'shared': [_SharedBlockTrain(src, f'roi_head.shared_head.{b}', model.use_winograd, buffers).to(device)
                             for b in range(nb)],
-                 'device': torch.device(device), 'anchors': {}}
+                 'device': torch.device(device), 'anchors': anchors}
 
 
-def shared_head_train(model, x, momentum: float):
+def shared_head_train(model, x, momentum: float, tape: Optional[list] = None):
     eps = model.cfg['backbone']['bn_eps']
     for blk in model._PT['shared']:
-        x = blk(x, eps, momentum)
+        x = blk(x, eps, momentum, tape)
     return x
 
 
@@ -155,6 +172,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     tcfg = cfg['train_cfg']
     rh, rp = cfg['roi_head'], cfg['rpn_head']
     tr = model.debug_trace
+    tape = getattr(model, '_tape', None)         # dict: the Trainer asks for what the backward pass needs
     B = qry_img.shape[0]
     main = torch.cuda.current_stream()
 
@@ -216,6 +234,11 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     losses = {'loss_rpn_cls': [loss_rpn_cls.view(())], 'loss_rpn_bbox': [loss_rpn_bbox.view(())]}
     if tr is not None:
         tr.update(qry_fmap=qry_fmap, rpn_head=head, rpn_sets=rpn_sets, rpn_num_total_samples=n_samples)
+    if tape is not None:
+        tape['rpn'] = dict(x=x, head=head, sets=rpn_sets, x_cat=x_cat, y_cat=y_cat, w_cat=w_cat, n_samples=n_samples,
+                           preds=torch.cat(preds).contiguous() if preds else None,
+                           tgts=torch.cat(tgts).contiguous() if tgts else None, qry_fmap=qry_fmap, vec=sc['vec'],
+                           A=A, n_ways=N)
 
     # ---- proposals with train_cfg.rpn_proposal (fgn.py:161-167)
     if proposals is None:
@@ -253,7 +276,8 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         tr['samples'] = samples
 
     # count_spp with the shared head in training mode (fgn_roi_head.py:491, 419-449)
-    model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum))
+    spp_tape = [] if tape is not None else None
+    model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum, spp_tape))
 
     # _bbox_forward_train (fgn_roi_head.py:344-358)
     rois = torch.cat([torch.cat([torch.full((len(s['pos_bboxes']) + len(s['neg_bboxes']), 1), float(i), device=dev),
@@ -264,7 +288,8 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     if n_rois:
         xr = ops.roi_align(qry_fmap, rois, rh['roi_out_size'], 1.0 / rh['featmap_stride'], rh['roi_sampling_ratio'],
                            True)
-        feats = shared_head_train(model, xr, bn_momentum)
+        roi_tape = [] if tape is not None else None
+        feats = shared_head_train(model, xr, bn_momentum, roi_tape)
         Q = ops.conv2d(feats, P['rel_q'])
         cls_raw, reg_raw = ops.relation_gn_head(Q, sc['S'], rois, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'])
@@ -304,13 +329,25 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         losses['loss_bbox'] = _zero(dev)
     if tr is not None:
         tr.update(rois=rois, bbox_feats=feats, cls_score=cls_score, bbox_pred=bbox_pred, labels=labels)
+    if tape is not None:
+        if not n_rois:
+            raise ValueError('training step without a single sampled RoI')
+        tape['roi'] = dict(rois=rois, blocks=roi_tape, feats=feats, Q=Q, S=sc['S'], cls_raw=cls_raw, cls_score=cls_score,
+                           bbox_pred=bbox_pred, labels=labels, lw=lw, avg=avg, pos_rows=pos_rows, n_rois=n_rois,
+                           pos_pred=pos_pred if pos_rows.numel() else None,
+                           pos_tgt=pos_tgt if pos_rows.numel() else None)
+        tape['spp'] = dict(blocks=spp_tape, masks7=sc['masks7'], cat_mean=sc['cat_mean'], B=B)
 
     # ---- mask branch (fgn_roi_head.py:498-527, 384-417): shared RoI extractor -> the positives' bbox_feats
     n_pos = int(pos_rows.numel())
     if n_pos:
         img_of = rois[pos_rows, 0].long()
         vmask = sc['cat_mean_mp'][labels[pos_rows] + N * img_of].contiguous()          # spp_vecs_mask
-        mlog, _ = model._mask_head(feats[pos_rows].contiguous(), vmask)
+        mfeat = feats[pos_rows].contiguous()
+        if tape is None:
+            mlog, _ = model._mask_head(mfeat, vmask)
+        else:
+            mlog, macts, mup = _mask_head_taped(model, mfeat, vmask)
         # mask_target_single + BitmapMasks.crop_and_resize: RoIAlign(aligned, adaptive grid) of the GT bitmaps
         gt_masks = []
         for m in qry_isegmaps:
@@ -331,6 +368,311 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         losses['loss_mask'] = ops.bce_logits_sum(mlog.contiguous(), tgt, None, float(mlog.numel()), y_threshold=0.5)
         if tr is not None:
             tr.update(mask_pred=mlog, mask_targets_soft=tgt)
+        if tape is not None:
+            tape['mask'] = dict(mfeat=mfeat, vmask=vmask, acts=macts, up=mup, mlog=mlog.contiguous(), tgt=tgt,
+                                rows=labels[pos_rows] + N * img_of)
     else:
         losses['loss_mask'] = _zero(dev)
+        if tape is not None:
+            tape['mask'] = None
     return losses
+
+
+def _mask_head_taped(model, mf, vmask):
+    """``FGN._mask_head`` keeping every activation: -> logits [D,14,14], [m1..m4] (post-ReLU), up [D,7,7,4*C']."""
+    P = model._P
+    acts, m = [], mf
+    for li, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
+        scale = vmask if li == 0 else None
+        if wg is not None and ops.winograd_pays(m.shape[0], m.shape[1], m.shape[2], wg.cin, wg.cout, wg.m):
+            m = ops.conv3x3_winograd(m, wg, in_scale=scale)
+        else:
+            m = ops.conv2d(m, layer, in_scale=scale)
+        acts.append(m)
+    up = ops.conv2d(m, P['upsample'])
+    mlog, _ = ops.mask_logits(up, P['logit_w'], P['logit_b'], model.cfg['roi_head']['roi_out_size'], None)
+    return mlog, acts, up
+
+
+# ------------------------------------------------------------------------------------------
+# backward of the trainable heads
+# ------------------------------------------------------------------------------------------
+def _mm_tn(a2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """a2 [rows, M], b2 [rows, K] -> a2^T b2 [M, K]: the weight-gradient product, a plain GEMM (rocBLAS)."""
+    return torch.matmul(a2.t(), b2)
+
+
+def _conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Data gradient of a 3x3 / stride 1 / pad 1 convolution with torch-layout weight [Cout,Cin,3,3]: the forward
+    convolution kernel applied to dy with the kernel flipped and the channel roles swapped."""
+    wd = w.flip(2, 3).transpose(0, 1).contiguous()                   # [Cin, Cout, 3, 3]
+    return ops.conv2d(dy.contiguous(), ops.pack_conv(wd, pad=1))
+
+
+def _conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """-> dW [Cout,Cin,3,3] = dy^T . im2col(x)."""
+    cout, cin = dy.shape[-1], x.shape[-1]
+    return _mm_tn(dy.reshape(-1, cout), ops.im2col3x3(x.contiguous())).view(cout, 3, 3, cin).permute(0, 3, 1, 2) \
+        .contiguous()
+
+
+def _block_backward(blk: _SharedBlockTrain, W: dict, t: dict, dout: torch.Tensor, eps: float, need_dx: bool, grads: dict):
+    """One shared-head Bottleneck (train-mode BN) backwards; weight gradients are ACCUMULATED into ``grads`` (the
+    block runs on the RoI batch and on the support batch)."""
+    p = blk.prefix
+
+    def acc(name, g):
+        grads[name] = g if name not in grads else grads[name] + g
+    (m1, v1), (m2, v2), (m3, v3) = t['stats']
+    w1 = W[p + '.conv1.weight'].view(W[p + '.conv1.weight'].shape[0], -1)
+    w2 = W[p + '.conv2.weight']
+    w3 = W[p + '.conv3.weight'].view(W[p + '.conv3.weight'].shape[0], -1)
+    d3, dg3, db3, g_id = ops.bn_train_backward(t['c3'], t['out'], dout.contiguous(), m3, v3, blk.bn[2]['weight'], eps,
+                                               want_g=True)
+    acc(p + '.bn3.weight', dg3); acc(p + '.bn3.bias', db3)
+    d3f = d3.view(-1, w3.shape[0])
+    acc(p + '.conv3.weight', _mm_tn(d3f, t['y2'].reshape(-1, w3.shape[1])).view_as(W[p + '.conv3.weight']))
+    dy2 = torch.matmul(d3f, w3).view_as(t['y2'])
+    d2, dg2, db2 = ops.bn_train_backward(t['c2'], t['y2'], dy2, m2, v2, blk.bn[1]['weight'], eps)
+    acc(p + '.bn2.weight', dg2); acc(p + '.bn2.bias', db2)
+    acc(p + '.conv2.weight', _conv3x3_wgrad(d2, t['y1']))
+    dy1 = _conv3x3_dgrad(d2, w2)
+    d1, dg1, db1 = ops.bn_train_backward(t['c1'], t['y1'], dy1, m1, v1, blk.bn[0]['weight'], eps)
+    acc(p + '.bn1.weight', dg1); acc(p + '.bn1.bias', db1)
+    d1f = d1.view(-1, w1.shape[0])
+    acc(p + '.conv1.weight', _mm_tn(d1f, t['x'].reshape(-1, w1.shape[1])).view_as(W[p + '.conv1.weight']))
+    if not need_dx:
+        return None
+    return g_id + torch.matmul(d1f, w1).view_as(t['x'])
+
+
+def _shared_backward(model, W, blocks_tape, dout, grads):
+    eps = model.cfg['backbone']['bn_eps']
+    blks = model._PT['shared']
+    for bi in range(len(blks) - 1, -1, -1):
+        dout = _block_backward(blks[bi], W, blocks_tape[bi], dout, eps, bi > 0, grads)
+
+
+def backward(model, W: dict, tape: dict) -> dict:
+    """Gradients of the summed losses (mmdet ``_parse_losses``: every key containing 'loss') with respect to the
+    trainable parameters ``W`` (torch-layout master weights on the device), from the tape of ``forward_train``.
+    The backbone is frozen (fgn.py:67-73), so nothing flows below RoIAlign / the AG-RPN input."""
+    cfg = model.cfg
+    N, K = model.n_ways, model.k_shots
+    P = model._P
+    rh = cfg['roi_head']
+    grads: dict = {}
+    dev = tape['roi']['rois'].device
+
+    # ---- mask head (fgn_roi_head.py:360-417) ------------------------------------------------------------
+    tr_, tm = tape['roi'], tape['mask']
+    feats = tr_['feats']
+    d_feats = None
+    C = feats.shape[-1]
+    d_cat_mean_mp = None
+    if tm is not None:
+        mlog = tm['mlog']
+        dlogit = ops.bce_logits_grad(mlog, tm['tgt'], None, 1.0 / float(mlog.numel()), y_threshold=0.5)
+        lw = W['roi_head.mask_head.conv_logits.weight'].reshape(-1).contiguous()
+        d_up, dlw = ops.mask_logits_backward(tm['up'], dlogit, lw, rh['roi_out_size'])
+        grads['roi_head.mask_head.conv_logits.weight'] = dlw.view_as(W['roi_head.mask_head.conv_logits.weight'])
+        grads['roi_head.mask_head.conv_logits.bias'] = dlogit.sum().view(1)
+        wt = W['roi_head.mask_head.upsample.weight']                         # [Cin, Cout, 2, 2]
+        cin_u, cout_u = wt.shape[:2]
+        w4 = wt.permute(2, 3, 1, 0).reshape(4 * cout_u, cin_u)
+        acts = tm['acts']
+        d_upf = d_up.view(-1, 4 * cout_u)
+        dw4 = _mm_tn(d_upf, acts[-1].reshape(-1, cin_u))                     # [4*Cout, Cin]
+        grads['roi_head.mask_head.upsample.weight'] = dw4.view(2, 2, cout_u, cin_u).permute(3, 2, 0, 1).contiguous()
+        grads['roi_head.mask_head.upsample.bias'] = ops.colsum(d_upf).view(4, cout_u).sum(0)
+        dm = torch.matmul(d_upf, w4).view_as(acts[-1])
+        for li in range(len(acts) - 1, -1, -1):
+            name = f'roi_head.mask_head.convs.{li}.conv'
+            dpre = (dm * (acts[li] > 0)).contiguous()                        # ReLU
+            x_in = acts[li - 1] if li > 0 else (tm['mfeat'] * tm['vmask'][:, None, None, :]).contiguous()
+            grads[name + '.weight'] = _conv3x3_wgrad(dpre, x_in)
+            grads[name + '.bias'] = ops.colsum(dpre)
+            dm = _conv3x3_dgrad(dpre, W[name + '.weight'])
+        # dm = gradient of the guided input mfeat * vmask (fgn_roi_head.py:379)
+        d_mfeat = dm * tm['vmask'][:, None, None, :]
+        d_vmask = (dm * tm['mfeat']).sum(dim=(1, 2))                         # [n_pos, C]
+        d_feats = torch.zeros_like(feats)
+        d_feats.index_add_(0, tr_['pos_rows'], d_mfeat)
+        d_cat_mean_mp = torch.zeros((tape['spp']['B'] * N, C), device=dev)
+        d_cat_mean_mp.index_add_(0, tm['rows'], d_vmask)
+
+    # ---- box head losses -> relation head (fgn_roi_head.py:58-118, 253-279, 302-326) ---------------------
+    n = tr_['n_rois']
+    dcls = ops.softmax_ce_grad(tr_['cls_score'], tr_['labels'], tr_['lw'], 1.0 / tr_['avg'])
+    dbbox = torch.zeros((n, N, 4), device=dev)
+    if tr_['pos_pred'] is not None:
+        dpos = ops.smooth_l1_grad(tr_['pos_pred'], tr_['pos_tgt'], None, 1.0 / float(n))
+        dbbox[tr_['pos_rows'], tr_['labels'][tr_['pos_rows']]] = dpos
+    if N == 1:
+        dcls_raw = dcls[:, [1, 0]]
+    else:
+        resh = tr_['cls_raw'].view(n, 2 * N)
+        top = resh[:, 1::2].argmax(dim=1) * 2
+        d_resh = torch.zeros_like(resh)
+        d_resh[:, 1::2] = dcls[:, :N]
+        d_resh[torch.arange(n, device=dev), top] += dcls[:, N]
+        dcls_raw = d_resh.view(n * N, 2)
+    d6 = torch.cat([dcls_raw, dbbox.view(n * N, 4)], 1).contiguous()
+    rel = rh['relation']
+    dQ, dZ, pooled, dgn_w, dgn_b = ops.relation_gn_head_backward(tr_['Q'], tr_['S'], tr_['rois'], P['gn_w'], P['gn_b'],
+                                                                 P['fc_w'], d6, N, rel['gn_groups'], rel['gn_eps'])
+    grads['roi_head.cls_reg_shared_conv_norm.weight'] = dgn_w
+    grads['roi_head.cls_reg_shared_conv_norm.bias'] = dgn_b
+    dfc = _mm_tn(d6, pooled)                                                 # [6, C]
+    dfcb = ops.colsum(d6)
+    grads['roi_head.bbox_head.fc_cls.weight'], grads['roi_head.bbox_head.fc_reg.weight'] = dfc[:2].contiguous(), \
+        dfc[2:].contiguous()
+    grads['roi_head.bbox_head.fc_cls.bias'], grads['roi_head.bbox_head.fc_reg.bias'] = dfcb[:2].contiguous(), \
+        dfcb[2:].contiguous()
+    wrel = W['roi_head.cls_reg_shared_conv.weight'].view(C, 2 * C)
+    wq, ws = wrel[:, :C], wrel[:, C:]
+    dQf = dQ.view(-1, C)
+    d_from_q = torch.matmul(dQf, wq).view_as(feats)
+    d_feats = d_from_q if d_feats is None else d_feats + d_from_q
+    dWq = _mm_tn(dQf, feats.reshape(-1, C))
+    # dS[b, cls] = sum over the RoIs of image b of dZ[r, cls]  (RoIs are image-major: bbox2roi)
+    B = tape['spp']['B']
+    img = tr_['rois'][:, 0].long()
+    counts = torch.bincount(img, minlength=B).tolist()
+    dS = torch.zeros_like(tr_['S'])
+    r0 = 0
+    for b in range(B):
+        if counts[b]:
+            ops.colsum(dZ[r0 * N:(r0 + counts[b]) * N].view(counts[b], -1), out=dS[b * N:(b + 1) * N].view(-1))
+        r0 += counts[b]
+    dSf = dS.view(-1, C)
+    cat_mean = tape['spp']['cat_mean']
+    dWs = _mm_tn(dSf, cat_mean.reshape(-1, C))
+    grads['roi_head.cls_reg_shared_conv.weight'] = torch.cat([dWq, dWs], 1).view_as(
+        W['roi_head.cls_reg_shared_conv.weight'])
+    grads['roi_head.cls_reg_shared_conv.bias'] = ops.colsum(dSf)
+    d_cat_mean = torch.matmul(dSf, ws).view_as(cat_mean)                    # [B*N, 7, 7, C]
+
+    # ---- shared head, RoI batch then support batch (count_spp, fgn_roi_head.py:419-449) ------------------
+    _shared_backward(model, W, tr_['blocks'], d_feats, grads)
+    # cat_mean = mean_k sfeat; cat_mean_mp = mean_{k,p} sfeat * masks7
+    ps = cat_mean.shape[1]
+    d_sfeat = (d_cat_mean / K).repeat_interleave(K, dim=0)
+    if d_cat_mean_mp is not None:
+        m7 = tape['spp']['masks7'].view(-1, ps, ps, 1)
+        d_sfeat = d_sfeat + d_cat_mean_mp.repeat_interleave(K, dim=0)[:, None, None, :] * m7 / float(K * ps * ps)
+    _shared_backward(model, W, tape['spp']['blocks'], d_sfeat.contiguous(), grads)
+
+    # ---- AG-RPN head (fgn_ag_rpn_head.py:48 -> RPNHead.forward_single; losses my_anchor_head.py:402-451) ----
+    t = tape['rpn']
+    A, head, G = t['A'], t['head'], t['head'].shape[0]
+    fh, fw, CH = head.shape[1:]
+    scale = 1.0 / (float(t['n_samples']) * N)                                # avg_factor and the 1/N balancer
+    dx_cat = ops.bce_logits_grad(t['x_cat'], t['y_cat'], t['w_cat'], scale)
+    dhead = torch.zeros((G, fh * fw, CH), device=dev)
+    o = 0
+    oc = 0
+    dpred = ops.smooth_l1_grad(t['preds'], t['tgts'], None, scale) if t['preds'] is not None else None
+    for g, (pos, neg) in enumerate(t['sets']):
+        for idx in (pos, neg):
+            k = idx.numel()
+            if k:
+                dhead[g, idx // A, idx % A] = dx_cat[o:o + k]
+            o += k
+        k = pos.numel()
+        if k:
+            col = (A + 4 * (pos % A))[:, None] + torch.arange(4, device=dev)[None]
+            dhead[g][(pos // A)[:, None].expand(k, 4), col] = dpred[oc:oc + k]
+            oc += k
+    rows = torch.nonzero(dhead.abs().sum(-1).view(-1) > 0).view(-1)          # active (pass, pixel) rows: <= num * G
+    Cf = t['x'].shape[-1]
+    dH = dhead.view(-1, CH)[rows]
+    X = t['x'].reshape(-1, Cf)[rows]
+    wh = torch.cat([W['rpn_head.rpn_cls.weight'].view(A, Cf), W['rpn_head.rpn_reg.weight'].view(4 * A, Cf)], 0)
+    dwh = _mm_tn(dH[:, :5 * A].contiguous(), X)
+    dbh = ops.colsum(dH[:, :5 * A].contiguous())
+    grads['rpn_head.rpn_cls.weight'] = dwh[:A].reshape(W['rpn_head.rpn_cls.weight'].shape).contiguous()
+    grads['rpn_head.rpn_reg.weight'] = dwh[A:].reshape(W['rpn_head.rpn_reg.weight'].shape).contiguous()
+    grads['rpn_head.rpn_cls.bias'], grads['rpn_head.rpn_reg.bias'] = dbh[:A].contiguous(), dbh[A:].contiguous()
+    dpre = (torch.matmul(dH[:, :5 * A], wh) * (X > 0)).contiguous()          # through the ReLU of rpn_conv
+    # rpn_conv weight gradient: only the active pixels contribute; their 3x3 neighbourhoods of the guided map
+    qf, vec = t['qry_fmap'], t['vec']                                        # [B,h,w,C], [B*N,C]
+    Cin = qf.shape[-1]
+    gi = rows // (fh * fw)
+    py, px = (rows % (fh * fw)) // fw, rows % fw
+    qpad = torch.nn.functional.pad(qf, (0, 0, 1, 1, 1, 1))                   # zero border (padding=1)
+    taps = [qpad[gi // N, py + ky, px + kx] for ky in range(3) for kx in range(3)]
+    patches = (torch.stack(taps, 1) * vec[gi][:, None, :]).reshape(rows.numel(), 9 * Cin)
+    grads['rpn_head.rpn_conv.weight'] = _mm_tn(dpre, patches).view(Cf, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+    grads['rpn_head.rpn_conv.bias'] = ops.colsum(dpre)
+    return grads
+
+
+TRAINABLE_PREFIXES = ('rpn_head.', 'roi_head.')
+
+
+def trainable_names(sd: dict) -> list:
+    return [k for k, v in sd.items() if k.startswith(TRAINABLE_PREFIXES) and v.is_floating_point()
+            and 'running_' not in k and 'num_batches' not in k]
+
+
+class Trainer:
+    """Training of the heads on the HIP path: ``step(batch)`` = forward_train (losses) + backward + Adagrad update,
+    the loop body the reference gets from mmcv's runner + torch.optim (main.py training branch with
+    fgn_train_schedule.py:3-13: Adagrad, lr 0.005, weight decay 1e-5, lr_mult 0.1 under ``roi_head``).  The backbone
+    is frozen (fgn_r50_c4_densecl.py:31).  Master weights live on the device in torch layout; the packed kernel
+    layouts are re-derived from them after every update."""
+
+    def __init__(self, model, lr: float = 0.005, weight_decay: float = 1e-5, roi_head_lr_mult: float = 0.1,
+                 eps: float = 1e-10, bn_momentum: float = 0.1):
+        if not torch.cuda.is_available():
+            raise ops._lib.FgnHipError('Trainer needs a GPU: the HIP path has no CPU fallback')
+        self.model, self.lr, self.wd, self.mult, self.eps = model, lr, weight_decay, roi_head_lr_mult, eps
+        self.bn_momentum = bn_momentum
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if model._packed_device != dev:
+            model._pack(dev)
+        self.device = dev
+        sd = model._sd
+        self.W = {k: sd[k].to(dev).float().contiguous().clone() for k in trainable_names(sd)}
+        self.state = {k: torch.zeros_like(v) for k, v in self.W.items()}
+        self.buffers = {k: v.to(dev).float().contiguous().clone() for k, v in sd.items()
+                        if k.startswith('roi_head.shared_head') and 'running_' in k}
+        self.grads: dict = {}
+        self.refresh()
+
+    def refresh(self) -> None:
+        """Re-derive every packed head layer from the master weights (device-side torch ops)."""
+        m = self.model
+        heads = m._pack_heads(self.W)
+        for k, v in heads.items():
+            m._P[k] = v if not isinstance(v, torch.Tensor) else v.float().contiguous()
+        pack_train(m, self.device, self.W, self.buffers)
+        m._graphs = {}
+
+    def forward_backward(self, batch: dict, perm_fn=torch.randperm) -> dict:
+        m = self.model
+        m._tape = {}
+        try:
+            losses = forward_train(m, perm_fn=perm_fn, bn_momentum=self.bn_momentum, **batch)
+            self.grads = backward(m, self.W, m._tape)
+        finally:
+            m._tape = None
+        return losses
+
+    def step(self, batch: dict, perm_fn=torch.randperm) -> dict:
+        losses = self.forward_backward(batch, perm_fn)
+        for k, g in self.grads.items():
+            lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
+            ops.adagrad_step(self.W[k], g.contiguous(), self.state[k], lr, self.wd, self.eps)
+        self.refresh()
+        return losses
+
+    def state_dict(self) -> dict:
+        """The model's state dict with the trained heads and the updated running statistics (CPU tensors)."""
+        sd = dict(self.model._sd)
+        for k, v in self.W.items():
+            sd[k] = v.detach().cpu()
+        for k, v in self.buffers.items():
+            sd[k] = v.detach().cpu()
+        return sd

@@ -247,6 +247,48 @@ int fgn_bn_train_f32(const float* x, int P, int C, const float* gamma, const flo
                      float* running_mean, float* running_var, const float* residual, int relu, void* scratch,
                      float* mean, float* var, float* out, void* stream);
 
+/* ---- backward of the trainable heads (the reference: torch.autograd under fgn.py:125-185) ---------------- */
+
+/* d(sum_i w_i loss_i / avg_factor)/d(prediction) * scale for the three loss forms above (scale carries 1/avg_factor
+ * and any upstream factor such as the 1/N balancer of fgn_ag_rpn_head.py:77-78) */
+int fgn_bce_logits_grad_f32(const float* x, const float* y, const float* w, long long n, float y_threshold, float scale,
+                            float* dx, void* stream);
+int fgn_smooth_l1_grad_f32(const float* pred, const float* target, const float* w, long long n, float beta, float scale,
+                           float* dpred, void* stream);
+int fgn_softmax_ce_grad_f32(const float* logits, const int64_t* labels, const float* w, int n, int n_classes,
+                            float scale, float* dlogits, void* stream);
+
+/* out[c] (+)= sum_r x[r][c]: bias gradients and reductions over RoIs; fp64 partials in a fixed order */
+size_t fgn_colsum_scratch_bytes(int C);
+int fgn_colsum_f32(const float* x, long long R, int C, void* scratch, float* out, int accumulate, void* stream);
+
+/* BatchNorm2d(train) backward on NHWC rows [P,C]: g = dy * [y_post > 0] (y_post optional: the ReLU after the norm);
+ * dx, dgamma, dbeta; g_out (optional) = g, the gradient of the identity branch of relu(bn3(conv3) + identity) */
+size_t fgn_bn_train_backward_scratch_bytes(int C);
+int fgn_bn_train_backward_f32(const float* x_pre, const float* y_post, const float* dy, const float* mean,
+                              const float* var, const float* gamma, float eps, int P, int C, void* scratch, float* dx,
+                              float* g_out, float* dgamma, float* dbeta, void* stream);
+
+/* Backward of fgn_relation_gn_head_f32 (fc_cls|fc_reg -> avg-pool -> ReLU -> GroupNorm -> Q + S): d_out6 [R*N,6] =
+ * (d cls_raw | d reg_raw); dQ [R,49,C]; dZ [R*N,49,C] (summed over the RoIs of an image it is dS); pooled [R*N,C]
+ * (forward value, for the fc weight gradient); dgamma_part / dbeta_part [R,C] (column-summed by the caller) */
+int fgn_relation_gn_head_backward_f32(const float* Q, const float* S, const float* rois, const float* gn_weight,
+                                      const float* gn_bias, const float* fc_weight, const float* d_out6, float* dQ,
+                                      float* dZ, float* pooled, float* dgamma_part, float* dbeta_part, int n_rois,
+                                      int n_ways, int C, int gn_groups, int roi_size, float eps, void* stream);
+
+/* Backward of fgn_mask_logits_f32 (ReLU(deconv) -> conv_logits): up [D,P*P,4,C], dlogit [D,2P,2P] ->
+ * d_up (through the ReLU) and dw_part [D,C] (column-summed by the caller) */
+int fgn_mask_logits_backward_f32(const float* up, const float* dlogit, const float* w, float* d_up, float* dw_part,
+                                 int n_det, int roi_size, int C, void* stream);
+
+/* im2col of a 3x3 / stride 1 / pad 1 input, NHWC: out [n*H*W, 9*C], column (ky*3+kx)*C + ci (weight gradients) */
+int fgn_im2col3x3_f32(const float* x, float* out, int n, int H, int W, int C, void* stream);
+
+/* torch.optim.Adagrad step (fgn_train_schedule.py:5-13): g += wd*p; state += g*g; p -= lr*g/(sqrt(state)+eps) */
+int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr, float weight_decay,
+                         float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
