@@ -260,6 +260,24 @@ def test_forward_train_full_width_given_proposals():
     torch.manual_seed(8)
     got = m.forward_train(proposals=tr_ref['proposals'], **b)
     _compare_losses(got, ref, 2e-4)
+    # gradients at full width (1024-channel relation head with 32-channel GroupNorm groups, 512 / 1024-channel
+    # BatchNorm, 1024 -> 256 mask conv): same bounds as the half-width end-to-end test
+    from fgn_amd.train import Trainer
+    sd_g = {k: v.clone() for k, v in sd.items()}
+    names = [k for k, v in sd_g.items() if k.startswith(T.TRAINABLE_PREFIXES) and v.is_floating_point()
+             and 'running_' not in k]
+    for k in names:
+        sd_g[k].requires_grad_(True)
+    torch.manual_seed(8)
+    T.total_loss(T.forward_train(sd_g, cfg, grad=True, proposals=tr_ref['proposals'], **b)).backward()
+    m2, _ = _models(cfg)
+    trn = Trainer(m2)
+    torch.manual_seed(8)
+    trn.forward_backward(dict(b, proposals=tr_ref['proposals']))
+    rep = _grad_report(trn.grads, {k: sd_g[k].grad for k in names})
+    print('full width, largest gradient errors (max/max, L2/L2):', sorted(rep.items(), key=lambda kv: -kv[1][1])[:4])
+    bad = {k: v for k, v in rep.items() if v[1] > 1e-2 or v[0] > 6e-2}
+    assert not bad, bad
 
 
 def test_forward_train_cfg3_size_runs_and_is_reproducible():
