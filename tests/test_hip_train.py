@@ -466,3 +466,40 @@ def test_relation_head_backward_alone_matches_autograd():
         dS[int(img[r]) * N:(int(img[r]) + 1) * N] += dZc[r]
     assert rel(dS.permute(0, 3, 1, 2), S.grad) <= 2e-5
     assert rel((d6.t() @ pl.cpu()), fcw.grad) <= 2e-5
+
+
+def test_forward_train_edge_cases_match_oracle():
+    """An image without any ground truth beside one whose objects all belong to class 0 (two guided passes of every
+    image see no GT at all: every inside anchor is a negative), and proposals handed in with a score column."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    from oracle import fgn_train_cpu as T
+    cfg = tiny_config(3, 2, width_div=2)
+    m, sd = _models(cfg)
+    b = make_batch(4, 2, 3, 2, 160, 224, 64)
+    b['qry_cat_ids'][0] = torch.zeros_like(b['qry_cat_ids'][0])
+    b['qry_bboxes'][1] = b['qry_bboxes'][1][:0]
+    b['qry_cat_ids'][1] = b['qry_cat_ids'][1][:0]
+    b['qry_isegmaps'][1] = b['qry_isegmaps'][1][:0]
+    tr_ref = {}
+    torch.manual_seed(9)
+    ref = T.forward_train(copy.deepcopy(sd), cfg, trace=tr_ref, **b)
+    m.debug_trace = {}
+    torch.manual_seed(9)
+    got = m.forward_train(**b)
+    s1 = m.debug_trace['samples'][1]
+    assert s1['pos_inds'].numel() == 0 and s1['neg_inds'].numel() == cfg['train_cfg']['rcnn']['num']
+    for s, r in zip(m.debug_trace['samples'], tr_ref['samples']):
+        assert np.array_equal(s['pos_inds'].cpu().numpy(), r['pos_inds'].numpy())
+        assert np.array_equal(s['neg_inds'].cpu().numpy(), r['neg_inds'].numpy())
+    _compare_losses(got, ref, 1e-4)
+    # no ground truth anywhere: zero box / mask losses, like `bbox_pred[pos_inds].sum()` / `mask_pred.sum()` of nothing
+    b['qry_bboxes'][0], b['qry_cat_ids'][0] = b['qry_bboxes'][0][:0], b['qry_cat_ids'][0][:0]
+    b['qry_isegmaps'][0] = b['qry_isegmaps'][0][:0]
+    torch.manual_seed(9)
+    ref = T.forward_train(copy.deepcopy(sd), cfg, **b)
+    m._PT = None
+    torch.manual_seed(9)
+    got = m.forward_train(**b)
+    assert float(got['loss_bbox']) == 0.0 and float(got['loss_mask']) == 0.0 and float(got['loss_rpn_bbox'][0]) == 0.0
+    _compare_losses(got, ref, 1e-4)
