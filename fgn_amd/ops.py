@@ -775,9 +775,10 @@ def dense_mask_rle(masks: torch.Tensor):
 # forward_train pieces (csrc/train.hip)
 # --------------------------------------------------------------------------------------
 def box_assign(boxes: torch.Tensor, gts: torch.Tensor, pos_iou_thr: float, neg_iou_thr: float, min_pos_iou: float,
-               match_low_quality: bool = True, inside: Optional[torch.Tensor] = None, with_overlaps: bool = False):
+               match_low_quality: bool = True, inside: Optional[torch.Tensor] = None, with_overlaps: bool = False,
+               out: Optional[torch.Tensor] = None):
     """MaxIoUAssigner: boxes [n, >=4], gts [k,4] -> gt_inds [n] int32 (-2 not a candidate, -1 ignored, 0 negative,
-    i+1 positive of GT i) (+ max_overlaps [n])."""
+    i+1 positive of GT i) (+ max_overlaps [n]).  ``out``: an int32 [n] slice to write into."""
     _chk(boxes, 'boxes')
     n, k = boxes.shape[0], gts.shape[0]
     if k:
@@ -785,7 +786,13 @@ def box_assign(boxes: torch.Tensor, gts: torch.Tensor, pos_iou_thr: float, neg_i
     if inside is not None:
         _chk(inside, 'inside', torch.uint8)
     L = _lib.load()
-    gt_inds = torch.empty((n,), device=boxes.device, dtype=torch.int32)
+    if out is None:
+        gt_inds = torch.empty((n,), device=boxes.device, dtype=torch.int32)
+    else:
+        _chk(out, 'out', torch.int32)
+        if out.numel() != n:
+            raise _lib.FgnHipError('box_assign: out must hold n entries')
+        gt_inds = out
     mo = torch.zeros((n,), device=boxes.device, dtype=torch.float32) if with_overlaps else None
     scratch = torch.empty(L.fgn_box_assign_scratch_bytes(n, k), device=boxes.device, dtype=torch.uint8)
     rc = L.fgn_box_assign_f32(_ptr(boxes), boxes.shape[1], _ptr(inside), _ptr(gts) if k else None, n, k,

@@ -136,19 +136,23 @@ def _anchors_for(model, fh: int, fw: int, img_hw, dev):
     return hit
 
 
-def _choose(cand: torch.Tensor, num: int, perm_fn) -> torch.Tensor:
+def _choose(cand: np.ndarray, num: int, perm_fn) -> np.ndarray:
     """RandomSampler._sample_pos/_sample_neg + the ``unique()`` of BaseSampler.sample: at most ``num`` of ``cand``
     (ascending indices), drawn with the CPU permutation mmdet draws (my_random_sampler.py:58-59)."""
-    if cand.numel() > num:
-        perm = perm_fn(cand.numel())[:num].to(cand.device)
-        cand = torch.sort(cand[perm]).values
+    if cand.size > num:
+        cand = np.sort(cand[perm_fn(cand.size)[:num].numpy()])
     return cand
 
 
-def _sample(gt_inds: torch.Tensor, num: int, pos_fraction: float, perm_fn):
-    pos = _choose(torch.nonzero(gt_inds > 0).view(-1), int(num * pos_fraction), perm_fn)
-    neg = _choose(torch.nonzero(gt_inds == 0).view(-1), num - pos.numel(), perm_fn)
+def _sample(gt_inds: np.ndarray, num: int, pos_fraction: float, perm_fn):
+    """On the host copy of the assignment: one device->host copy per stage replaces a sync per sampled set."""
+    pos = _choose(np.flatnonzero(gt_inds > 0), int(num * pos_fraction), perm_fn)
+    neg = _choose(np.flatnonzero(gt_inds == 0), num - pos.size, perm_fn)
     return pos, neg
+
+
+def _dev_idx(a, dev) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
 
 
 def _zero(dev):
@@ -178,8 +182,10 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
 
     # ---- modify_input (fgn.py:79-108): H2D, YXYX -> XYXY on private copies
     qry = qry_img.to(dev, torch.float32, non_blocking=True)
-    gt_xyxy = [b.to(dev, torch.float32)[:, [1, 0, 3, 2]].contiguous() for b in qry_bboxes]
-    cat_ids = [torch.as_tensor(c).to(dev, torch.int64) for c in qry_cat_ids]
+    gt_h = [torch.as_tensor(b).detach().cpu().float().reshape(-1, 4)[:, [1, 0, 3, 2]].contiguous().numpy()
+            for b in qry_bboxes]                                            # host copies drive the bookkeeping
+    cat_h = [torch.as_tensor(c).detach().cpu().long().reshape(-1).numpy() for c in qry_cat_ids]
+    gt_xyxy = [torch.from_numpy(g).to(dev, non_blocking=True) for g in gt_h]
     ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
     if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
         raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
@@ -206,72 +212,90 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     flat = head.reshape(G, fh * fw, head.shape[-1])
     logits_all = flat[:, :, :A].reshape(G, n_total)
     deltas_all = flat[:, :, A:5 * A].reshape(G, n_total, 4)
-    xs, ys, preds, tgts = [], [], [], []
-    n_pos_total = n_neg_total = 0
-    rpn_sets = []
+    # per-(image, class) GT lists (fgn_ag_rpn_head.py:58-73), assignment of all G guided passes, then ONE copy of the
+    # assignment to the host, where the reference-style sampling bookkeeping runs
+    grp_gt_h = [gt_h[g // N][cat_h[g // N] == (g % N)] for g in range(G)]
+    gi_all = torch.empty((G, n_total), device=dev, dtype=torch.int32)
     for g in range(G):
-        i, j = divmod(g, N)
-        gts = gt_xyxy[i][torch.nonzero(cat_ids[i] == j).view(-1)]          # per-class GT list, image-major order
-        gi = ops.box_assign(anchors, gts, tc['pos_iou_thr'], tc['neg_iou_thr'], tc['min_pos_iou'],
-                            tc['match_low_quality'], inside=inside)
-        pos, neg = _sample(gi, tc['num'], tc['pos_fraction'], perm_fn)
-        rpn_sets.append((pos, neg))
-        n_pos_total += max(pos.numel(), 1)
-        n_neg_total += max(neg.numel(), 1)
-        xs += [logits_all[g][pos], logits_all[g][neg]]
-        ys += [torch.ones(pos.numel(), device=dev), torch.zeros(neg.numel(), device=dev)]
-        if pos.numel():
-            preds.append(deltas_all[g][pos])
-            tgts.append(ops.bbox2delta(anchors[pos].contiguous(), gts[(gi[pos] - 1).long()].contiguous(),
-                                       rp['target_means'], rp['target_stds']))
+        gts = torch.from_numpy(grp_gt_h[g]).to(dev, non_blocking=True) if len(grp_gt_h[g]) else gt_xyxy[0][:0]
+        ops.box_assign(anchors, gts, tc['pos_iou_thr'], tc['neg_iou_thr'], tc['min_pos_iou'], tc['match_low_quality'],
+                       inside=inside, out=gi_all[g])
+    gi_host = gi_all.cpu().numpy()
+    n_pos_total = n_neg_total = 0
+    sets_h, flat, ycat, pos_flat, pos_anchor, pos_gt = [], [], [], [], [], []
+    for g in range(G):
+        pos, neg = _sample(gi_host[g], tc['num'], tc['pos_fraction'], perm_fn)
+        sets_h.append((pos, neg))
+        n_pos_total += max(pos.size, 1)
+        n_neg_total += max(neg.size, 1)
+        flat += [g * n_total + pos, g * n_total + neg]
+        ycat += [np.ones(pos.size, np.float32), np.zeros(neg.size, np.float32)]
+        if pos.size:
+            pos_flat.append(g * n_total + pos)
+            pos_anchor.append(pos)
+            pos_gt.append(grp_gt_h[g][gi_host[g][pos] - 1])
     n_samples = n_pos_total + n_neg_total
     pw = 1.0 if tc['pos_weight'] <= 0 else float(tc['pos_weight'])
-    x_cat, y_cat = torch.cat(xs).contiguous(), torch.cat(ys).contiguous()
+    x_cat = logits_all.reshape(-1)[_dev_idx(np.concatenate(flat), dev)].contiguous()
+    y_cat = torch.from_numpy(np.concatenate(ycat)).to(dev, non_blocking=True)
     w_cat = None if pw == 1.0 else torch.where(y_cat > 0, pw, 1.0).float().contiguous()
     loss_rpn_cls = ops.bce_logits_sum(x_cat, y_cat, w_cat, n_samples) / N              # the 1/N balancer
-    loss_rpn_bbox = (ops.smooth_l1_sum(torch.cat(preds).contiguous(), torch.cat(tgts).contiguous(), None, n_samples)
-                     if preds else torch.zeros(1, device=dev)) / N
+    preds = tgts = None
+    if pos_flat:
+        preds = deltas_all.reshape(-1, 4)[_dev_idx(np.concatenate(pos_flat), dev)].contiguous()
+        tgts = ops.bbox2delta(anchors[_dev_idx(np.concatenate(pos_anchor), dev)].contiguous(),
+                              torch.from_numpy(np.concatenate(pos_gt).astype(np.float32)).to(dev),
+                              rp['target_means'], rp['target_stds'])
+        loss_rpn_bbox = ops.smooth_l1_sum(preds, tgts, None, n_samples) / N
+    else:
+        loss_rpn_bbox = torch.zeros(1, device=dev)
     losses = {'loss_rpn_cls': [loss_rpn_cls.view(())], 'loss_rpn_bbox': [loss_rpn_bbox.view(())]}
+    rpn_sets = [(torch.from_numpy(p_), torch.from_numpy(n_)) for p_, n_ in sets_h]
     if tr is not None:
         tr.update(qry_fmap=qry_fmap, rpn_head=head, rpn_sets=rpn_sets, rpn_num_total_samples=n_samples)
     if tape is not None:
-        tape['rpn'] = dict(x=x, head=head, sets=rpn_sets, x_cat=x_cat, y_cat=y_cat, w_cat=w_cat, n_samples=n_samples,
-                           preds=torch.cat(preds).contiguous() if preds else None,
-                           tgts=torch.cat(tgts).contiguous() if tgts else None, qry_fmap=qry_fmap, vec=sc['vec'],
-                           A=A, n_ways=N)
+        tape['rpn'] = dict(x=x, head=head, sets=sets_h, x_cat=x_cat, y_cat=y_cat, w_cat=w_cat, n_samples=n_samples,
+                           preds=preds, tgts=tgts, qry_fmap=qry_fmap, vec=sc['vec'], A=A, n_ways=N, n_total=n_total)
 
     # ---- proposals with train_cfg.rpn_proposal (fgn.py:161-167)
+    rc = tcfg['rcnn']
     if proposals is None:
         pc = tcfg['rpn_proposal']
         _, scores, deltas = ops.rpn_merge(head, B, N, A)
         props, n_props = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
                                            rp['target_means'], rp['target_stds'], pc['nms_pre'], pc['min_bbox_size'],
                                            pc['nms_iou_threshold'], pc['max_per_img'])
-        counts = n_props.tolist()
-        proposals = [props[i, :counts[i]] for i in range(B)]
+        prop_list = [props[i] for i in range(B)]           # rows past n_props[i] are zero boxes, never sampled
     else:
-        proposals = [torch.as_tensor(p).to(dev, torch.float32).contiguous() for p in proposals]
-    if tr is not None:
-        tr['proposals'] = proposals
+        prop_list = [torch.as_tensor(p).to(dev, torch.float32).contiguous() for p in proposals]
+        n_props = torch.tensor([p.shape[0] for p in prop_list], device=dev, dtype=torch.int32)
 
-    # ---- FGNRoIHead.forward_train (fgn_roi_head.py:451-529): assign + sample per image
-    rc = tcfg['rcnn']
-    samples = []
+    # ---- FGNRoIHead.forward_train (fgn_roi_head.py:451-529): assign per image, one copy to the host, sample there
+    gis = [ops.box_assign(prop_list[i], gt_xyxy[i], rc['pos_iou_thr'], rc['neg_iou_thr'], rc['min_pos_iou'],
+                          rc['match_low_quality']) if prop_list[i].shape[0] else
+           torch.zeros((0,), device=dev, dtype=torch.int32) for i in range(B)]
+    packed = torch.cat(gis + [n_props.to(torch.int32)]).cpu().numpy()
+    counts = packed[-B:].tolist()
+    if tr is not None:
+        tr['proposals'] = [prop_list[i][:counts[i]] for i in range(B)]
+    samples, roi_parts, lab_parts, off = [], [], [], 0
     for i in range(B):
-        pr, gts = proposals[i], gt_xyxy[i]
-        k = gts.shape[0]
-        gi = ops.box_assign(pr, gts, rc['pos_iou_thr'], rc['neg_iou_thr'], rc['min_pos_iou'],
-                            rc['match_low_quality']) if pr.shape[0] else \
-            torch.zeros((0,), device=dev, dtype=torch.int32)
-        boxes = pr[:, :4]
+        gi = packed[off:off + counts[i]]
+        off += prop_list[i].shape[0]
+        k = gt_h[i].shape[0]
+        boxes = prop_list[i][:, :4]
         if rc['add_gt_as_proposals'] and k > 0:           # BaseSampler.sample: GT boxes in front, assigned to themselves
-            boxes = torch.cat([gts, boxes])
-            gi = torch.cat([torch.arange(1, k + 1, device=dev, dtype=torch.int32), gi])
+            boxes = torch.cat([gt_xyxy[i], boxes])
+            gi = np.concatenate([np.arange(1, k + 1, dtype=np.int32), gi])
         pos, neg = _sample(gi, rc['num'], rc['pos_fraction'], perm_fn)
-        assigned = (gi[pos] - 1).long()
-        samples.append(dict(pos_bboxes=boxes[pos], neg_bboxes=boxes[neg], pos_assigned_gt_inds=assigned,
-                            pos_gt_bboxes=gts[assigned] if k else gts.view(-1, 4)[:0],
-                            pos_gt_labels=cat_ids[i][assigned] if k else cat_ids[i][:0], pos_inds=pos, neg_inds=neg))
+        assigned = (gi[pos] - 1).astype(np.int64)
+        sel = boxes[_dev_idx(np.concatenate([pos, neg]), dev)]
+        samples.append(dict(pos_bboxes=sel[:pos.size], n_pos=int(pos.size), n_neg=int(neg.size),
+                            pos_assigned_gt_inds=assigned, pos_gt_bboxes_h=gt_h[i][assigned].reshape(-1, 4),
+                            pos_gt_labels=torch.from_numpy(cat_h[i][assigned]), pos_inds=torch.from_numpy(pos),
+                            neg_inds=torch.from_numpy(neg)))
+        roi_parts.append(torch.cat([torch.full((sel.shape[0], 1), float(i), device=dev), sel], 1))
+        lab_parts.append(np.concatenate([cat_h[i][assigned], np.full(neg.size, N, np.int64)]))
     if tr is not None:
         tr['samples'] = samples
 
@@ -280,9 +304,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum, spp_tape))
 
     # _bbox_forward_train (fgn_roi_head.py:344-358)
-    rois = torch.cat([torch.cat([torch.full((len(s['pos_bboxes']) + len(s['neg_bboxes']), 1), float(i), device=dev),
-                                 torch.cat([s['pos_bboxes'], s['neg_bboxes']])], 1) for i, s in enumerate(samples)])
-    rois = rois.contiguous()
+    rois = torch.cat(roi_parts).contiguous()
     n_rois = rois.shape[0]
     rel, bh = rh['relation'], rh['bbox_head']
     if n_rois:
@@ -307,22 +329,25 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         cls_score = torch.zeros((0, N + 1), device=dev)
         bbox_pred = torch.zeros((0, 4 * N), device=dev)
     # FGNBBoxHead.get_targets / loss (fgn_roi_head.py:58-160): background label = n_ways
-    labels = torch.cat([torch.cat([s['pos_gt_labels'], torch.full((len(s['neg_bboxes']),), N, device=dev,
-                                                                  dtype=torch.int64)]) for s in samples]).contiguous()
-    pos_rows = torch.nonzero(labels < N).view(-1)
+    lab_h = np.concatenate(lab_parts) if lab_parts else np.zeros(0, np.int64)
+    labels = torch.from_numpy(lab_h).to(dev)
+    pos_rows_h = np.flatnonzero(lab_h < N)
+    pos_rows = _dev_idx(pos_rows_h, dev)
     pw = 1.0 if rc['pos_weight'] <= 0 else float(rc['pos_weight'])
     lw = None if pw == 1.0 else torch.where(labels < N, pw, 1.0).float().contiguous()
     avg = max(float(n_rois), 1.0)                     # every sampled RoI has label weight > 0
     if n_rois:
         losses['loss_cls'] = ops.softmax_ce_sum(cls_score, labels, lw, avg).view(())
-        pred_h, lab_h = cls_score.argmax(dim=-1).cpu().numpy(), labels.cpu().numpy()     # get_accuracy: on the host
+        pred_h = cls_score.argmax(dim=-1).cpu().numpy()                                   # get_accuracy: on the host
         acc = float((pred_h == lab_h).mean())
         bal = float(np.mean([(pred_h[lab_h == c] == c).mean() for c in np.unique(lab_h)]))
         losses['ACC-Unbalanced'], losses['ACC-Balanced'] = torch.Tensor([acc]), torch.Tensor([bal])
-    if pos_rows.numel():
+    pos_pred = pos_tgt = None
+    if pos_rows_h.size:
         pos_pred = bbox_pred.view(n_rois, -1, 4)[pos_rows, labels[pos_rows]].contiguous()
         pos_tgt = ops.bbox2delta(torch.cat([s['pos_bboxes'] for s in samples]).contiguous(),
-                                 torch.cat([s['pos_gt_bboxes'] for s in samples]).contiguous(),
+                                 torch.from_numpy(np.concatenate([s['pos_gt_bboxes_h'] for s in samples])
+                                                  .astype(np.float32)).to(dev),
                                  bh['target_means'], bh['target_stds'])
         losses['loss_bbox'] = ops.smooth_l1_sum(pos_pred, pos_tgt, None, float(n_rois)).view(())
     else:
@@ -334,15 +359,16 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
             raise ValueError('training step without a single sampled RoI')
         tape['roi'] = dict(rois=rois, blocks=roi_tape, feats=feats, Q=Q, S=sc['S'], cls_raw=cls_raw, cls_score=cls_score,
                            bbox_pred=bbox_pred, labels=labels, lw=lw, avg=avg, pos_rows=pos_rows, n_rois=n_rois,
-                           pos_pred=pos_pred if pos_rows.numel() else None,
-                           pos_tgt=pos_tgt if pos_rows.numel() else None)
+                           pos_pred=pos_pred, pos_tgt=pos_tgt,
+                           img_counts=[s['n_pos'] + s['n_neg'] for s in samples])
         tape['spp'] = dict(blocks=spp_tape, masks7=sc['masks7'], cat_mean=sc['cat_mean'], B=B)
 
     # ---- mask branch (fgn_roi_head.py:498-527, 384-417): shared RoI extractor -> the positives' bbox_feats
-    n_pos = int(pos_rows.numel())
+    n_pos = int(pos_rows_h.size)
     if n_pos:
-        img_of = rois[pos_rows, 0].long()
-        vmask = sc['cat_mean_mp'][labels[pos_rows] + N * img_of].contiguous()          # spp_vecs_mask
+        img_of_h = np.concatenate([np.full(s['n_pos'], i, np.int64) for i, s in enumerate(samples)])
+        vrows = _dev_idx(lab_h[pos_rows_h] + N * img_of_h, dev)
+        vmask = sc['cat_mean_mp'][vrows].contiguous()                                     # spp_vecs_mask
         mfeat = feats[pos_rows].contiguous()
         if tape is None:
             mlog, _ = model._mask_head(mfeat, vmask)
@@ -350,17 +376,17 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
             mlog, macts, mup = _mask_head_taped(model, mfeat, vmask)
         # mask_target_single + BitmapMasks.crop_and_resize: RoIAlign(aligned, adaptive grid) of the GT bitmaps
         gt_masks = []
-        for m in qry_isegmaps:
-            m = torch.as_tensor(m).to(dev)
-            gt_masks.append((m if m.dtype in (torch.bool, torch.uint8) else (m != 0)).to(torch.uint8))
-        first = np.cumsum([0] + [m.shape[0] for m in gt_masks[:-1]])
+        for m_ in qry_isegmaps:
+            m_ = torch.as_tensor(m_).to(dev, non_blocking=True)
+            gt_masks.append((m_ if m_.dtype in (torch.bool, torch.uint8) else (m_ != 0)).to(torch.uint8))
+        first = np.cumsum([0] + [m_.shape[0] for m_ in gt_masks[:-1]])
         masks_all = torch.cat(gt_masks).contiguous()
         mh_, mw_ = masks_all.shape[-2:]
         pb = torch.cat([s['pos_bboxes'] for s in samples])
         pb = torch.stack([pb[:, 0].clamp(0, mw_), pb[:, 1].clamp(0, mh_), pb[:, 2].clamp(0, mw_),
                           pb[:, 3].clamp(0, mh_)], 1)
-        gidx = torch.cat([s['pos_assigned_gt_inds'] + int(first[i]) for i, s in enumerate(samples)])
-        mrois = torch.cat([gidx.float()[:, None], pb], 1).contiguous()
+        gidx = np.concatenate([s['pos_assigned_gt_inds'] + int(first[i]) for i, s in enumerate(samples)])
+        mrois = torch.cat([torch.from_numpy(gidx.astype(np.float32)).to(dev)[:, None], pb], 1).contiguous()
         ms = rc['mask_size']
         tgt = ops.roi_align_mask(masks_all, mrois, ms, 1.0, 0, True)                  # [n_pos, ms, ms] in [0,1]
         if tuple(mlog.shape[1:]) != (ms, ms):
@@ -369,8 +395,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         if tr is not None:
             tr.update(mask_pred=mlog, mask_targets_soft=tgt)
         if tape is not None:
-            tape['mask'] = dict(mfeat=mfeat, vmask=vmask, acts=macts, up=mup, mlog=mlog.contiguous(), tgt=tgt,
-                                rows=labels[pos_rows] + N * img_of)
+            tape['mask'] = dict(mfeat=mfeat, vmask=vmask, acts=macts, up=mup, mlog=mlog.contiguous(), tgt=tgt, rows=vrows)
     else:
         losses['loss_mask'] = _zero(dev)
         if tape is not None:
@@ -537,8 +562,7 @@ def backward(model, W: dict, tape: dict) -> dict:
     dWq = _mm_tn(dQf, feats.reshape(-1, C))
     # dS[b, cls] = sum over the RoIs of image b of dZ[r, cls]  (RoIs are image-major: bbox2roi)
     B = tape['spp']['B']
-    img = tr_['rois'][:, 0].long()
-    counts = torch.bincount(img, minlength=B).tolist()
+    counts = tr_['img_counts']
     dS = torch.zeros_like(tr_['S'])
     r0 = 0
     for b in range(B):
@@ -570,20 +594,18 @@ def backward(model, W: dict, tape: dict) -> dict:
     scale = 1.0 / (float(t['n_samples']) * N)                                # avg_factor and the 1/N balancer
     dx_cat = ops.bce_logits_grad(t['x_cat'], t['y_cat'], t['w_cat'], scale)
     dhead = torch.zeros((G, fh * fw, CH), device=dev)
-    o = 0
-    oc = 0
     dpred = ops.smooth_l1_grad(t['preds'], t['tgts'], None, scale) if t['preds'] is not None else None
+    # one scatter for the objectness columns, one for the delta columns (flat indices built on the host)
+    hw = fh * fw
+    li, ri = [], []
     for g, (pos, neg) in enumerate(t['sets']):
         for idx in (pos, neg):
-            k = idx.numel()
-            if k:
-                dhead[g, idx // A, idx % A] = dx_cat[o:o + k]
-            o += k
-        k = pos.numel()
-        if k:
-            col = (A + 4 * (pos % A))[:, None] + torch.arange(4, device=dev)[None]
-            dhead[g][(pos // A)[:, None].expand(k, 4), col] = dpred[oc:oc + k]
-            oc += k
+            li.append((g * hw + idx // A) * CH + idx % A)
+        ri.append(((g * hw + pos // A) * CH + A + 4 * (pos % A))[:, None] + np.arange(4)[None])
+    dflat = dhead.view(-1)
+    dflat[_dev_idx(np.concatenate(li), dev)] = dx_cat
+    if dpred is not None:
+        dflat[_dev_idx(np.concatenate(ri).reshape(-1), dev)] = dpred.reshape(-1)
     rows = torch.nonzero(dhead.abs().sum(-1).view(-1) > 0).view(-1)          # active (pass, pixel) rows: <= num * G
     Cf = t['x'].shape[-1]
     dH = dhead.view(-1, CH)[rows]

@@ -184,14 +184,18 @@ def _models(cfg, seed=0):
     return m, sd
 
 
+def _f(v):
+    v = v[0] if isinstance(v, list) else v
+    return float(v.detach().reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v)
+
+
 def _compare_losses(got, ref, rel):
     for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
         assert isinstance(got[k], list) and len(got[k]) == 1
-        assert float(got[k][0]) == pytest.approx(float(ref[k][0]), rel=rel, abs=1e-7), k
-    for k in ('loss_cls', 'loss_bbox', 'loss_mask'):
-        assert float(got[k]) == pytest.approx(float(ref[k]), rel=rel, abs=1e-7), k
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'loss_mask'):
+        assert _f(got[k]) == pytest.approx(_f(ref[k]), rel=rel, abs=1e-7), k
     for k in ('ACC-Unbalanced', 'ACC-Balanced'):
-        assert float(got[k]) == pytest.approx(float(ref[k]), abs=1e-6), k
+        assert _f(got[k]) == pytest.approx(_f(ref[k]), abs=1e-6), k
     assert set(got) == set(ref)
 
 
