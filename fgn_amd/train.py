@@ -683,7 +683,13 @@ class Trainer:
         return losses
 
     def step(self, batch: dict, perm_fn=torch.randperm) -> dict:
+        """One optimisation step on this rank's batch.  Under an initialised ``torch.distributed`` group (one process
+        per GPU, backend "nccl" = RCCL) the gradients are averaged over the ranks first - one all-reduce of one flat
+        bucket - so every rank applies the same update (data-parallel training; BatchNorm statistics stay per rank,
+        like torch DDP without SyncBN)."""
         losses = self.forward_backward(batch, perm_fn)
+        from .dist import allreduce_mean
+        self.grads = allreduce_mean(self.grads)
         for k, g in self.grads.items():
             lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
             ops.adagrad_step(self.W[k], g.contiguous(), self.state[k], lr, self.wd, self.eps)

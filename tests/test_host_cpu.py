@@ -196,6 +196,39 @@ def test_episode_sharding_and_gather_world2_gloo():
         assert r[5][3][1] == [0, 0, 0] and r[5][2][1] == [2, 2] and r[5][3][2] == (3, 4)
 
 
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from fgn_amd import dist as fd
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        g = {'b.weight': torch.full((3, 2), float(rank + 1)), 'a.bias': torch.arange(4, dtype=torch.float32) * (rank + 1)}
+        out = fd.allreduce_mean(g)
+        q.put((rank, out['b.weight'].tolist(), out['a.bias'].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    """Data-parallel training: every rank ends with the mean gradient, one flat bucket, key order independent of the
+    dict's insertion order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in out:
+        assert r[1] == [[1.5, 1.5]] * 3 and r[2] == [0.0, 1.5, 3.0, 4.5]
+    from fgn_amd import dist as fd
+    g = {'x': torch.ones(2)}
+    assert fd.allreduce_mean(g) is g                      # no process group: unchanged
+
+
 def test_gather_is_identity_without_process_group():
     from fgn_amd import dist as fd
     recs, cnts = fd.pack_detections([_fake_det(3), _fake_det(6)], 4)
