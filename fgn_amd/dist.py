@@ -123,7 +123,7 @@ def _hip_rle(prob, boxes, h, w, thr):
 # ------------------------------------------------------------------------------------------
 def allreduce_mean(tensors: dict) -> dict:
     """Average a dict of same-device fp32 tensors over the ranks with a single all-reduce of one flat bucket (the heads
-    hold ~34 M parameters: one 136 MB message per step - bandwidth-bound on the xGMI ring, never one collective per
+    hold ~26 M parameters: one 105 MB message per step - bandwidth-bound on the xGMI ring, never one collective per
     tensor).  Keys are visited in sorted order so that every rank builds the same bucket.  No process group or a
     single rank: the dict is returned unchanged."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not tensors:
