@@ -90,6 +90,26 @@ extern "C" int fgn_softmax_ce_grad_f32(const float* logits, const int64_t* label
     return FGN_OK;
 }
 
+// ReLU backward: out = dy * [y > 0]  (y = the ReLU's output)
+__global__ void relu_backward_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ out,
+                                     long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 d = dy[i], v = y[i];
+        out[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+    }
+}
+
+extern "C" int fgn_relu_backward_f32(const float* dy, const float* y, float* out, long long n, hipStream_t stream) {
+    if (n > 0 && (!dy || !y || !out)) return FGN_ERR_ARG;
+    if (n % 4) return FGN_ERR_SHAPE;
+    if (n <= 0) return FGN_OK;
+    hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y),
+                       reinterpret_cast<float4*>(out), n / 4);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Column sums of x [R, C] (bias gradients, reductions over RoIs): fp64 partials over row chunks, fixed order.
 // ---------------------------------------------------------------------------------------------------------

@@ -66,6 +66,7 @@ SIGNATURES = {
     'fgn_bce_logits_grad_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _p, _p]),
     'fgn_smooth_l1_grad_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _p, _p]),
     'fgn_softmax_ce_grad_f32': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
+    'fgn_relu_backward_f32': (_i, [_p, _p, _p, C.c_longlong, _p]),
     'fgn_colsum_scratch_bytes': (C.c_size_t, [_i]),
     'fgn_colsum_f32': (_i, [_p, C.c_longlong, _i, _p, _p, _i, _p]),
     'fgn_bn_train_backward_scratch_bytes': (C.c_size_t, [_i]),
@@ -76,7 +77,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 

@@ -917,6 +917,18 @@ def softmax_ce_grad(logits, labels, w, scale: float) -> torch.Tensor:
     return d
 
 
+def relu_backward(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dy * [y > 0] (y: the ReLU's output)."""
+    _chk(dy, 'dy')
+    _chk(y, 'y')
+    if dy.numel() != y.numel():
+        raise _lib.FgnHipError('relu_backward: operand sizes differ')
+    out = torch.empty_like(dy)
+    rc = _lib.load().fgn_relu_backward_f32(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), _stream())
+    _lib.check(rc, 'fgn_relu_backward_f32')
+    return out
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """x [..., C] -> [C] = sum over all leading dims (fp64 partials, fixed order)."""
     _chk(x, 'x')

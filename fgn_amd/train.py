@@ -513,13 +513,13 @@ def backward(model, W: dict, tape: dict) -> dict:
         dm = torch.matmul(d_upf, w4).view_as(acts[-1])
         for li in range(len(acts) - 1, -1, -1):
             name = f'roi_head.mask_head.convs.{li}.conv'
-            dpre = (dm * (acts[li] > 0)).contiguous()                        # ReLU
+            dpre = ops.relu_backward(dm.contiguous(), acts[li])                # ReLU
             x_in = acts[li - 1] if li > 0 else (tm['mfeat'] * tm['vmask'][:, None, None, :]).contiguous()
             grads[name + '.weight'] = _conv3x3_wgrad(dpre, x_in)
             grads[name + '.bias'] = ops.colsum(dpre)
             dm = _conv3x3_dgrad(dpre, W[name + '.weight'])
         # dm = gradient of the guided input mfeat * vmask (fgn_roi_head.py:379)
-        d_mfeat = dm * tm['vmask'][:, None, None, :]
+        d_mfeat = ops.scale_channels(dm.contiguous(), tm['vmask'], 1)          # dm * vmask per (RoI, channel)
         d_vmask = (dm * tm['mfeat']).sum(dim=(1, 2))                         # [n_pos, C]
         d_feats = torch.zeros_like(feats)
         d_feats.index_add_(0, tr_['pos_rows'], d_mfeat)
@@ -616,7 +616,7 @@ def backward(model, W: dict, tape: dict) -> dict:
     grads['rpn_head.rpn_cls.weight'] = dwh[:A].reshape(W['rpn_head.rpn_cls.weight'].shape).contiguous()
     grads['rpn_head.rpn_reg.weight'] = dwh[A:].reshape(W['rpn_head.rpn_reg.weight'].shape).contiguous()
     grads['rpn_head.rpn_cls.bias'], grads['rpn_head.rpn_reg.bias'] = dbh[:A].contiguous(), dbh[A:].contiguous()
-    dpre = (torch.matmul(dH[:, :5 * A], wh) * (X > 0)).contiguous()          # through the ReLU of rpn_conv
+    dpre = ops.relu_backward(torch.matmul(dH[:, :5 * A], wh), X.contiguous())  # through the ReLU of rpn_conv
     # rpn_conv weight gradient: only the active pixels contribute; their 3x3 neighbourhoods of the guided map
     qf, vec = t['qry_fmap'], t['vec']                                        # [B,h,w,C], [B*N,C]
     Cin = qf.shape[-1]

@@ -258,6 +258,9 @@ int fgn_smooth_l1_grad_f32(const float* pred, const float* target, const float* 
 int fgn_softmax_ce_grad_f32(const float* logits, const int64_t* labels, const float* w, int n, int n_classes,
                             float scale, float* dlogits, void* stream);
 
+/* ReLU backward: out = dy * [y > 0], y = the ReLU's output; n % 4 == 0 (mask convs, rpn_conv) */
+int fgn_relu_backward_f32(const float* dy, const float* y, float* out, long long n, void* stream);
+
 /* out[c] (+)= sum_r x[r][c]: bias gradients and reductions over RoIs; fp64 partials in a fixed order */
 size_t fgn_colsum_scratch_bytes(int C);
 int fgn_colsum_f32(const float* x, long long R, int C, void* scratch, float* out, int accumulate, void* stream);
