@@ -212,15 +212,37 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     flat = head.reshape(G, fh * fw, head.shape[-1])
     logits_all = flat[:, :, :A].reshape(G, n_total)
     deltas_all = flat[:, :, A:5 * A].reshape(G, n_total, 4)
-    # per-(image, class) GT lists (fgn_ag_rpn_head.py:58-73), assignment of all G guided passes, then ONE copy of the
-    # assignment to the host, where the reference-style sampling bookkeeping runs
+    # per-(image, class) GT lists (fgn_ag_rpn_head.py:58-73) and the assignment of all G guided passes
     grp_gt_h = [gt_h[g // N][cat_h[g // N] == (g % N)] for g in range(G)]
     gi_all = torch.empty((G, n_total), device=dev, dtype=torch.int32)
     for g in range(G):
         gts = torch.from_numpy(grp_gt_h[g]).to(dev, non_blocking=True) if len(grp_gt_h[g]) else gt_xyxy[0][:0]
         ops.box_assign(anchors, gts, tc['pos_iou_thr'], tc['neg_iou_thr'], tc['min_pos_iou'], tc['match_low_quality'],
                        inside=inside, out=gi_all[g])
-    gi_host = gi_all.cpu().numpy()
+    # ---- proposals with train_cfg.rpn_proposal (fgn.py:161-167)
+    rc = tcfg['rcnn']
+    if proposals is None:
+        pc = tcfg['rpn_proposal']
+        _, scores, deltas = ops.rpn_merge(head, B, N, A)
+        props, n_props = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
+                                           rp['target_means'], rp['target_stds'], pc['nms_pre'], pc['min_bbox_size'],
+                                           pc['nms_iou_threshold'], pc['max_per_img'])
+        prop_list = [props[i] for i in range(B)]           # rows past n_props[i] are zero boxes, never sampled
+    else:
+        prop_list = [torch.as_tensor(p).to(dev, torch.float32).contiguous() for p in proposals]
+        n_props = torch.tensor([p.shape[0] for p in prop_list], device=dev, dtype=torch.int32)
+
+    # FGNRoIHead.forward_train (fgn_roi_head.py:451-529): assignment of every image's proposals
+    gis = [ops.box_assign(prop_list[i], gt_xyxy[i], rc['pos_iou_thr'], rc['neg_iou_thr'], rc['min_pos_iou'],
+                          rc['match_low_quality']) if prop_list[i].shape[0] else
+           torch.zeros((0,), device=dev, dtype=torch.int32) for i in range(B)]
+    # count_spp with the shared head in training mode (fgn_roi_head.py:491, 419-449): queued before the host copy too
+    spp_tape = [] if tape is not None else None
+    model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum, spp_tape))
+    # ONE device->host copy (one sync) per step: both stages' assignment vectors and the proposal counts; the
+    # reference-style sampling bookkeeping then runs on the host copy
+    packed_all = torch.cat([gi_all.view(-1)] + gis + [n_props.to(torch.int32)]).cpu().numpy()
+    gi_host = packed_all[:G * n_total].reshape(G, n_total)
     n_pos_total = n_neg_total = 0
     sets_h, flat, ycat, pos_flat, pos_anchor, pos_gt = [], [], [], [], [], []
     for g in range(G):
@@ -257,24 +279,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         tape['rpn'] = dict(x=x, head=head, sets=sets_h, x_cat=x_cat, y_cat=y_cat, w_cat=w_cat, n_samples=n_samples,
                            preds=preds, tgts=tgts, qry_fmap=qry_fmap, vec=sc['vec'], A=A, n_ways=N, n_total=n_total)
 
-    # ---- proposals with train_cfg.rpn_proposal (fgn.py:161-167)
-    rc = tcfg['rcnn']
-    if proposals is None:
-        pc = tcfg['rpn_proposal']
-        _, scores, deltas = ops.rpn_merge(head, B, N, A)
-        props, n_props = ops.rpn_proposals(scores, deltas, P['anchors'], fh, fw, rp['anchor_stride'], ih, iw,
-                                           rp['target_means'], rp['target_stds'], pc['nms_pre'], pc['min_bbox_size'],
-                                           pc['nms_iou_threshold'], pc['max_per_img'])
-        prop_list = [props[i] for i in range(B)]           # rows past n_props[i] are zero boxes, never sampled
-    else:
-        prop_list = [torch.as_tensor(p).to(dev, torch.float32).contiguous() for p in proposals]
-        n_props = torch.tensor([p.shape[0] for p in prop_list], device=dev, dtype=torch.int32)
-
-    # ---- FGNRoIHead.forward_train (fgn_roi_head.py:451-529): assign per image, one copy to the host, sample there
-    gis = [ops.box_assign(prop_list[i], gt_xyxy[i], rc['pos_iou_thr'], rc['neg_iou_thr'], rc['min_pos_iou'],
-                          rc['match_low_quality']) if prop_list[i].shape[0] else
-           torch.zeros((0,), device=dev, dtype=torch.int32) for i in range(B)]
-    packed = torch.cat(gis + [n_props.to(torch.int32)]).cpu().numpy()
+    packed = packed_all[G * n_total:]
     counts = packed[-B:].tolist()
     if tr is not None:
         tr['proposals'] = [prop_list[i][:counts[i]] for i in range(B)]
@@ -298,10 +303,6 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         lab_parts.append(np.concatenate([cat_h[i][assigned], np.full(neg.size, N, np.int64)]))
     if tr is not None:
         tr['samples'] = samples
-
-    # count_spp with the shared head in training mode (fgn_roi_head.py:491, 419-449)
-    spp_tape = [] if tape is not None else None
-    model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum, spp_tape))
 
     # _bbox_forward_train (fgn_roi_head.py:344-358)
     rois = torch.cat(roi_parts).contiguous()
