@@ -639,6 +639,17 @@ def trainable_names(sd: dict) -> list:
             and 'running_' not in k and 'num_batches' not in k]
 
 
+def step_lr(base_lr: float, it: int, epoch: int, steps=(3,), gamma: float = 0.1, min_lr: float = 1e-6,
+            warmup_iters: int = 100, warmup_ratio: float = 0.01) -> float:
+    """mmcv ``StepLrUpdaterHook`` as configured in fgn_train_schedule.py:17-23: lr = base * gamma^(#steps <= epoch),
+    floored at ``min_lr``; linear warm-up over the first ``warmup_iters`` iterations from ``warmup_ratio`` of it
+    (mmcv: warmup_lr = regular_lr * (1 - (1 - it / warmup_iters) * (1 - warmup_ratio)))."""
+    lr = max(base_lr * gamma ** sum(1 for s_ in steps if epoch >= s_), min_lr)
+    if it < warmup_iters:
+        lr *= 1.0 - (1.0 - it / float(warmup_iters)) * (1.0 - warmup_ratio)
+    return lr
+
+
 class Trainer:
     """Training of the heads on the HIP path: ``step(batch)`` = forward_train (losses) + backward + Adagrad update,
     the loop body the reference gets from mmcv's runner + torch.optim (main.py training branch with

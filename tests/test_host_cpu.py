@@ -380,3 +380,13 @@ def test_resnet18_extension_config_weights_and_reference_style_dict():
     assert n['backbone']['block'] == 'basic' and n['backbone']['stage_blocks'] == (2, 2, 2)
     out = O.simple_test(sd, cfg, **make_batch(2, 1, 3, 1, 96, 128, 64))
     assert set(out[0]) >= {'dt_scores', 'dt_bboxes', 'dt_cat_ids', 'dt_isegmaps_rle', 'qry_isegmaps_rle'}
+
+
+def test_step_lr_schedule_of_the_reference():
+    """fgn_train_schedule.py:17-23: Step policy [3] x0.1, min_lr 1e-6, linear warm-up over 100 iterations from 1 %."""
+    from fgn_amd.train import step_lr
+    assert step_lr(0.005, 0, 0) == pytest.approx(0.005 * 0.01)
+    assert step_lr(0.005, 50, 0) == pytest.approx(0.005 * (1 - 0.5 * 0.99))
+    assert step_lr(0.005, 100, 0) == 0.005 and step_lr(0.005, 10 ** 4, 2) == 0.005
+    assert step_lr(0.005, 10 ** 4, 3) == pytest.approx(0.0005)
+    assert step_lr(1e-6, 10 ** 4, 5) == 1e-6
