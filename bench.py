@@ -76,6 +76,11 @@ def parse_args():
     ap.add_argument('--accuracy-episodes', type=int, default=0,
                     help='off the timed path: compare this many episodes HIP vs the CPU oracle (matched-pair maxima, '
                          'agreement AP at IoU 0.5 / 0.75 / 0.95); 0 = reuse the CPU-baseline episodes')
+    ap.add_argument('--train-heads-steps', type=int, default=300,
+                    help='off the timed path: overfit the heads on the accuracy episodes for this many Trainer steps '
+                         '(frozen backbone, like the reference) so that AP against the synthetic ground truth is not '
+                         '0 vs 0, then score HIP and the CPU oracle with those weights; 0 = skip')
+    ap.add_argument('--trained-eval-episodes', type=int, default=3, help='episodes scored by both paths with the trained heads')
     ap.add_argument('--inflight', type=int, default=1, help='episodes queued ahead of result packing per GPU')
     ap.add_argument('--streams', type=int, default=1,
                     help='caller streams the steps alternate between: with 2, the low-occupancy tail of one episode '
@@ -447,10 +452,80 @@ def cpu_and_accuracy(args, cfg, sd, shape, model) -> dict:
             'max_abs_dmask_prob': float(np.max([m['max_dprob'] for m in maxima])),
             'max_abs_dbox_px': float(np.max([m['max_dbox'] for m in maxima])),
             'tolerance': 'north_star: scores / mask probabilities within 1e-4'}
+    if args.train_heads_steps > 0:
+        try:
+            out['trained_heads'] = trained_heads_leg(args, cfg, sd, batches)
+        except Exception as e:          # the accuracy extra must never cost the bench line
+            out['trained_heads'] = {'error': f'{type(e).__name__}: {e}'}
     out['cpu_baseline'] = {'value': n_timed / cdt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                            'cpu_model': cpu_model(),
                            'sample': f'{n_timed} {args.workload} episodes (after 2 warm-up episodes) through '
                                      'oracle/fgn_ref_cpu.py (PyTorch fp32 CPU restatement of the reference path)'}
+    return out
+
+
+def trained_heads_leg(args, cfg, sd, batches) -> dict:
+    """Seeded random weights detect nothing, so AP against the synthetic ground truth is 0 for both paths.  Here the
+    heads are overfitted on the accuracy episodes themselves (fgn_amd.train.Trainer: the reference's forward_train +
+    backward + Adagrad, backbone frozen as in fgn_r50_c4_densecl.py:31), and BOTH paths then score those episodes with
+    the same trained weights: a parity vehicle with real detections, not a generalisation claim."""
+    import numpy as np
+    import torch
+    from fgn_amd.agreement import episode_maxima
+    from fgn_amd.detector import FGN
+    from fgn_amd.fsiseg_eval import as_ground_truth, evaluate_results
+    from fgn_amd.train import Trainer
+    from oracle import fgn_ref_cpu as O
+    n_ways, k_shots = cfg['n_ways'], cfg['k_shots']
+    train_b = batches[:5]
+    m = FGN(n_ways, k_shots, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+            test_cfg=cfg['test_cfg'], state_dict=sd)
+    tr = Trainer(m)
+    t0 = time.perf_counter()
+    first = last = None
+    for it in range(args.train_heads_steps):
+        torch.manual_seed(it)
+        L = tr.step(train_b[it % len(train_b)])
+        tot = sum(float(v[0] if isinstance(v, list) else v) for k, v in L.items() if 'loss' in k)
+        first = tot if first is None else first
+        last = tot
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    sd2 = tr.state_dict()
+    m.load_state_dict(sd2)
+    ev_b = train_b[:max(1, args.trained_eval_episodes)]
+    hip_res, cpu_res, maxima = [], [], []
+    for j, b in enumerate(ev_b):
+        trc = {}
+        r = O.simple_test(sd2, cfg, **b, trace=trc)
+        print(f'[trained heads] oracle episode {j + 1}/{len(ev_b)}', file=sys.stderr, flush=True)
+        dets = m.detect_device(b['qry_img'], b['spp_imgs'], b['spp_bboxes'], b['spp_isegmaps'], b['img_shape'],
+                               qry_isegmaps=b['qry_isegmaps'])
+        h = m.pack_results(dets, 1, qry_bboxes=b['qry_bboxes'], qry_cat_ids=b['qry_cat_ids'],
+                           qry_isegmaps=b['qry_isegmaps'], img_shape=b['img_shape'], idx=b['idx'])
+        cpu_res.extend(r)
+        hip_res.extend(h)
+        n = len(h[0]['dt_scores'])
+        if n and len(r[0]['dt_scores']) and 'mask_prob' in trc:
+            maxima.append(episode_maxima(r[0], h[0], trc['mask_prob'].numpy(), dets[0]['mask_prob'][:n].cpu().numpy()))
+    ap_cpu, ap_hip = evaluate_results(cpu_res, n_ways), evaluate_results(hip_res, n_ways)
+    out = {'what': f'heads overfitted for {args.train_heads_steps} Trainer steps on {len(train_b)} of the accuracy '
+                   f'episodes (frozen random backbone), {len(ev_b)} of them scored by both paths with those weights',
+           'train_seconds': round(t_train, 2), 'summed_loss_first_last': [round(first, 4), round(last, 4)],
+           'ap50_vs_ground_truth': {k: {'hip': round(ap_hip[k], 4), 'cpu_ref': round(ap_cpu[k], 4)}
+                                    for k in ('bbox_mAP50', 'segm_mAP50')},
+           'detections': {'hip': [len(r['dt_scores']) for r in hip_res], 'cpu_ref': [len(r['dt_scores']) for r in cpu_res]}}
+    agree = {}
+    for thr in (0.5, 0.95):
+        a = evaluate_results(as_ground_truth(cpu_res, hip_res), n_ways, iou_thr=thr)
+        agree[f'iou_{thr}'] = {k: round(v, 4) for k, v in a.items() if 'mAP' in k}
+    out['hip_detections_scored_against_cpu_detections'] = agree
+    if maxima:
+        out['matched_pair_maxima'] = {
+            'matched': int(sum(x['matched'] for x in maxima)), 'detections_cpu': int(sum(x['n_ref'] for x in maxima)),
+            'selection_flips': int(sum(x['flips_ref'] + x['flips_got'] for x in maxima)),
+            'max_abs_dscore': float(np.max([x['max_dscore'] for x in maxima])),
+            'max_abs_dmask_prob': float(np.max([x['max_dprob'] for x in maxima]))}
     return out
 
 

@@ -16,17 +16,23 @@ ap.add_argument('--steps', type=int, default=300)
 ap.add_argument('--episodes', type=int, default=2)
 ap.add_argument('--lr', type=float, default=0.005)
 ap.add_argument('--every', type=int, default=50)
-ap.add_argument('--dataset', default='OMNIISEG')
+ap.add_argument('--dataset', default='OMNIISEG', help='OMNIISEG / MNISTISEG (cluttered characters) or cfg1..cfg5 (bench episodes)')
 a = ap.parse_args()
-ds = ClutteredCharsFewShotISEG(a.dataset, 3, 1, n_imgs=max(a.episodes, 8), img_size=256, batch=a.episodes)
-batch = collate([ds[i] for i in range(a.episodes)])
-m = FGN(3, 1)
+if a.dataset.startswith('cfg'):
+    from fgn_amd.episodes import CONFIGS, make_batch
+    batches = [make_batch(i, 1, **CONFIGS[a.dataset]) for i in range(a.episodes)]
+    K = CONFIGS[a.dataset]['k_shots']
+else:
+    ds = ClutteredCharsFewShotISEG(a.dataset, 3, 1, n_imgs=max(a.episodes, 8), img_size=256, batch=a.episodes)
+    batches = [collate([ds[i] for i in range(a.episodes)])]
+    K = 1
+m = FGN(3, K)
 tr = Trainer(m, lr=a.lr)
 t0 = time.perf_counter()
 for it in range(a.steps + 1):
     if it % a.every == 0:
         m.load_state_dict(tr.state_dict())
-        res = m.simple_test(**batch, rescale=True)
+        res = [r for b in batches for r in m.simple_test(**b, rescale=True)]
         ev = evaluate_results(res, 3)
         tr.refresh()                               # load_state_dict dropped the packed training layers
         print(f'step {it:4d} ({time.perf_counter() - t0:6.1f} s): detections {[len(r["dt_scores"]) for r in res]} '
@@ -34,6 +40,6 @@ for it in range(a.steps + 1):
     if it == a.steps:
         break
     torch.manual_seed(it)
-    L = tr.step(batch)
+    L = tr.step(batches[it % len(batches)])
     if it % a.every == 0:
         print('   losses', {k: round(float(v[0] if isinstance(v, list) else v), 4) for k, v in L.items()}, flush=True)
