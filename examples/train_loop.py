@@ -65,7 +65,7 @@ def main():
               ', '.join(f'{k} {v / n:.4f}' for k, v in tot.items()))
     sd = trainer.state_dict()
     if args.save:
-        torch.save({'state_dict': sd, 'meta': {'iter': it}}, args.save)
+        torch.save(trainer.checkpoint(meta={'iter': it, 'epoch': args.epochs}), args.save)   # resumable: Trainer.resume
     model.load_state_dict(sd)
     with tempfile.TemporaryDirectory() as work_dir:
         loader = DataLoader(ds, batch_size=ds.batch, num_workers=2, collate_fn=collate)

@@ -708,6 +708,29 @@ class Trainer:
         self.refresh()
         return losses
 
+    def checkpoint(self, meta: Optional[dict] = None) -> dict:
+        """mmcv checkpoint layout with the optimizer (checkpoint_config save_optimizer=True,
+        fgn_train_schedule.py:33-38): {'state_dict', 'optimizer': Adagrad sums per parameter, 'meta'}."""
+        return {'state_dict': self.state_dict(), 'meta': dict(meta or {}),
+                'optimizer': {'type': 'Adagrad', 'lr': self.lr, 'weight_decay': self.wd,
+                              'roi_head_lr_mult': self.mult, 'eps': self.eps,
+                              'state_sum': {k: v.detach().cpu() for k, v in self.state.items()}}}
+
+    def resume(self, ckpt: dict) -> None:
+        """Continue from ``checkpoint()`` (or from a plain mmcv checkpoint without optimizer state)."""
+        sd = ckpt.get('state_dict', ckpt)
+        for k in self.W:
+            self.W[k].copy_(sd[k].to(self.device, torch.float32))
+        for k in self.buffers:
+            if k in sd:
+                self.buffers[k].copy_(sd[k].to(self.device, torch.float32))
+        opt = ckpt.get('optimizer')
+        if opt is not None:
+            for k, v in opt['state_sum'].items():
+                self.state[k].copy_(v.to(self.device, torch.float32))
+            self.lr, self.wd = opt.get('lr', self.lr), opt.get('weight_decay', self.wd)
+        self.refresh()
+
     def state_dict(self) -> dict:
         """The model's state dict with the trained heads and the updated running statistics (CPU tensors)."""
         sd = dict(self.model._sd)

@@ -572,3 +572,31 @@ def test_training_produces_a_working_detector():
     assert last < 0.5 * first
     assert before['bbox_mAP50'] < 0.2
     assert after['bbox_mAP50'] >= 0.6 and after['segm_mAP50'] >= 0.6
+
+
+def test_checkpoint_resume_continues_bit_identically():
+    """Two steps, checkpoint (weights + Adagrad sums + running statistics), a fresh Trainer resumed from it: the third
+    step gives the same losses and the same weights as the uninterrupted run."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.train import Trainer
+    cfg = tiny_config(3, 2, width_div=2)
+    b = make_batch(2, 1, 3, 2, 160, 224, 64)
+    m1, _ = _models(cfg)
+    t1 = Trainer(m1)
+    for it in range(2):
+        torch.manual_seed(it)
+        t1.step(b)
+    ck = t1.checkpoint(meta={'iter': 2})
+    torch.manual_seed(2)
+    l1 = t1.step(b)
+    m2, _ = _models(cfg)
+    t2 = Trainer(m2)
+    t2.resume(ck)
+    torch.manual_seed(2)
+    l2 = t2.step(b)
+    for k in l1:
+        assert _f(l1[k]) == _f(l2[k]), k
+    for k in t1.W:
+        assert torch.equal(t1.W[k], t2.W[k]), k
+    assert set(ck) == {'state_dict', 'optimizer', 'meta'} and ck['meta']['iter'] == 2
