@@ -390,3 +390,27 @@ def test_step_lr_schedule_of_the_reference():
     assert step_lr(0.005, 100, 0) == 0.005 and step_lr(0.005, 10 ** 4, 2) == 0.005
     assert step_lr(0.005, 10 ** 4, 3) == pytest.approx(0.0005)
     assert step_lr(1e-6, 10 ** 4, 5) == 1e-6
+
+
+def test_host_sampler_matches_the_oracle_sampler_under_the_same_seed():
+    """fgn_amd.train._sample (the product's host-side RandomSampler bookkeeping, numpy on the copied assignment
+    vector) against the oracle's restatement of BaseSampler.sample / RandomSampler, which is itself pinned by the
+    vendored my_random_sampler.py golden."""
+    from fgn_amd.train import _sample
+    from oracle import fgn_train_cpu as T
+    g = torch.Generator().manual_seed(3)
+    for n, n_pos, num, frac in ((63000, 40, 64, 0.5), (63000, 5, 64, 0.5), (2000, 300, 128, 0.25), (50, 0, 128, 0.25)):
+        gi = torch.zeros(n, dtype=torch.long)
+        gi[torch.randperm(n, generator=g)[:n // 7]] = -1
+        gi[torch.randperm(n, generator=g)[:n // 9]] = -2                     # anchors outside the image
+        if n_pos:
+            gi[torch.randperm(n, generator=g)[:n_pos]] = torch.randint(1, 4, (n_pos,), generator=g)
+        torch.manual_seed(11)
+        pos, neg = _sample(gi.numpy().astype(np.int32), num, frac, torch.randperm)
+        # the reference samples on the compacted list of inside anchors: same relative order, same permutation
+        inside = gi != -2
+        torch.manual_seed(11)
+        ref = T.random_sample(gi[inside], torch.zeros(int(inside.sum()), 4), torch.zeros(3, 4), None, num, frac, False)
+        full = torch.nonzero(inside).view(-1)
+        assert np.array_equal(pos, full[ref['pos_inds']].numpy())
+        assert np.array_equal(neg, full[ref['neg_inds']].numpy())
