@@ -1,10 +1,11 @@
-"""``FGN.forward_train`` on the HIP path (reference: subprojects/sp02_omniiseg_fgn_mmdet/fgn.py:125-185).
+"""``FGN.forward_train`` and the training step on the HIP path (reference: subprojects/sp02_omniiseg_fgn_mmdet/
+fgn.py:125-185; the loop around it is mmcv's runner + OptimizerHook + torch.optim.Adagrad, fgn_train_schedule.py).
 
-Returns the reference's loss dict - ``loss_rpn_cls`` / ``loss_rpn_bbox`` (lists of one tensor, AG-RPN,
+``forward_train`` returns the reference's loss dict - ``loss_rpn_cls`` / ``loss_rpn_bbox`` (lists of one tensor, AG-RPN,
 fgn_ag_rpn_head.py:58-79), ``loss_cls`` / ``ACC-Unbalanced`` / ``ACC-Balanced`` / ``loss_bbox`` (FGNBBoxHead.loss,
-fgn_roi_head.py:58-118) and ``loss_mask`` (fgn_roi_head.py:384-417) - as FORWARD VALUES: the HIP path has no
-autograd graph, so the tensors carry no ``grad_fn`` (the backward kernels of the heads are the next step of this row,
-DESIGN.md section 8).  What runs where:
+fgn_roi_head.py:58-118) and ``loss_mask`` (fgn_roi_head.py:384-417).  The HIP path has no autograd graph, so the
+tensors carry no ``grad_fn``; ``Trainer`` keeps a tape of the forward pass instead and runs the backward pass of the
+trainable heads, the Adagrad update and the re-pack of the kernel layouts itself.  What runs where:
 
   * backbone (frozen, BatchNorm in eval mode: frozen_stages=4 / norm_eval=True, fgn_r50_c4_densecl.py:31-36 with
     fgn.py:67-77), AG-RPN convolutions, RoIAlign, relation head, mask head: the inference kernels
@@ -12,13 +13,16 @@ DESIGN.md section 8).  What runs where:
     train(), fgn_roi_head.py:202-238): raw convolutions + ``ops.bn_train`` (batch statistics, running update)
   * MaxIoUAssigner for anchors and proposals, box encoding, the five loss reductions, the 12000 -> 2000 proposal
     stage: ``csrc/train.hip`` / ``csrc/rpn_post.hip``
-  * RandomSampler: the permutation is drawn like mmdet does, ``torch.randperm(n)`` on the CPU generator
-    (my_random_sampler.py:58), and applied on the device; index bookkeeping (nonzero / gather / cat) is torch
-    device plumbing and, like the reference's assign + sample loop, host-driven (one sync per sampled set).
+  * RandomSampler: both stages' assignment vectors are copied to the host once per step; candidate lists, the
+    permutation mmdet draws (``torch.randperm(n)`` on the CPU generator, my_random_sampler.py:58) and the label /
+    target gathers run there in numpy, the selected indices go back as small index tensors
+  * backward: loss gradients, BatchNorm(train) / relation-GroupNorm / mask-logit backward, im2col, column sums,
+    Adagrad: ``csrc/train_bwd.hip``; 3x3 data gradients: the forward convolution kernel with flipped weights; the
+    plain weight / data gradient GEMMs: rocBLAS (``torch.matmul``)
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

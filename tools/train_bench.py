@@ -2,7 +2,7 @@
 proposals, 128 sampled RoIs per image): forward_train alone (losses) and Trainer.step (forward + backward of the heads +
 Adagrad + re-pack), beside the CPU oracle's forward_train and forward+autograd-backward.
 usage (GPU box): python tools/train_bench.py [--batch 1] [--steps 10] [--out profiles/r02_train_step.json]"""
-import argparse, copy, json, os, sys, time
+import argparse, json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import torch
