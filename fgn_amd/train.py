@@ -662,7 +662,11 @@ class Trainer:
     layouts are re-derived from them after every update."""
 
     def __init__(self, model, lr: float = 0.005, weight_decay: float = 1e-5, roi_head_lr_mult: float = 0.1,
-                 eps: float = 1e-10, bn_momentum: float = 0.1):
+                 eps: float = 1e-10, bn_momentum: float = 0.1, freeze_backbone: bool = False):
+        if model.cfg['backbone'].get('norm', 'BN') != 'BN' and not freeze_backbone:
+            raise NotImplementedError('the from-scratch configuration (fgn_r50_c4_scratch.py: frozen_stages=-1, GroupNorm) '
+                                      'trains its backbone; only the heads have backward kernels - pass '
+                                      'freeze_backbone=True to train the heads on the fixed backbone')
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('Trainer needs a GPU: the HIP path has no CPU fallback')
         self.model, self.lr, self.wd, self.mult, self.eps = model, lr, weight_decay, roi_head_lr_mult, eps

@@ -414,3 +414,13 @@ def test_host_sampler_matches_the_oracle_sampler_under_the_same_seed():
         full = torch.nonzero(inside).view(-1)
         assert np.array_equal(pos, full[ref['pos_inds']].numpy())
         assert np.array_equal(neg, full[ref['neg_inds']].numpy())
+
+
+def test_trainer_refuses_the_trainable_backbone_config():
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.train import Trainer
+    cfg = tiny_config(3, 1, width_div=8, scratch=True)
+    m = FGN(3, 1, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'])
+    with pytest.raises(NotImplementedError):
+        Trainer(m)
