@@ -400,7 +400,8 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         if tr is not None:
             tr.update(mask_pred=mlog, mask_targets_soft=tgt)
         if tape is not None:
-            tape['mask'] = dict(mfeat=mfeat, vmask=vmask, acts=macts, up=mup, mlog=mlog.contiguous(), tgt=tgt, rows=vrows)
+            tape['mask'] = dict(mfeat=mfeat, vmask=vmask, acts=macts, up=mup, mlog=mlog.contiguous(), tgt=tgt, rows=vrows,
+                                rows_h=lab_h[pos_rows_h] + N * img_of_h)
     else:
         losses['loss_mask'] = _zero(dev)
         if tape is not None:
@@ -528,8 +529,12 @@ def backward(model, W: dict, tape: dict) -> dict:
         d_vmask = (dm * tm['mfeat']).sum(dim=(1, 2))                         # [n_pos, C]
         d_feats = torch.zeros_like(feats)
         d_feats.index_add_(0, tr_['pos_rows'], d_mfeat)
+        # sum over the positives that share a (image, class) support vector: column sums in a fixed order (an
+        # index_add_ would accumulate with atomics, in an order that changes from run to run)
         d_cat_mean_mp = torch.zeros((tape['spp']['B'] * N, C), device=dev)
-        d_cat_mean_mp.index_add_(0, tm['rows'], d_vmask)
+        for r_ in np.unique(tm['rows_h']):
+            sel = _dev_idx(np.flatnonzero(tm['rows_h'] == r_), dev)
+            ops.colsum(d_vmask[sel].contiguous(), out=d_cat_mean_mp[int(r_)])
 
     # ---- box head losses -> relation head (fgn_roi_head.py:58-118, 253-279, 302-326) ---------------------
     n = tr_['n_rois']
