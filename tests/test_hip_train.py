@@ -199,7 +199,7 @@ def _compare_losses(got, ref, rel):
     assert set(got) == set(ref)
 
 
-@pytest.mark.parametrize('n_ways,k_shots,batch', [(3, 3, 2), (1, 1, 1)])
+@pytest.mark.parametrize('n_ways,k_shots,batch', [(3, 3, 2), (1, 1, 1), (5, 2, 1)])
 def test_forward_train_matches_oracle_small(n_ways, k_shots, batch):
     """Half-width model, 160x224 queries: every stage compared - sampled sets and labels bit-exact, losses to 1e-4."""
     from fgn_amd.config import tiny_config
