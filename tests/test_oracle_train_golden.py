@@ -103,3 +103,19 @@ def test_rpn_loss_matches_the_vendored_anchor_head():
                         [torch.from_numpy(z['img_hw'])] * n, cfg, torch.randperm)
     assert float(lc) == pytest.approx(float(z['loss_cls']), rel=1e-6)
     assert float(lb) == pytest.approx(float(z['loss_bbox']), rel=1e-6)
+
+
+def test_default_train_and_test_constants_equal_the_reference_configs():
+    """config.fgn_r50_c4_config's train_cfg / test_cfg against the dicts of the reference's own model configs (dumped
+    as data by make_golden_train.py), through the same normalisation `FGN(..., train_cfg=, test_cfg=)` applies."""
+    import json
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.detector import normalise_config
+    z = json.load(open(os.path.join(G, 'train_cfg_reference.json')))
+    ours = fgn_r50_c4_config(3, 3)
+    got = normalise_config(3, 3, test_cfg=z['test_cfg'], train_cfg=z['train_cfg'])
+    assert got['train_cfg'] == ours['train_cfg']
+    assert got['test_cfg'] == ours['test_cfg']
+    # and the values themselves, spelled out
+    assert got['train_cfg']['rpn']['num'] == 64 and got['train_cfg']['rcnn']['num'] == 128
+    assert got['train_cfg']['rpn_proposal'] == dict(nms_pre=12000, max_per_img=2000, nms_iou_threshold=0.7, min_bbox_size=0)
