@@ -1,12 +1,13 @@
 // Backward kernels of the trainable heads (AG-RPN head, shared head, relation / box head, mask head) for
 // FGN.forward_train (fgn.py:125-185; the reference obtains these gradients from torch.autograd).  The backbone is
 // frozen (frozen_stages=4 + torch.no_grad in extract_feat, fgn_r50_c4_densecl.py:31, fgn.py:67-73), so no gradient
-// flows below RoIAlign.  What is here is everything that is not a plain GEMM:
+// flows below RoIAlign.  Here:
 //   loss gradients (sigmoid CE, smooth L1, softmax CE), BatchNorm(train) backward, the fused relation-head backward
 //   (fc -> avg-pool -> ReLU -> GroupNorm -> split 1x1 conv sum), mask-logit backward, im2col for the 3x3 weight
-//   gradients, column sums (bias gradients), the Adagrad update (fgn_train_schedule.py:5-13).
-// The 1x1 / im2col weight- and data-gradient products are plain GEMMs and go through rocBLAS (host side, train.py);
-// the 3x3 data gradients run on the forward convolution kernel with flipped, transposed weights.
+//   gradients, the weight-gradient GEMM dW = dY^T . X on fp32 MFMA, column sums (bias gradients), the Adagrad
+//   update (fgn_train_schedule.py:5-13).
+// Data gradients run on the forward convolution kernel (conv_igemm.hip) with transposed (1x1) or flipped and
+// transposed (3x3) weights (host side, train.py).
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -502,6 +503,138 @@ extern "C" int fgn_im2col3x3_f32(const float* x, float* out, int n, int H, int W
     const long long total = (long long)n * H * W * 9 * (C / 4);
     hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<float4*>(out), n, H, W, C / 4);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM  C[M,N] = A[R,M]^T . B[R,N]  (A = dY rows x Cout, B = X or im2col(X) rows x K): both operands
+// are row-major with the REDUCTION index R as the slow one, which is exactly the lane layout of
+// v_mfma_f32_16x16x4_f32 (lane = (k = lane/16, m or n = lane%16)): a K-chunk of 32 rows x 64 columns of each operand is
+// staged in LDS as it lies in memory (coalesced float4 loads, rows padded to 80 floats so that the two 16-lane groups
+// of a half-wave hit disjoint banks) and every MFMA operand is one conflict-free ds_read_b32.  64x64 output tile per
+// workgroup, 4 waves x (2x2 tiles of 16x16), global loads of chunk k+1 in flight while chunk k is multiplied.
+// Few output tiles (Cout x Cin of a 1x1 conv) -> the rows are split into slabs; partial tiles are reduced in slab
+// order by gemm_tn_reduce_kernel (bit-reproducible, no atomics).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TN_BK = 32, TN_LD = 80;
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ C, int R, int M, int N, int n_tiles_n,
+                                                      int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[2][TN_BK][TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TN_BK][TN_LD];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tile_m = blockIdx.x / n_tiles_n, tile_n = blockIdx.x - tile_m * n_tiles_n;
+    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
+    const int lrow = t >> 4, lc4 = (t & 15) * 4;                 // this thread's float4 of a 16-row half chunk
+    const bool a_ok = m0 + lc4 < M, b_ok = n0 + lc4 < N;          // M, N are multiples of 4
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = k0 + lrow + 16 * h;
+            ra[h] = (a_ok && r < r1) ? *reinterpret_cast<const float4*>(A + (size_t)r * M + m0 + lc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[h] = (b_ok && r < r1) ? *reinterpret_cast<const float4*>(B + (size_t)r * N + n0 + lc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store = [&](int st) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&As[st][lrow + 16 * h][lc4]) = ra[h];
+            *reinterpret_cast<float4*>(&Bs[st][lrow + 16 * h][lc4]) = rb[h];
+        }
+    };
+    const int r16 = lane & 15, g16 = lane >> 4;
+    load(r0);
+    store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = r0; k0 < r1; k0 += TN_BK) {
+        const bool more = k0 + TN_BK < r1;
+        if (more) load(k0 + TN_BK);
+#pragma unroll
+        for (int ks = 0; ks < TN_BK / 4; ++ks) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[cur][ks * 4 + g16][wm * 32 + 16 * i + r16];
+                b[i] = Bs[cur][ks * 4 + g16][wn * 32 + 16 * i + r16];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* Cs = C + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + 16 * j + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + 16 * i + 4 * g16 + r;
+                if (m < M && n < N) Cs[(size_t)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void gemm_tn_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, long long n4, int S) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = part[i];
+        for (int k = 1; k < S; ++k) {
+            const float4 v = part[(size_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[i] = s;
+    }
+}
+
+static inline int tn_splits(int R, int M, int N) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int S = cdiv(1024, tiles);                      // about four workgroups per CU in flight
+    const int max_s = R / 256 > 1 ? R / 256 : 1;    // at least 256 rows per slab
+    if (S > max_s) S = max_s;
+    if (S > 64) S = 64;
+    return S < 1 ? 1 : S;
+}
+
+extern "C" size_t fgn_gemm_tn_workspace_bytes(int R, int M, int N) {
+    const int S = tn_splits(R, M, N);
+    return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
+// C [M,N] = A [R,M]^T B [R,N]; M % 4 == 0, N % 4 == 0; workspace: fgn_gemm_tn_workspace_bytes(R, M, N)
+extern "C" int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, int M, int N, void* workspace,
+                               hipStream_t stream) {
+    if (!A || !B || !C) return FGN_ERR_ARG;
+    if (R <= 0 || M <= 0 || N <= 0 || M % 4 || N % 4) return FGN_ERR_SHAPE;
+    const int S = tn_splits(R, M, N);
+    if (S > 1 && !workspace) return FGN_ERR_ARG;
+    const int ntn = cdiv(N, 64);
+    int rows_per = cdiv(R, S);
+    rows_per = cdiv(rows_per, TN_BK) * TN_BK;
+    const int S_eff = cdiv(R, rows_per);
+    float* dst = S_eff > 1 ? reinterpret_cast<float*>(workspace) : C;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(M, 64) * ntn, S_eff), dim3(256), 0, stream, A, B, dst, R, M, N, ntn,
+                       rows_per);
+    if (S_eff > 1) {
+        const long long n4 = (long long)M * N / 4;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for(n4)), dim3(256), 0, stream,
+                           reinterpret_cast<const float4*>(dst), reinterpret_cast<float4*>(C), n4, S_eff);
+    }
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -74,10 +74,12 @@ SIGNATURES = {
     'fgn_relation_gn_head_backward_f32': (_i, [_p] * 12 + [_i, _i, _i, _i, _i, _f, _p]),
     'fgn_mask_logits_backward_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'fgn_im2col3x3_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'fgn_gemm_tn_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_gemm_tn_f32': (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

@@ -1013,6 +1013,23 @@ def im2col3x3(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [R,M], b [R,N] -> a^T b [M,N] (the weight-gradient product: reduction over the rows) on the MFMA kernel."""
+    _chk(a, 'a')
+    _chk(b, 'b')
+    r, m = a.shape
+    n = b.shape[1]
+    if b.shape[0] != r:
+        raise _lib.FgnHipError('gemm_tn: operands must share the row count')
+    L = _lib.load()
+    out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    wsb = L.fgn_gemm_tn_workspace_bytes(r, m, n)
+    ws = torch.empty(wsb, device=a.device, dtype=torch.uint8) if wsb else None
+    rc = L.fgn_gemm_tn_f32(_ptr(a), _ptr(b), _ptr(out), r, m, n, _ptr(ws), _stream())
+    _lib.check(rc, 'fgn_gemm_tn_f32')
+    return out
+
+
 def adagrad_step(param: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, lr: float, weight_decay: float,
                  eps: float = 1e-10) -> None:
     for t, nm in ((param, 'param'), (grad, 'grad'), (state, 'state')):

@@ -16,9 +16,10 @@ trainable heads, the Adagrad update and the re-pack of the kernel layouts itself
   * RandomSampler: both stages' assignment vectors are copied to the host once per step; candidate lists, the
     permutation mmdet draws (``torch.randperm(n)`` on the CPU generator, my_random_sampler.py:58) and the label /
     target gathers run there in numpy, the selected indices go back as small index tensors
-  * backward: loss gradients, BatchNorm(train) / relation-GroupNorm / mask-logit backward, im2col, column sums,
-    Adagrad: ``csrc/train_bwd.hip``; 3x3 data gradients: the forward convolution kernel with flipped weights; the
-    plain weight / data gradient GEMMs: rocBLAS (``torch.matmul``)
+  * backward: loss gradients, BatchNorm(train) / relation-GroupNorm / mask-logit backward, im2col, column sums, the
+    weight-gradient GEMM (``fgn_gemm_tn_f32``, fp32 MFMA), Adagrad: ``csrc/train_bwd.hip``; data gradients: the forward
+    convolution kernel with transposed (1x1) / flipped (3x3) weights; rocBLAS only for the 6-row fc products and the
+    75-channel AG-RPN head
 """
 from __future__ import annotations
 
@@ -429,8 +430,21 @@ def _mask_head_taped(model, mf, vmask):
 # backward of the trainable heads
 # ------------------------------------------------------------------------------------------
 def _mm_tn(a2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
-    """a2 [rows, M], b2 [rows, K] -> a2^T b2 [M, K]: the weight-gradient product, a plain GEMM (rocBLAS)."""
-    return torch.matmul(a2.t(), b2)
+    """a2 [rows, M], b2 [rows, K] -> a2^T b2 [M, K]: the weight-gradient product (reduction over the rows) on the
+    MFMA kernel ``fgn_gemm_tn_f32``; the 6-row fc gradient (M not a multiple of 4) goes through rocBLAS."""
+    if a2.shape[1] % 4 or b2.shape[1] % 4 or a2.shape[0] == 0:
+        return torch.matmul(a2.t(), b2)
+    return ops.gemm_tn(a2.contiguous(), b2.contiguous())
+
+
+def _dgrad_1x1(dy: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Data gradient of a 1x1 convolution, dy [..., Cout] x w2 [Cout, Cin] -> [..., Cin]: the forward convolution
+    kernel with the transposed weight (Cout is the reduction, a multiple of 32 for every trainable 1x1 layer)."""
+    cout, cin = w2.shape
+    if cout % 32:
+        return torch.matmul(dy.reshape(-1, cout), w2).view(tuple(dy.shape[:-1]) + (cin,))
+    x = dy.contiguous().view(1, -1, 1, cout)
+    return ops.conv2d(x, ops.pack_conv(w2.t().contiguous().view(cin, cout, 1, 1))).view(tuple(dy.shape[:-1]) + (cin,))
 
 
 def _conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -463,7 +477,7 @@ def _block_backward(blk: _SharedBlockTrain, W: dict, t: dict, dout: torch.Tensor
     acc(p + '.bn3.weight', dg3); acc(p + '.bn3.bias', db3)
     d3f = d3.view(-1, w3.shape[0])
     acc(p + '.conv3.weight', _mm_tn(d3f, t['y2'].reshape(-1, w3.shape[1])).view_as(W[p + '.conv3.weight']))
-    dy2 = torch.matmul(d3f, w3).view_as(t['y2'])
+    dy2 = _dgrad_1x1(d3, w3).view_as(t['y2'])
     d2, dg2, db2 = ops.bn_train_backward(t['c2'], t['y2'], dy2, m2, v2, blk.bn[1]['weight'], eps)
     acc(p + '.bn2.weight', dg2); acc(p + '.bn2.bias', db2)
     acc(p + '.conv2.weight', _conv3x3_wgrad(d2, t['y1']))
@@ -474,7 +488,7 @@ def _block_backward(blk: _SharedBlockTrain, W: dict, t: dict, dout: torch.Tensor
     acc(p + '.conv1.weight', _mm_tn(d1f, t['x'].reshape(-1, w1.shape[1])).view_as(W[p + '.conv1.weight']))
     if not need_dx:
         return None
-    return g_id + torch.matmul(d1f, w1).view_as(t['x'])
+    return g_id + _dgrad_1x1(d1, w1).view_as(t['x'])
 
 
 def _shared_backward(model, W, blocks_tape, dout, grads):
@@ -516,7 +530,7 @@ def backward(model, W: dict, tape: dict) -> dict:
         dw4 = _mm_tn(d_upf, acts[-1].reshape(-1, cin_u))                     # [4*Cout, Cin]
         grads['roi_head.mask_head.upsample.weight'] = dw4.view(2, 2, cout_u, cin_u).permute(3, 2, 0, 1).contiguous()
         grads['roi_head.mask_head.upsample.bias'] = ops.colsum(d_upf).view(4, cout_u).sum(0)
-        dm = torch.matmul(d_upf, w4).view_as(acts[-1])
+        dm = _dgrad_1x1(d_up, w4).view_as(acts[-1])
         for li in range(len(acts) - 1, -1, -1):
             name = f'roi_head.mask_head.convs.{li}.conv'
             dpre = ops.relu_backward(dm.contiguous(), acts[li])                # ReLU
@@ -567,7 +581,7 @@ def backward(model, W: dict, tape: dict) -> dict:
     wrel = W['roi_head.cls_reg_shared_conv.weight'].view(C, 2 * C)
     wq, ws = wrel[:, :C], wrel[:, C:]
     dQf = dQ.view(-1, C)
-    d_from_q = torch.matmul(dQf, wq).view_as(feats)
+    d_from_q = _dgrad_1x1(dQ, wq.contiguous()).view_as(feats)
     d_feats = d_from_q if d_feats is None else d_feats + d_from_q
     dWq = _mm_tn(dQf, feats.reshape(-1, C))
     # dS[b, cls] = sum over the RoIs of image b of dZ[r, cls]  (RoIs are image-major: bbox2roi)
@@ -585,7 +599,7 @@ def backward(model, W: dict, tape: dict) -> dict:
     grads['roi_head.cls_reg_shared_conv.weight'] = torch.cat([dWq, dWs], 1).view_as(
         W['roi_head.cls_reg_shared_conv.weight'])
     grads['roi_head.cls_reg_shared_conv.bias'] = ops.colsum(dSf)
-    d_cat_mean = torch.matmul(dSf, ws).view_as(cat_mean)                    # [B*N, 7, 7, C]
+    d_cat_mean = _dgrad_1x1(dS, ws.contiguous()).view_as(cat_mean)          # [B*N, 7, 7, C]
 
     # ---- shared head, RoI batch then support batch (count_spp, fgn_roi_head.py:419-449) ------------------
     _shared_backward(model, W, tr_['blocks'], d_feats, grads)
@@ -621,7 +635,7 @@ def backward(model, W: dict, tape: dict) -> dict:
     dH = dhead.view(-1, CH)[rows]
     X = t['x'].reshape(-1, Cf)[rows]
     wh = torch.cat([W['rpn_head.rpn_cls.weight'].view(A, Cf), W['rpn_head.rpn_reg.weight'].view(4 * A, Cf)], 0)
-    dwh = _mm_tn(dH[:, :5 * A].contiguous(), X)
+    dwh = _mm_tn(dH, X)[:5 * A]                                              # CH = 5A padded to a multiple of 4
     dbh = ops.colsum(dH[:, :5 * A].contiguous())
     grads['rpn_head.rpn_cls.weight'] = dwh[:A].reshape(W['rpn_head.rpn_cls.weight'].shape).contiguous()
     grads['rpn_head.rpn_reg.weight'] = dwh[A:].reshape(W['rpn_head.rpn_reg.weight'].shape).contiguous()

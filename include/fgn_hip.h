@@ -288,6 +288,11 @@ int fgn_mask_logits_backward_f32(const float* up, const float* dlogit, const flo
 /* im2col of a 3x3 / stride 1 / pad 1 input, NHWC: out [n*H*W, 9*C], column (ky*3+kx)*C + ci (weight gradients) */
 int fgn_im2col3x3_f32(const float* x, float* out, int n, int H, int W, int C, void* stream);
 
+/* Weight-gradient GEMM C [M,N] = A [R,M]^T . B [R,N] (A = dY, B = X or im2col(X); reduction over the rows) on fp32
+ * MFMA; M % 4 == 0, N % 4 == 0; slabs of rows reduced in a fixed order.  workspace: fgn_gemm_tn_workspace_bytes() */
+size_t fgn_gemm_tn_workspace_bytes(int R, int M, int N);
+int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, int M, int N, void* workspace, void* stream);
+
 /* torch.optim.Adagrad step (fgn_train_schedule.py:5-13): g += wd*p; state += g*g; p -= lr*g/(sqrt(state)+eps) */
 int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr, float weight_decay,
                          float eps, void* stream);
