@@ -511,45 +511,59 @@ extern "C" int fgn_im2col3x3_f32(const float* x, float* out, int n, int H, int W
 // Weight-gradient GEMM  C[M,N] = A[R,M]^T . B[R,N]  (A = dY rows x Cout, B = X or im2col(X) rows x K): both operands
 // are row-major with the REDUCTION index R as the slow one, which is exactly the lane layout of
 // v_mfma_f32_16x16x4_f32 (lane = (k = lane/16, m or n = lane%16)): a K-chunk of 32 rows x 64 columns of each operand is
-// staged in LDS as it lies in memory (coalesced float4 loads, rows padded to 80 floats so that the two 16-lane groups
+// staged in LDS as it lies in memory (coalesced float4 loads, rows padded by 16 floats so that the two 16-lane groups
 // of a half-wave hit disjoint banks) and every MFMA operand is one conflict-free ds_read_b32.  64x64 output tile per
-// workgroup, 4 waves x (2x2 tiles of 16x16), global loads of chunk k+1 in flight while chunk k is multiplied.
+// workgroup, 4 waves x (2x2 tiles of 16x16) - or 128x128 with 4x4 tiles per wave when those alone fill the chip -,
+// global loads of chunk k+1 in flight while chunk k is multiplied.
 // Few output tiles (Cout x Cin of a 1x1 conv) -> the rows are split into slabs; partial tiles are reduced in slab
 // order by gemm_tn_reduce_kernel (bit-reproducible, no atomics).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int TN_BK = 32, TN_LD = 80;
-
+template <int BM, int BN, int TN_BK>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int R, int M, int N, int n_tiles_n,
                                                       int rows_per_split) {
-    __shared__ __attribute__((aligned(16))) float As[2][TN_BK][TN_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TN_BK][TN_LD];
+    constexpr int LDA = BM + 16, LDB = BN + 16;          // +16 floats: rows k and k+1 start 16 banks apart
+    constexpr int TM = BM / 32, TN = BN / 32;            // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
+    constexpr int A4 = BM / 4, B4 = BN / 4;              // float4 per chunk row
+    constexpr int A_LD = TN_BK * A4 / 256, B_LD = TN_BK * B4 / 256;      // float4 loads per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+    float* As = tn_smem;                                 // [2][TN_BK][LDA]
+    float* Bs = tn_smem + 2 * TN_BK * LDA;               // [2][TN_BK][LDB]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int tile_m = blockIdx.x / n_tiles_n, tile_n = blockIdx.x - tile_m * n_tiles_n;
-    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
-    const int lrow = t >> 4, lc4 = (t & 15) * 4;                 // this thread's float4 of a 16-row half chunk
-    const bool a_ok = m0 + lc4 < M, b_ok = n0 + lc4 < N;          // M, N are multiples of 4
-    f32x4 acc[2][2];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 ra[2], rb[2];
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[A_LD], rb[B_LD];
     auto load = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = k0 + lrow + 16 * h;
-            ra[h] = (a_ok && r < r1) ? *reinterpret_cast<const float4*>(A + (size_t)r * M + m0 + lc4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[h] = (b_ok && r < r1) ? *reinterpret_cast<const float4*>(B + (size_t)r * N + n0 + lc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = 0; h < A_LD; ++h) {
+            const int e = t + 256 * h, row = e / A4, c = (e - row * A4) * 4, r = k0 + row;
+            ra[h] = (m0 + c < M && r < r1) ? *reinterpret_cast<const float4*>(A + (size_t)r * M + m0 + c)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < B_LD; ++h) {
+            const int e = t + 256 * h, row = e / B4, c = (e - row * B4) * 4, r = k0 + row;
+            rb[h] = (n0 + c < N && r < r1) ? *reinterpret_cast<const float4*>(B + (size_t)r * N + n0 + c)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store = [&](int st) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(&As[st][lrow + 16 * h][lc4]) = ra[h];
-            *reinterpret_cast<float4*>(&Bs[st][lrow + 16 * h][lc4]) = rb[h];
+        for (int h = 0; h < A_LD; ++h) {
+            const int e = t + 256 * h, row = e / A4, c = (e - row * A4) * 4;
+            *reinterpret_cast<float4*>(As + (st * TN_BK + row) * LDA + c) = ra[h];
+        }
+#pragma unroll
+        for (int h = 0; h < B_LD; ++h) {
+            const int e = t + 256 * h, row = e / B4, c = (e - row * B4) * 4;
+            *reinterpret_cast<float4*>(Bs + (st * TN_BK + row) * LDB + c) = rb[h];
         }
     };
     const int r16 = lane & 15, g16 = lane >> 4;
@@ -560,18 +574,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     for (int k0 = r0; k0 < r1; k0 += TN_BK) {
         const bool more = k0 + TN_BK < r1;
         if (more) load(k0 + TN_BK);
+        const float* Ac = As + cur * TN_BK * LDA + wm * (BM / 2) + r16;
+        const float* Bc = Bs + cur * TN_BK * LDB + wn * (BN / 2) + r16;
 #pragma unroll
         for (int ks = 0; ks < TN_BK / 4; ++ks) {
-            float a[2], b[2];
+            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[cur][ks * 4 + g16][wm * 32 + 16 * i + r16];
-                b[i] = Bs[cur][ks * 4 + g16][wn * 32 + 16 * i + r16];
-            }
+            for (int i = 0; i < TM; ++i) a[i] = Ac[(ks * 4 + g16) * LDA + 16 * i];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) b[j] = Bc[(ks * 4 + g16) * LDB + 16 * j];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) store(cur ^ 1);
         __syncthreads();
@@ -579,13 +594,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
     float* Cs = C + (size_t)blockIdx.y * M * N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + 16 * j + r16;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + 16 * j + r16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + 16 * i + 4 * g16 + r;
+                const int m = m0 + wm * (BM / 2) + 16 * i + 4 * g16 + r;
                 if (m < M && n < N) Cs[(size_t)m * N + n] = acc[i][j][r];
             }
         }
@@ -602,9 +617,19 @@ __global__ void gemm_tn_reduce_kernel(const float4* __restrict__ part, float4* _
     }
 }
 
+// 128x128 tiles (half the L2 traffic per MFMA, 2 workgroups per CU) for the large products, 64x64 tiles otherwise;
+// few output tiles -> row slabs
+#include <cstdlib>
+static inline bool tn_big(int R, int M, int N) {
+    static const int force = getenv("FGN_TN_BIG") ? atoi(getenv("FGN_TN_BIG")) : -1;       // tools/gemm_tn_bench.py
+    if (force >= 0) return force != 0 && M >= 128 && N >= 128;
+    return M >= 1024 && N >= 1024 && R >= 1024;      // measured: 96 vs 87 TFLOP/s at 1024 x 1024 x 6272 rows, a loss below
+}
+
 static inline int tn_splits(int R, int M, int N) {
-    const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    int S = cdiv(1024, tiles);                      // about four workgroups per CU in flight
+    const bool big = tn_big(R, M, N);
+    const int tiles = big ? cdiv(M, 128) * cdiv(N, 128) : cdiv(M, 64) * cdiv(N, 64);
+    int S = cdiv(big ? 512 : 1024, tiles);          // about two (128x128) / four (64x64) workgroups per CU in flight
     const int max_s = R / 256 > 1 ? R / 256 : 1;    // at least 256 rows per slab
     if (S > max_s) S = max_s;
     if (S > 64) S = 64;
@@ -616,20 +641,21 @@ extern "C" size_t fgn_gemm_tn_workspace_bytes(int R, int M, int N) {
     return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
 }
 
-// C [M,N] = A [R,M]^T B [R,N]; M % 4 == 0, N % 4 == 0; workspace: fgn_gemm_tn_workspace_bytes(R, M, N)
-extern "C" int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, int M, int N, void* workspace,
-                               hipStream_t stream) {
-    if (!A || !B || !C) return FGN_ERR_ARG;
-    if (R <= 0 || M <= 0 || N <= 0 || M % 4 || N % 4) return FGN_ERR_SHAPE;
+template <int BM, int BN, int TN_BK>
+static int tn_launch(const float* A, const float* B, float* C, int R, int M, int N, void* workspace, hipStream_t stream) {
     const int S = tn_splits(R, M, N);
     if (S > 1 && !workspace) return FGN_ERR_ARG;
-    const int ntn = cdiv(N, 64);
+    const int ntn = cdiv(N, BN);
     int rows_per = cdiv(R, S);
     rows_per = cdiv(rows_per, TN_BK) * TN_BK;
     const int S_eff = cdiv(R, rows_per);
     float* dst = S_eff > 1 ? reinterpret_cast<float*>(workspace) : C;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(M, 64) * ntn, S_eff), dim3(256), 0, stream, A, B, dst, R, M, N, ntn,
-                       rows_per);
+    constexpr size_t lds = (size_t)2 * TN_BK * ((BM + 16) + (BN + 16)) * sizeof(float);      // 40 KB / 73.7 KB
+    static unsigned long long ok = 0ull;
+    const hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(gemm_tn_kernel<BM, BN, TN_BK>), &ok);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, TN_BK>), dim3(cdiv(M, BM) * ntn, S_eff), dim3(256), lds, stream, A, B, dst, R, M, N,
+                       ntn, rows_per);
     if (S_eff > 1) {
         const long long n4 = (long long)M * N / 4;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for(n4)), dim3(256), 0, stream,
@@ -637,6 +663,16 @@ extern "C" int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, 
     }
     FGN_LAUNCH_CHECK();
     return FGN_OK;
+}
+
+// C [M,N] = A [R,M]^T B [R,N]; M % 4 == 0, N % 4 == 0; workspace: fgn_gemm_tn_workspace_bytes(R, M, N)
+extern "C" int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, int M, int N, void* workspace,
+                               hipStream_t stream) {
+    if (!A || !B || !C) return FGN_ERR_ARG;
+    if (R <= 0 || M <= 0 || N <= 0 || M % 4 || N % 4) return FGN_ERR_SHAPE;
+    // (64-row chunks at half the occupancy were 8 % slower on every shape of tools/gemm_tn_bench.py)
+    return tn_big(R, M, N) ? tn_launch<128, 128, 32>(A, B, C, R, M, N, workspace, stream)
+                           : tn_launch<64, 64, 32>(A, B, C, R, M, N, workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
