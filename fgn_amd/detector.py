@@ -376,15 +376,7 @@ class FGN(torch.nn.Module):
                     sd, f'backbone.layer{li + 1}.{b}', stride if b == 0 else 1, eps, winograd=self.use_winograd)
                 for b in range(nblk)])
         P.update(self._pack_heads(sd))
-        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
-                       for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
-        # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
-        # (RoIAlign commutes with it); the shift is added after the pooling
-        c1 = P['shared'][0].conv1
-        P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
-                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
-            if self.use_roi_commute else None
-        P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
+        P.update(self._pack_shared(sd))
         rp = cfg['rpn_head']
         P['anchors'] = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'],
                                                          rp['anchor_stride']))
@@ -405,6 +397,24 @@ class FGN(torch.nn.Module):
             return o
         self._P = {k: mv(v) for k, v in P.items()}
         self._packed_device = torch.device(device)
+        self._shared_dirty = None
+
+    def _pack_shared(self, sd) -> dict:
+        """The shared head for INFERENCE (BatchNorm in eval mode, folded into the conv epilogues) from torch-layout
+        weights and running statistics ``sd`` (CPU state dict, or a Trainer's device-resident masters + buffers)."""
+        cfg = self.cfg
+        eps = cfg['backbone']['bn_eps']
+        P = {}
+        P['shared'] = [_Bottleneck(sd, f'roi_head.shared_head.{b}', 1, eps, winograd=self.use_winograd)
+                       for b in range(cfg['roi_head']['shared_head']['num_blocks'])]
+        # conv1 of the first shared_head block with its BN scale folded and no shift / ReLU: applied to the C4 map
+        # (RoIAlign commutes with it); the shift is added after the pooling
+        c1 = P['shared'][0].conv1
+        P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
+                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
+            if self.use_roi_commute else None
+        P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
+        return P
 
     def _pack_heads(self, sd) -> dict:
         """The packed AG-RPN / relation / box / mask head layers from torch-layout weights ``sd`` (CPU tensors of the
@@ -575,10 +585,22 @@ class FGN(torch.nn.Module):
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._packed_device != dev:
             self._pack(dev)
+        self._sync_trained_shared()
         B = spp_imgs.shape[0] if spp_imgs.dim() == 5 else 1
         sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, torch.cuda.current_stream())
         self._support_back(sc, B, dev)
         return sc
+
+    def _sync_trained_shared(self) -> None:
+        """A ``fgn_amd.train.Trainer`` updates the head layers in place after every step; the inference form of the
+        shared head (eval-mode BatchNorm folded from the CURRENT weights and running statistics) is rebuilt here, on
+        the first inference call after a training step, so ``simple_test`` always sees the trainer's weights."""
+        src = getattr(self, '_shared_dirty', None)
+        if src is not None:
+            for k, v in self._pack_shared(src).items():
+                self._P[k] = v
+            self._shared_dirty = None
+            self._graphs = {}
 
     def _stream_for(self, role: str, main) -> 'torch.cuda.Stream':
         """One auxiliary HIP stream per (role, caller stream)."""
@@ -668,6 +690,7 @@ class FGN(torch.nn.Module):
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._packed_device != dev:
             self._pack(dev)
+        self._sync_trained_shared()
         with ops.arena(dev):     # zero-initialised small outputs of this episode: one fill (caller's stream only)
             return self._detect_body(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev)
 

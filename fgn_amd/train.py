@@ -709,6 +709,7 @@ class Trainer:
         for k, v in heads.items():
             m._P[k] = v if not isinstance(v, torch.Tensor) else v.float().contiguous()
         pack_train(m, self.device, self.W, self.buffers)
+        m._shared_dirty = {**self.W, **self.buffers}      # the inference form of the shared head is rebuilt lazily
         m._graphs = {}
 
     def forward_backward(self, batch: dict, perm_fn=torch.randperm) -> dict:

@@ -566,8 +566,10 @@ def test_training_produces_a_working_detector():
         tot = sum(_f(v) for k, v in L.items() if 'loss' in k)
         first = tot if first is None else first
         last = tot
+    live = evaluate_results(m.simple_test(**batch, rescale=True), 3)      # straight after the last step: the trainer's weights
     m.load_state_dict(tr.state_dict())
-    after = evaluate_results(m.simple_test(**batch, rescale=True), 3)
+    after = evaluate_results(m.simple_test(**batch, rescale=True), 3)       # and through a checkpoint round trip
+    assert live == after
     print('summed loss', round(first, 3), '->', round(last, 3), '| AP50 before', before, 'after', after)
     assert last < 0.5 * first
     assert before['bbox_mAP50'] < 0.2
