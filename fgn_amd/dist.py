@@ -130,7 +130,12 @@ def allreduce_mean(tensors: dict) -> dict:
         return tensors
     keys = sorted(tensors)
     flat = torch.cat([tensors[k].reshape(-1) for k in keys])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == 'gloo':        # CPU rehearsals of the multi-rank path: stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= dist.get_world_size()
     out, o = {}, 0
     for k in keys:
