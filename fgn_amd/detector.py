@@ -28,7 +28,7 @@ import torch
 
 from . import config as _config
 from . import ops, rle
-from .weights import init_state_dict
+from .weights import backbone_state_from_pretrained, init_state_dict
 
 
 # ------------------------------------------------------------------------------------------
@@ -287,8 +287,20 @@ class FGN(torch.nn.Module):
         self.cfg = normalise_config(self.n_ways, self.k_shots, backbone, rpn_head, roi_head, test_cfg, train_cfg)
         self.train_cfg = train_cfg
         self.test_cfg = self.cfg['test_cfg']
-        self._sd = OrderedDict((k, v.detach().float().cpu()) for k, v in
+        if self.test_cfg['rcnn'].get('mask_thr_binary', 0.5) < 0.5:
+            import warnings
+            warnings.warn('mask_thr_binary < 0.5: masks are pasted inside the integer-expanded box only (mmdet '
+                          '_do_paste_mask(skip_empty=True), the CPU semantics this build and its oracle follow); the '
+                          'reference on a CUDA device pastes over the whole image and can set up to box_w/28 more '
+                          'pixels outside the box below 0.5 (DESIGN.md section 2)', stacklevel=2)
+        self._sd = OrderedDict((k, self._canon(k, v)) for k, v in
                                (state_dict if state_dict is not None else init_state_dict(self.cfg, seed)).items())
+        # mmcv `Pretrained` init_cfg of the backbone (fgn_r50_c4_densecl.py:39-41) / the deprecated `pretrained=` kwarg:
+        # applied by init_weights(), as in the reference (main.py:431-434)
+        ic = (backbone or {}).get('init_cfg') or init_cfg
+        ic = ic[0] if isinstance(ic, (list, tuple)) and ic else ic
+        self.backbone_pretrained = pretrained or (ic.get('checkpoint') if isinstance(ic, dict) and
+                                                  ic.get('type') == 'Pretrained' else None) or None
         self._packed_device = None
         self._PT = None                           # train-mode layers of the shared head (fgn_amd.train.pack_train)
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
@@ -326,26 +338,75 @@ class FGN(torch.nn.Module):
         return cls(**model_cfg)
 
     # --- weights --------------------------------------------------------------------------
+    def _trainer_alive(self):
+        ref = getattr(self, '_trainer', None)
+        return ref() if ref is not None else None
+
+    def _source_sd(self) -> dict:
+        """The weights every (re-)pack starts from: the state dict, overlaid with the device-resident master weights
+        and running statistics of a live ``fgn_amd.train.Trainer`` - so a re-pack after training steps (device change,
+        ``use_winograd`` setter, ``_packed_device`` reset) never falls back to the initial heads."""
+        tr = self._trainer_alive()
+        if tr is None:
+            return self._sd
+        sd = OrderedDict(self._sd)
+        sd.update(tr.W)
+        sd.update(tr.buffers)
+        return sd
+
     def state_dict(self, *a, **k):
-        return OrderedDict(self._sd)
+        tr = self._trainer_alive()
+        return OrderedDict(self._sd) if tr is None else OrderedDict(tr.state_dict())
+
+    @staticmethod
+    def _canon(name: str, v: torch.Tensor) -> torch.Tensor:
+        return v.detach().cpu() if name.endswith('num_batches_tracked') else v.detach().float().cpu()
+
+    def init_weights(self) -> None:
+        """mmcv ``BaseModule.init_weights`` as far as this path needs it: the backbone's ``Pretrained`` init_cfg
+        (fgn_r50_c4_densecl.py:39-41; main.py:431-434).  Without one the seeded initialisation stands."""
+        if self.backbone_pretrained:
+            self.load_backbone_pretrained(self.backbone_pretrained)
+
+    def load_backbone_pretrained(self, ckpt) -> dict:
+        """Load a backbone-only checkpoint (path, or state dict with un-prefixed torchvision / mmcv ResNet keys) into
+        ``backbone.*`` only, non-strict like mmcv's ``load_checkpoint(backbone, ..., strict=False)``: entries the C4
+        backbone does not have (``layer4.*``, ``fc.*``) are reported as unexpected, absent ones as missing (the
+        optional ``num_batches_tracked`` buffers aside).  Heads keep their weights."""
+        src = backbone_state_from_pretrained(ckpt)
+        own = [k for k in self._sd if k.startswith('backbone.')]
+        picked = {k: src[k] for k in own if k in src}
+        for k, v in picked.items():
+            if tuple(v.shape) != tuple(self._sd[k].shape):
+                raise ValueError(f'shape mismatch for {k}: {tuple(v.shape)} vs {tuple(self._sd[k].shape)}')
+        report = dict(loaded=len(picked),
+                      missing=[k for k in own if k not in src and not k.endswith('num_batches_tracked')],
+                      unexpected=[k for k in src if k not in self._sd])
+        if not picked:
+            raise KeyError('no backbone tensor found in the checkpoint (expected keys like conv1.weight, layer1.0.conv1.weight)')
+        self.load_state_dict(picked, strict=False)
+        return report
 
     def load_state_dict(self, state_dict, strict: bool = True):
         sd = state_dict.get('state_dict', state_dict)
-        missing = [k for k in self._sd if k not in sd]
+        missing = [k for k in self._sd if k not in sd and not k.endswith('num_batches_tracked')]
         if strict and missing:
             raise KeyError(f'missing keys in state_dict: {missing[:5]} ...')
         for k in self._sd:
             if k in sd:
                 if tuple(sd[k].shape) != tuple(self._sd[k].shape):
                     raise ValueError(f'shape mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._sd[k].shape)}')
-                self._sd[k] = sd[k].detach().float().cpu()
+                self._sd[k] = self._canon(k, sd[k])
         self._packed_device = None
         self._PT = None
         self._graphs = {}
+        tr = self._trainer_alive()
+        if tr is not None:              # a live trainer adopts the loaded weights (its Adagrad sums are kept)
+            tr.adopt(self._sd)
 
     def _pack(self, device):
         """Fold BN, re-layout weights for the kernels and move them to ``device``."""
-        sd, cfg = self._sd, self.cfg
+        sd, cfg = self._source_sd(), self.cfg
         eps = cfg['backbone']['bn_eps']
         P = {}
         bb = cfg['backbone']
@@ -398,6 +459,8 @@ class FGN(torch.nn.Module):
         self._P = {k: mv(v) for k, v in P.items()}
         self._packed_device = torch.device(device)
         self._shared_dirty = None
+        if self._trainer_alive() is not None:      # the train-mode layers follow the same weights
+            self._PT = None
 
     def _pack_shared(self, sd) -> dict:
         """The shared head for INFERENCE (BatchNorm in eval mode, folded into the conv epilogues) from torch-layout

@@ -121,14 +121,21 @@ def _hip_rle(prob, boxes, h, w, thr):
 # ------------------------------------------------------------------------------------------
 # data-parallel training: one episode batch per rank, gradients averaged with ONE all-reduce
 # ------------------------------------------------------------------------------------------
-def allreduce_mean(tensors: dict) -> dict:
+def allreduce_mean(tensors: dict, keys=None) -> dict:
     """Average a dict of same-device fp32 tensors over the ranks with a single all-reduce of one flat bucket (the heads
     hold ~26 M parameters: one 105 MB message per step - bandwidth-bound on the xGMI ring, never one collective per
-    tensor).  Keys are visited in sorted order so that every rank builds the same bucket.  No process group or a
-    single rank: the dict is returned unchanged."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not tensors:
+    tensor).  ``keys``: the rank-invariant key list of the bucket (default: the sorted keys of ``tensors``, which must
+    then be the same set on every rank); every key must be present - a rank whose batch produced no gradient for a
+    tensor passes zeros, never a shorter dict (ranks disagreeing on the bucket length hang or corrupt the collective).
+    No process group or a single rank: the dict is returned unchanged."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tensors
-    keys = sorted(tensors)
+    keys = sorted(tensors) if keys is None else list(keys)
+    missing = [k for k in keys if k not in tensors]
+    if missing:
+        raise KeyError(f'allreduce_mean: no tensor for {missing[:3]} on this rank; fill missing gradients with zeros')
+    if not keys:
+        return tensors
     flat = torch.cat([tensors[k].reshape(-1) for k in keys])
     if flat.is_cuda and dist.get_backend() == 'gloo':        # CPU rehearsals of the multi-rank path: stage through the host
         host = flat.cpu()

@@ -87,6 +87,9 @@ class _SharedBlockTrain:
 def pack_train(model, device, weights: Optional[dict] = None, buffers: Optional[dict] = None) -> None:
     """Raw (un-folded) shared-head layers and their BatchNorm parameters / running buffers on ``device``."""
     nb = model.cfg['roi_head']['shared_head']['num_blocks']
+    tr = model._trainer_alive() if hasattr(model, '_trainer_alive') else None
+    if weights is None and tr is not None:         # never rebuild from the stale initial state dict while training
+        weights, buffers = tr.W, tr.buffers
     src = model._sd if weights is None else weights
     anchors = model._PT['anchors'] if getattr(model, '_PT', None) else {}
     model._PT = {'shared': [_SharedBlockTrain(src, f'roi_head.shared_head.{b}', model.use_winograd, buffers).to(device)
@@ -361,9 +364,9 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     if tr is not None:
         tr.update(rois=rois, bbox_feats=feats, cls_score=cls_score, bbox_pred=bbox_pred, labels=labels)
     if tape is not None:
-        if not n_rois:
-            raise ValueError('training step without a single sampled RoI')
-        tape['roi'] = dict(rois=rois, blocks=roi_tape, feats=feats, Q=Q, S=sc['S'], cls_raw=cls_raw, cls_score=cls_score,
+        # (an episode without proposals and without ground truth samples no RoI: the RoI stage then contributes zero
+        # gradients - a rank-local exception here would strand the other ranks of a data-parallel job in all_reduce)
+        tape['roi'] = None if not n_rois else dict(rois=rois, blocks=roi_tape, feats=feats, Q=Q, S=sc['S'], cls_raw=cls_raw, cls_score=cls_score,
                            bbox_pred=bbox_pred, labels=labels, lw=lw, avg=avg, pos_rows=pos_rows, n_rois=n_rois,
                            pos_pred=pos_pred, pos_tgt=pos_tgt,
                            img_counts=[s['n_pos'] + s['n_neg'] for s in samples])
@@ -502,11 +505,18 @@ def backward(model, W: dict, tape: dict) -> dict:
     """Gradients of the summed losses (mmdet ``_parse_losses``: every key containing 'loss') with respect to the
     trainable parameters ``W`` (torch-layout master weights on the device), from the tape of ``forward_train``.
     The backbone is frozen (fgn.py:67-73), so nothing flows below RoIAlign / the AG-RPN input."""
+    grads: dict = {}
+    if tape['roi'] is not None:
+        _backward_roi_stage(model, W, tape, grads)
+    _backward_rpn_stage(model, W, tape, grads)
+    return grads
+
+
+def _backward_roi_stage(model, W: dict, tape: dict, grads: dict) -> None:
     cfg = model.cfg
     N, K = model.n_ways, model.k_shots
     P = model._P
     rh = cfg['roi_head']
-    grads: dict = {}
     dev = tape['roi']['rois'].device
 
     # ---- mask head (fgn_roi_head.py:360-417) ------------------------------------------------------------
@@ -611,6 +621,10 @@ def backward(model, W: dict, tape: dict) -> dict:
         d_sfeat = d_sfeat + d_cat_mean_mp.repeat_interleave(K, dim=0)[:, None, None, :] * m7 / float(K * ps * ps)
     _shared_backward(model, W, tape['spp']['blocks'], d_sfeat.contiguous(), grads)
 
+
+def _backward_rpn_stage(model, W: dict, tape: dict, grads: dict) -> None:
+    N = model.n_ways
+    dev = tape['rpn']['head'].device
     # ---- AG-RPN head (fgn_ag_rpn_head.py:48 -> RPNHead.forward_single; losses my_anchor_head.py:402-451) ----
     t = tape['rpn']
     A, head, G = t['A'], t['head'], t['head'].shape[0]
@@ -651,7 +665,6 @@ def backward(model, W: dict, tape: dict) -> dict:
     patches = (torch.stack(taps, 1) * vec[gi][:, None, :]).reshape(rows.numel(), 9 * Cin)
     grads['rpn_head.rpn_conv.weight'] = _mm_tn(dpre, patches).view(Cf, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
     grads['rpn_head.rpn_conv.bias'] = ops.colsum(dpre)
-    return grads
 
 
 TRAINABLE_PREFIXES = ('rpn_head.', 'roi_head.')
@@ -700,6 +713,11 @@ class Trainer:
         self.buffers = {k: v.to(dev).float().contiguous().clone() for k, v in sd.items()
                         if k.startswith('roi_head.shared_head') and 'running_' in k}
         self.grads: dict = {}
+        self.n_steps = 0
+        self._bn_tracked0 = {k: int(v) for k, v in sd.items()
+                             if k.startswith('roi_head.shared_head') and k.endswith('num_batches_tracked')}
+        import weakref
+        model._trainer = weakref.ref(self)      # the model sources its weights from W / buffers while a trainer lives
         self.refresh()
 
     def refresh(self) -> None:
@@ -712,14 +730,31 @@ class Trainer:
         m._shared_dirty = {**self.W, **self.buffers}      # the inference form of the shared head is rebuilt lazily
         m._graphs = {}
 
+    def adopt(self, sd: dict) -> None:
+        """Take over weights / running statistics loaded into the model (``FGN.load_state_dict`` during training)."""
+        for k in self.W:
+            if k in sd:
+                self.W[k].copy_(sd[k].to(self.device, torch.float32))
+        for k in self.buffers:
+            if k in sd:
+                self.buffers[k].copy_(sd[k].to(self.device, torch.float32))
+        if self.model._packed_device != self.device:
+            self.model._pack(self.device)
+        self.refresh()
+
     def forward_backward(self, batch: dict, perm_fn=torch.randperm) -> dict:
         m = self.model
         m._tape = {}
         try:
             losses = forward_train(m, perm_fn=perm_fn, bn_momentum=self.bn_momentum, **batch)
-            self.grads = backward(m, self.W, m._tape)
+            g = backward(m, self.W, m._tape)
         finally:
             m._tape = None
+        # a gradient for EVERY trainable tensor, zeros where this batch produced none (no positive RoI -> the mask
+        # head, no sampled RoI -> the whole RoI stage).  The reference gets zero - not None - gradients there
+        # (loss_mask = mask_pred.sum() * 0 on an empty selection), so Adagrad still applies its weight decay; and the
+        # data-parallel bucket has the same layout on every rank whatever each rank's batch held.
+        self.grads = {k: g[k] if k in g else torch.zeros_like(w) for k, w in self.W.items()}
         return losses
 
     def step(self, batch: dict, perm_fn=torch.randperm) -> dict:
@@ -729,34 +764,70 @@ class Trainer:
         like torch DDP without SyncBN)."""
         losses = self.forward_backward(batch, perm_fn)
         from .dist import allreduce_mean
-        self.grads = allreduce_mean(self.grads)
-        for k, g in self.grads.items():
+        self.grads = allreduce_mean(self.grads, keys=sorted(self.W))
+        for k in self.W:
             lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
-            ops.adagrad_step(self.W[k], g.contiguous(), self.state[k], lr, self.wd, self.eps)
+            ops.adagrad_step(self.W[k], self.grads[k].contiguous(), self.state[k], lr, self.wd, self.eps)
+        self.n_steps += 1
         self.refresh()
         return losses
 
+    def optimizer_state_dict(self) -> dict:
+        """``torch.optim.Adagrad.state_dict()`` layout, as mmcv saves it (checkpoint_config save_optimizer=True,
+        fgn_train_schedule.py:33-38): 'state' {index: {'step', 'sum'}} and one param group per parameter - mmcv's
+        DefaultOptimizerConstructor builds one group per parameter under ``paramwise_cfg`` (the 0.1 lr_mult of
+        ``roi_head``, fgn_train_schedule.py:3-13).  Parameter order = ``trainable_names`` = the order of the heads'
+        parameters in the state dict; the frozen backbone's parameters (no state in torch either) are not listed, so
+        indices are relative to the first trainable parameter - ``param_names`` (an extra key) spells them out."""
+        names = list(self.W)
+        step = torch.tensor(float(self.n_steps))
+        return {'state': {i: {'step': step.clone(), 'sum': self.state[k].detach().cpu()} for i, k in enumerate(names)},
+                'param_groups': [{'lr': self.lr * (self.mult if k.startswith('roi_head') else 1.0), 'lr_decay': 0,
+                                  'eps': self.eps, 'weight_decay': self.wd, 'initial_accumulator_value': 0,
+                                  'foreach': None, 'maximize': False, 'differentiable': False, 'fused': None,
+                                  'params': [i]} for i, k in enumerate(names)],
+                'param_names': names}
+
     def checkpoint(self, meta: Optional[dict] = None) -> dict:
-        """mmcv checkpoint layout with the optimizer (checkpoint_config save_optimizer=True,
-        fgn_train_schedule.py:33-38): {'state_dict', 'optimizer': Adagrad sums per parameter, 'meta'}."""
-        return {'state_dict': self.state_dict(), 'meta': dict(meta or {}),
-                'optimizer': {'type': 'Adagrad', 'lr': self.lr, 'weight_decay': self.wd,
-                              'roi_head_lr_mult': self.mult, 'eps': self.eps,
-                              'state_sum': {k: v.detach().cpu() for k, v in self.state.items()}}}
+        """mmcv checkpoint layout: {'state_dict', 'optimizer' (torch Adagrad layout, see ``optimizer_state_dict``),
+        'meta'}."""
+        return {'state_dict': self.state_dict(), 'meta': dict(meta or {}, iter=self.n_steps),
+                'optimizer': self.optimizer_state_dict()}
 
     def resume(self, ckpt: dict) -> None:
-        """Continue from ``checkpoint()`` (or from a plain mmcv checkpoint without optimizer state)."""
+        """Continue from ``checkpoint()``, from a torch / mmcv checkpoint whose 'optimizer' is a
+        ``torch.optim.Adagrad.state_dict()`` over the same parameter order, or from a plain state dict."""
         sd = ckpt.get('state_dict', ckpt)
         for k in self.W:
             self.W[k].copy_(sd[k].to(self.device, torch.float32))
         for k in self.buffers:
             if k in sd:
                 self.buffers[k].copy_(sd[k].to(self.device, torch.float32))
+        for k in self._bn_tracked0:
+            if k in sd:
+                self._bn_tracked0[k] = int(sd[k]) - 2 * int(ckpt.get('meta', {}).get('iter', 0))
         opt = ckpt.get('optimizer')
         if opt is not None:
-            for k, v in opt['state_sum'].items():
-                self.state[k].copy_(v.to(self.device, torch.float32))
-            self.lr, self.wd = opt.get('lr', self.lr), opt.get('weight_decay', self.wd)
+            if 'state_sum' in opt:                                    # this package's round-2 layout
+                sums = opt['state_sum']
+                self.lr, self.wd = opt.get('lr', self.lr), opt.get('weight_decay', self.wd)
+            elif 'state' in opt and 'param_groups' in opt:
+                names = list(opt.get('param_names', self.W))
+                n_idx = sum(len(g['params']) for g in opt['param_groups'])
+                if n_idx != len(names) or set(names) != set(self.W):
+                    raise ValueError(f'optimizer state covers {n_idx} parameters, the trainable heads have '
+                                     f'{len(self.W)}: cannot map indices to parameters (pass param_names)')
+                sums = {names[int(i)]: st['sum'] for i, st in opt['state'].items()}
+                steps = [float(st['step']) for st in opt['state'].values()]
+                self.n_steps = int(max(steps)) if steps else 0
+                by_name = {names[i]: g for g in opt['param_groups'] for i in g['params']}
+                rp = next((g for k, g in by_name.items() if not k.startswith('roi_head')), None)
+                if rp is not None:
+                    self.lr, self.wd = float(rp['lr']), float(rp['weight_decay'])
+            else:
+                raise ValueError("unknown 'optimizer' entry: expected torch.optim.Adagrad.state_dict() layout")
+            for k, v in sums.items():
+                self.state[k].copy_(v.to(self.device, torch.float32).view_as(self.state[k]))
         self.refresh()
 
     def state_dict(self) -> dict:
@@ -766,4 +837,6 @@ class Trainer:
             sd[k] = v.detach().cpu()
         for k, v in self.buffers.items():
             sd[k] = v.detach().cpu()
+        for k, v0 in self._bn_tracked0.items():       # every BatchNorm of the shared head runs twice per step
+            sd[k] = torch.tensor(v0 + 2 * self.n_steps, dtype=torch.long)       # (RoI batch + support batch)
         return sd

@@ -48,6 +48,7 @@ def _bn(sd, g, name, c, gamma_scale=1.0):
     sd[name + '.bias'] = 0.1 * torch.randn(c, generator=g)
     sd[name + '.running_mean'] = 0.1 * torch.randn(c, generator=g)
     sd[name + '.running_var'] = 0.75 + 0.5 * torch.rand(c, generator=g)
+    sd[name + '.num_batches_tracked'] = torch.zeros((), dtype=torch.long)      # torch BatchNorm buffer (no RNG draw)
 
 
 def _gn(sd, g, name, c, gamma_scale=1.0):
@@ -183,4 +184,27 @@ def load_checkpoint(path: str) -> 'OrderedDict[str, torch.Tensor]':
     state_dict (main.py:426-430 resumes from the former)."""
     ckpt = torch.load(path, map_location='cpu')
     sd = ckpt.get('state_dict', ckpt)
-    return OrderedDict((k, v.float()) for k, v in sd.items())
+    return OrderedDict((k, v if k.endswith('num_batches_tracked') else v.float()) for k, v in sd.items())
+
+
+def backbone_state_from_pretrained(ckpt, prefix: str = 'backbone.') -> 'OrderedDict[str, torch.Tensor]':
+    """Keys of a backbone-only checkpoint -> this model's ``backbone.*`` names.
+
+    The reference initialises its headline config from a DenseCL ResNet-50 file through mmcv's ``Pretrained``
+    init_cfg on the BACKBONE module (fgn_r50_c4_densecl.py:4-11, 39-41; ``model.init_weights()``, main.py:431-434):
+    ``load_checkpoint(backbone, path, strict=False)``.  Such a file is a torchvision-style ResNet state dict - keys
+    ``conv1.weight``, ``bn1.*``, ``layer1.0.conv1.weight`` ... without any module prefix, possibly wrapped in
+    ``{'state_dict': ...}``, possibly carrying a ``module.`` / ``backbone.`` / ``encoder_q.`` prefix from the
+    self-supervised trainer, and with ``layer4.*`` / ``fc.*`` entries this C4 model does not have (main.py:403-405
+    deletes layer4).  Returns the renamed tensors; what does not belong to the backbone is dropped by the caller
+    (non-strict, like mmcv)."""
+    if isinstance(ckpt, str):
+        ckpt = torch.load(ckpt, map_location='cpu')
+    sd = ckpt.get('state_dict', ckpt)
+    out = OrderedDict()
+    for k, v in sd.items():
+        for pre in ('module.', 'backbone.', 'encoder_q.', 'encoder.'):      # mmcv strips 'module.'; the rest is lenient
+            while k.startswith(pre):
+                k = k[len(pre):]
+        out[prefix + k] = v if k.endswith('num_batches_tracked') else v.float()
+    return out

@@ -153,3 +153,60 @@ def test_mask_head_stage_matches_oracle_full_width():
     print(f'[parity mask head 100 RoIs x 1024ch] rel err logits {e_l:.2e} (|logit| <= {ref_logits.abs().max():.1f}), '
           f'max |d prob| {e_p:.2e}')
     assert e_l <= 2e-5 and e_p <= 1e-4
+
+
+def test_input_shim_and_result_packing_match_reference_fgn_py(golden_dir):
+    """tests/golden/fgn_glue.npz = the reference's own fgn.py (``modify_input``, ``get_img_metas``, the packing loop
+    of ``simple_test``: fgn.py:79-123, 240-303) run around recorder heads.  HIP side: ``FGN._support_front`` must
+    hand the heads the same XYXY support boxes / mask views without touching the caller's tensors, and
+    ``FGN.pack_results`` must turn the same head outputs (detections, labels, dense masks -> device RLE) and
+    passthrough inputs into the same result dicts: keys, key order, dtypes, shapes, values, RLE strings."""
+    from fgn_amd import ops
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.weights import init_state_dict
+    from _glue import assert_results_equal, glue_expected, glue_inputs
+    ins = glue_inputs()
+    before = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in ins.items()}
+    z = np.load(os.path.join(golden_dir, 'fgn_glue.npz'))
+    cfg = tiny_config(3, 2, width_div=8)
+    model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    model._pack(dev)
+    main = torch.cuda.current_stream()
+    B = ins['qry_img'].shape[0]
+    # ---- input side (modify_input + the views of fgn.py:213-218)
+    sc = model._support_front(ins['spp_imgs'], ins['spp_bboxes'], ins['spp_isegmaps'], B, dev, main)
+    assert np.array_equal(sc['spp_xyxy'].cpu().numpy(), z['server__roi_spp_bboxes'].reshape(-1, 4))
+    assert np.array_equal(sc['spp_masks'].cpu().numpy().astype(bool), z['server__roi_spp_isegmaps'][:, 0])
+    assert tuple(sc['spp_fmaps'].shape[:1]) == (int(z['server__extract_shapes'][1][0]),)
+    # ---- output side: the recorder heads' outputs as the device tensors detect_device produces
+    D, H, W = cfg['test_cfg']['rcnn']['max_per_img'], 24, 40
+    outs = []
+    for i in range(B):
+        det, lab, seg = z[f'server__head_det{i}'], z[f'server__head_lab{i}'], z[f'server__head_seg{i}']
+        n = len(det)
+        d = dict(det_bboxes=torch.zeros(D, 5, device=dev), det_labels=torch.zeros(D, dtype=torch.int64, device=dev),
+                 n_dets=torch.tensor([n], dtype=torch.int32, device=dev), mask_prob=torch.zeros(D, 14, 14, device=dev),
+                 rle_bytes=torch.zeros(D, ops.RLE_BYTE_CAP, dtype=torch.uint8, device=dev),
+                 rle_len=torch.zeros(D, dtype=torch.int32, device=dev),
+                 rle_overflow=torch.zeros(D, dtype=torch.int32, device=dev), img_hw=(H, W))
+        if n:
+            d['det_bboxes'][:n] = torch.from_numpy(det).to(dev)
+            d['det_labels'][:n] = torch.from_numpy(lab).to(dev)
+            rb, rl, ro = ops.dense_mask_rle(torch.from_numpy(seg).to(dev))
+            d['rle_bytes'][:n], d['rle_len'][:n], d['rle_overflow'][:n] = rb, rl, ro
+        outs.append(d)
+    _, gt_rle, uploaded = model._upload({'qry_img': ins['qry_img']}, ins['qry_isegmaps'], dev, main)
+    for d, g in zip(outs, gt_rle):
+        d['gt_rle'] = g
+    model._start_download(outs, main, uploaded)
+    got = model.pack_results(outs, B, **{k: ins[k] for k in (
+        'qry_bboxes', 'qry_cat_ids', 'qry_isegmaps', 'img_shape', 'qry_child_idx', 'cats_ids_to_sample_real',
+        'spp_insts_ids', 'idx')})
+    assert_results_equal(got, glue_expected(z))
+    # SERVER semantics: nothing the caller owns was modified
+    for k, v in ins.items():
+        for a, b in zip(v if isinstance(v, list) else [v], before[k] if isinstance(v, list) else [before[k]]):
+            assert torch.equal(a, b), k

@@ -104,14 +104,26 @@ def test_ag_rpn_merge_matches_reference_golden(golden_dir):
         conv = ops.pack_conv(w['rpn_head.rpn_conv.weight'], bias=w['rpn_head.rpn_conv.bias'], pad=1, relu=True).to('cuda')
         head = ops.pack_conv(torch.cat([w['rpn_head.rpn_cls.weight'], w['rpn_head.rpn_reg.weight']], 0),
                              bias=torch.cat([w['rpn_head.rpn_cls.bias'], w['rpn_head.rpn_reg.bias']], 0)).to('cuda')
-        x = ops.conv2d(_nhwc(qry).cuda(), conv, in_scale=vec, a_img_div=n)
-        y = ops.conv2d(x, head)
-        logits, scores, deltas = ops.rpn_merge(y, b, n, 15)
         ref_cls = torch.from_numpy(z['cls']).permute(0, 2, 3, 1).reshape(b, -1)          # (y,x,a)
         ref_reg = torch.from_numpy(z['reg']).permute(0, 2, 3, 1).reshape(b, -1, 4)
-        _close(logits.cpu(), ref_cls, 1e-5)
-        # the arg-max choice is discrete: compare deltas where the winner is unambiguous
-        _close(deltas.cpu(), ref_reg, 1e-4)
+        # three forms of the guided 3x3 conv: the guidance multiply fused into the A-operand staging of the direct
+        # kernel; the DEFAULT path of the detector (F(4x4,3x3) Winograd, guidance in wg4_input_kernel, grouped GEMM,
+        # detector.py::_detect_body); F(2x2,3x3)
+        guided = {'direct in_scale': lambda: ops.conv2d(_nhwc(qry).cuda(), conv, in_scale=vec, a_img_div=n)}
+        for m in (4, 2):
+            wg = ops.pack_winograd(w['rpn_head.rpn_conv.weight'], bias=w['rpn_head.rpn_conv.bias'], relu=True,
+                                   m=m).to('cuda')
+            guided[f'winograd F({m}x{m}) guided'] = \
+                lambda wg=wg: ops.conv3x3_winograd(_nhwc(qry).cuda(), wg, in_scale=vec, a_img_div=n)
+        for form, run in guided.items():
+            y = ops.conv2d(run(), head)
+            logits, scores, deltas = ops.rpn_merge(y, b, n, 15)
+            dl = (logits.cpu() - ref_cls).abs().max().item() / ref_cls.abs().max().item()
+            dd = (deltas.cpu() - ref_reg).abs().max().item() / ref_reg.abs().max().item()
+            print(f'[{name} {form}] rel err logits {dl:.1e}, deltas {dd:.1e}')
+            _close(logits.cpu(), ref_cls, 2e-5)
+            # the arg-max choice is discrete: compare deltas where the winner is unambiguous
+            _close(deltas.cpu(), ref_reg, 1e-4)
 
 
 # ---------------------------------------------------------------- relation head

@@ -607,6 +607,76 @@ def test_checkpoint_resume_continues_the_run():
     assert set(ck) == {'state_dict', 'optimizer', 'meta'} and ck['meta']['iter'] == 2
 
 
+def test_step_without_positives_keeps_every_gradient_and_torch_optimizer_layout():
+    """(1) A batch without any ground truth samples no positive RoI: the mask head (and the box regression) get ZERO
+    gradients - not missing ones - so the data-parallel bucket has the same keys on every rank and Adagrad still
+    applies its weight decay (torch: g = 0 + wd * p), as the reference's ``mask_pred.sum() * 0`` losses do.
+    (2) The checkpoint's optimizer entry is ``torch.optim.Adagrad.state_dict()`` layout: torch loads it, and
+    ``resume`` accepts torch's own.  (3) A re-pack after training (device / Winograd switch / ``_packed_device`` reset)
+    starts from the trainer's weights, not from the initial state dict."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.train import Trainer
+    cfg = tiny_config(3, 2, width_div=2)
+    b = make_batch(4, 2, 3, 2, 160, 224, 64)
+    empty = copy.deepcopy(b)
+    for i in range(2):
+        empty['qry_bboxes'][i], empty['qry_cat_ids'][i] = b['qry_bboxes'][i][:0], b['qry_cat_ids'][i][:0]
+        empty['qry_isegmaps'][i] = b['qry_isegmaps'][i][:0]
+    m, _ = _models(cfg)
+    t = Trainer(m)
+    torch.manual_seed(0)
+    t.step(b)
+    name = 'roi_head.mask_head.convs.1.conv.weight'
+    w0, s0 = t.W[name].clone(), t.state[name].clone()
+    torch.manual_seed(1)
+    t.step(empty)
+    assert set(t.grads) == set(t.W)
+    assert float(t.grads[name].abs().max()) == 0.0 and float(t.grads['rpn_head.rpn_conv.weight'].abs().max()) > 0.0
+    # torch.optim.Adagrad on a zero gradient with weight decay: sum += (wd p)^2, p -= lr * wd p / (sqrt(sum) + eps)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adagrad([p], lr=t.lr * t.mult, weight_decay=t.wd, eps=t.eps)
+    opt.state[p]['sum'].copy_(s0)
+    p.grad = torch.zeros_like(p)
+    opt.step()
+    assert torch.allclose(t.W[name], p.detach(), rtol=1e-6, atol=1e-9) and not torch.equal(t.W[name], w0)
+    assert torch.allclose(t.state[name], opt.state[p]['sum'], rtol=1e-6, atol=0)
+    # ---- torch layout of the optimizer entry
+    ck = t.checkpoint()
+    names = ck['optimizer']['param_names']
+    assert names == list(t.W) and ck['meta']['iter'] == 2
+    params = [torch.nn.Parameter(ck['state_dict'][k].clone()) for k in names]
+    topt = torch.optim.Adagrad([{'params': [q], 'lr': g['lr']} for q, g in zip(params, ck['optimizer']['param_groups'])],
+                               lr=t.lr, weight_decay=t.wd, eps=t.eps)
+    topt.load_state_dict({k: v for k, v in ck['optimizer'].items() if k != 'param_names'})
+    for q, k in zip(params, names):
+        assert torch.equal(topt.state[q]['sum'], t.state[k].cpu()) and float(topt.state[q]['step']) == 2.0
+    assert topt.param_groups[names.index(name)]['lr'] == pytest.approx(t.lr * t.mult)
+    assert topt.param_groups[names.index('rpn_head.rpn_conv.weight')]['lr'] == pytest.approx(t.lr)
+    bn_key = 'roi_head.shared_head.0.bn1.num_batches_tracked'
+    assert int(ck['state_dict'][bn_key]) == int(m._sd[bn_key]) + 4          # 2 steps x (RoI batch + support batch)
+    m2, _ = _models(cfg)
+    t2 = Trainer(m2)
+    t2.resume({'state_dict': ck['state_dict'], 'optimizer': topt.state_dict(), 'meta': ck['meta']})   # torch's own dict
+    assert t2.n_steps == 2
+    for k in t.W:
+        assert torch.equal(t2.state[k], t.state[k]) and torch.equal(t2.W[k], t.W[k])
+    # ---- re-pack after training
+    want = m.simple_test(**b, rescale=True)
+    m._packed_device = None                          # what a device change / use_winograd switch does
+    got = m.simple_test(**b, rescale=True)
+    for w, g in zip(want, got):
+        assert np.array_equal(w['dt_scores'], g['dt_scores']) and np.array_equal(w['dt_bboxes'], g['dt_bboxes'])
+    torch.manual_seed(2)
+    l_a = t.step(b)                                   # forward_train after the re-pack: trainer's weights, too
+    torch.manual_seed(2)
+    l_b = t2.step(b)
+    for k in l_a:
+        assert _f(l_a[k]) == pytest.approx(_f(l_b[k]), rel=1e-5, abs=1e-7), k
+    fresh = m.state_dict()
+    assert torch.equal(fresh[name], t.W[name].cpu())   # the model's state dict is the trainer's
+
+
 @pytest.mark.parametrize('R,M,N', [(6272, 1024, 512), (441, 512, 4608), (200, 1024, 9216), (1000, 76, 1024), (37, 8, 12),
                                    (300, 1024, 4), (5000, 4, 256), (33, 64, 64)])
 def test_weight_gradient_gemm_matches_fp64(R, M, N):

@@ -424,3 +424,47 @@ def test_trainer_refuses_the_trainable_backbone_config():
     m = FGN(3, 1, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'])
     with pytest.raises(NotImplementedError):
         Trainer(m)
+
+
+def test_backbone_only_pretrained_checkpoint_loads_into_backbone_only(tmp_path):
+    """The reference's headline config initialises the BACKBONE from a DenseCL ResNet-50 file through mmcv's
+    ``Pretrained`` init_cfg (fgn_r50_c4_densecl.py:4-11, 39-41; ``model.init_weights()``, main.py:431-434): a
+    torchvision-style state dict without module prefix, with layer4 / fc entries the C4 model lacks."""
+    import warnings
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 1, width_div=8)
+    donor = init_state_dict(cfg, 7)
+    file_sd = {k[len('backbone.'):]: v for k, v in donor.items() if k.startswith('backbone.')}
+    file_sd['layer4.0.conv1.weight'] = torch.zeros(4, 4, 1, 1)
+    file_sd['fc.weight'] = torch.zeros(10, 4)
+    path = str(tmp_path / 'densecl_like.pth')
+    torch.save({'state_dict': {'module.' + k: v for k, v in file_sd.items()}, 'meta': {}}, path)
+    bb = dict(type='ResNet', depth=50, num_stages=4, strides=(1, 2, 2, 2), out_indices=(2,), frozen_stages=4,
+              norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch',
+              init_cfg=[dict(type='Pretrained', checkpoint=path)])
+    m = FGN(3, 1, backbone=bb, seed=0)                      # full-width R50 from the reference-style dict ...
+    assert m.backbone_pretrained == path
+    m = FGN(3, 1, backbone=dict(cfg['backbone'], init_cfg=[dict(type='Pretrained', checkpoint=path)]),
+            rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'], test_cfg=cfg['test_cfg'], seed=0)   # ... narrow for the load
+    before = m.state_dict()
+    m.init_weights()
+    after = m.state_dict()
+    for k, v in after.items():
+        if k.startswith('backbone.'):
+            assert torch.equal(v, donor[k]), k
+        else:
+            assert torch.equal(v, before[k]), k
+    rep = m.load_backbone_pretrained(file_sd)                # bare dict, no prefix
+    assert rep['missing'] == [] and sorted(rep['unexpected']) == ['backbone.fc.weight', 'backbone.layer4.0.conv1.weight']
+    with pytest.raises(KeyError):
+        m.load_backbone_pretrained({'fc.weight': torch.zeros(2, 2)})
+    # a checkpoint without the optional num_batches_tracked buffers still loads strictly
+    m.load_state_dict({k: v for k, v in donor.items() if not k.endswith('num_batches_tracked')})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        c2 = tiny_config(3, 1)
+        c2['test_cfg']['rcnn']['mask_thr_binary'] = 0.3
+        FGN(3, 1, backbone=c2['backbone'], rpn_head=c2['rpn_head'], roi_head=c2['roi_head'], test_cfg=c2['test_cfg'])
+    assert any('mask_thr_binary' in str(x.message) for x in w)

@@ -106,3 +106,170 @@ def test_published_known_answers_of_the_upstream_box_code():
     scores = np.array([0.9, 0.9, 0.5, 0.5, 0.5, 0.4, 0.3], np.float32)
     dets, inds = O.nms(boxes, scores, 0.6)
     assert len(dets) == len(inds) == 3 and inds.tolist() == [0, 3, 4]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's own detector file (fgn.py) - tests/golden/make_golden_fgn.py
+# ---------------------------------------------------------------------------------------------------
+from _glue import assert_results_equal, glue_expected, glue_inputs as _glue_inputs  # noqa: E402
+
+
+def test_fgn_glue_matches_reference(golden_dir):
+    """modify_input / get_img_metas / the packing loop of simple_test against fgn.py itself (fgn.py:79-123, 187-303)."""
+    z = _load(golden_dir, 'fgn_glue.npz')
+    ins = _glue_inputs()
+    B = ins['qry_img'].shape[0]
+    for pre in ('server__', 'other__'):
+        assert z[pre + 'wiring_ok'].all()
+        # the views the heads receive
+        assert z[pre + 'extract_shapes'].tolist() == [list(ins['qry_img'].shape),
+                                                      [B * 6] + list(ins['spp_imgs'].shape[-3:])]
+        assert np.allclose(z[pre + 'extract_sums'], [float(ins['qry_img'].double().sum()),
+                                                     float(ins['spp_imgs'].double().sum())])
+        assert np.array_equal(z[pre + 'roi_spp_bboxes'], O.modify_input(ins['spp_bboxes'], B))
+        assert np.array_equal(z[pre + 'roi_spp_isegmaps'], ins['spp_isegmaps'].reshape(-1, 1, 16, 16).numpy())
+        for i, m in enumerate(O.get_img_metas(ins['img_shape'])):
+            for k in ('img_shape', 'ori_shape', 'pad_shape', 'scale_factor'):
+                want = z[f'{pre}meta{i}__{k}']
+                assert m[k].dtype == want.dtype and np.array_equal(m[k], want)
+    # SERVER (the build's semantics): the caller's tensors are untouched, passthrough boxes stay YXYX
+    for k, v in ins.items():
+        if isinstance(v, list):
+            for i, t in enumerate(v):
+                assert np.array_equal(z[f'server__caller_after__{k}__{i}'], t.numpy())
+        else:
+            assert np.array_equal(z[f'server__caller_after__{k}'], v.numpy())
+    det = [z['server__head_det0'], z['server__head_det1']]
+    lab = [z['server__head_lab0'], z['server__head_lab1']]
+    seg = [z['server__head_seg0'], z['server__head_seg1']]
+    got = O.pack_results(det, lab, seg, **{k: ins[k] for k in (
+        'qry_bboxes', 'qry_cat_ids', 'qry_isegmaps', 'img_shape', 'qry_child_idx', 'cats_ids_to_sample_real',
+        'spp_insts_ids', 'idx')})
+    assert_results_equal(got, glue_expected(z))
+    # the 'OTHER' environment (no device copies): same results except that the caller's qry_bboxes list and
+    # spp_bboxes tensor were swapped in place, so the passthrough boxes come out XYXY (SURVEY 8b quirk)
+    other = glue_expected(z, 'other__')
+    for i, (o, s) in enumerate(zip(other, glue_expected(z))):
+        for k in s:
+            if k == 'qry_bboxes':
+                assert np.array_equal(o[k], s[k][:, [1, 0, 3, 2]])
+            elif k.endswith('_rle'):
+                assert o[k] == s[k]
+            else:
+                assert np.array_equal(o[k], s[k])
+        assert np.array_equal(z[f'other__caller_after__qry_bboxes__{i}'], ins['qry_bboxes'][i].numpy()[:, [1, 0, 3, 2]])
+    assert np.array_equal(z['other__caller_after__spp_bboxes'], ins['spp_bboxes'].numpy()[:, :, [1, 0, 3, 2]])
+
+
+# ---------------------------------------------------------------------------------------------------
+# independent second formulations of third-party semantics that no reference file can pin
+# ---------------------------------------------------------------------------------------------------
+def _roi_align_grid_sample(fmap, rois, P, scale, sampling_ratio, aligned):
+    """RoIAlign through torch.nn.functional.grid_sample: every sample point of every bin becomes one grid location
+    (align_corners=True: normalised -1 / +1 = pixel index 0 / size-1; padding 'border' = RoIAlign's clamping of
+    coordinates in [-1, 0] and [size-1, size]); points beyond [-1, size] contribute zero; bins are averaged."""
+    import torch.nn.functional as F
+    _, C, H, W = fmap.shape
+    out = torch.zeros(len(rois), C, P, P, dtype=torch.float64)
+    off = 0.5 if aligned else 0.0
+    for r, roi in enumerate(rois.astype(np.float64)):
+        b = int(roi[0])
+        x1, y1, x2, y2 = roi[1:] * scale - off
+        rw, rh = x2 - x1, y2 - y1
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / P))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / P))
+        ys = y1 + (np.arange(P * gh) + 0.5) * rh / (P * gh)          # bin p, sample i -> index p*g+i
+        xs = x1 + (np.arange(P * gw) + 0.5) * rw / (P * gw)
+        gy, gx = np.meshgrid(ys, xs, indexing='ij')
+        valid = (gy >= -1) & (gy <= H) & (gx >= -1) & (gx <= W)
+        grid = torch.from_numpy(np.stack([2 * gx / (W - 1) - 1, 2 * gy / (H - 1) - 1], -1))[None]
+        s = F.grid_sample(fmap[b:b + 1].double(), grid, mode='bilinear', padding_mode='border', align_corners=True)
+        s = s[0] * torch.from_numpy(valid)
+        out[r] = s.view(C, P, gh, P, gw).mean(dim=(2, 4))
+    return out
+
+
+def test_roi_align_against_grid_sample_formulation():
+    g = torch.Generator().manual_seed(3)
+    fmap = torch.randn(2, 5, 13, 17, generator=g)
+    rois = np.array([[0, 10.3, 20.7, 150.2, 140.9], [1, -30.0, -20.0, 90.0, 100.0], [0, 200.0, 150.0, 290.0, 230.0],
+                     [1, 40.0, 40.0, 41.0, 42.0], [0, 0.0, 0.0, 272.0, 208.0], [1, 5.5, 3.25, 300.0, 260.0]], np.float32)
+    worst = 0.0
+    for aligned, sr, scale in ((True, 2, 1 / 16), (True, 0, 1 / 16), (False, -1, 1 / 16), (False, 2, 1 / 16)):
+        a = O.roi_align(fmap, rois, 7, scale, sr, aligned).double()
+        b = _roi_align_grid_sample(fmap, rois, 7, scale, sr, aligned)
+        worst = max(worst, float((a - b).abs().max()))
+        assert torch.allclose(a, b, atol=2e-5), (aligned, sr, float((a - b).abs().max()))
+    print(f'roi_align vs grid_sample formulation: max abs diff {worst:.2e}')
+
+
+def test_rle_hand_derived_string_and_round_trip():
+    """COCO compressed RLE.  Hand-derived: a 23x2 mask with column-major runs [2, 40, 1, 3]; run 3 is delta-coded
+    against run 1 (3 - 40 = -37).  5-bit groups, continuation bit 0x20, +48:  2 -> '2';  40 = 8 + 1*32 -> 'X','1';
+    1 -> '1';  -37 = ...11011011b -> low group 27 (sign bit 0x10 set, rest -2 != -1: continue) 'k', next group
+    30 (rest -1: stop) 'N'."""
+    from fgn_amd import rle as R
+    flat = np.array([0] * 2 + [1] * 40 + [0] + [1] * 3, np.uint8)
+    mask = flat.reshape(2, 23).T                                     # column-major
+    assert O.rle_encode(mask) == {'size': [23, 2], 'counts': b'2X11kN'}
+    assert R.encode(mask) == {'size': [23, 2], 'counts': b'2X11kN'}
+    assert np.array_equal(R.decode({'size': [23, 2], 'counts': b'2X11kN'}), mask)
+    # round trips through the independently written decoder / vectorised encoder, incl. mask starting with 1,
+    # empty, full, long runs (multi-character counts) and negative deltas
+    rng = np.random.default_rng(11)
+    cases = [np.zeros((7, 5), np.uint8), np.ones((7, 5), np.uint8), (rng.random((64, 48)) > 0.5).astype(np.uint8),
+             (rng.random((300, 211)) > 0.97).astype(np.uint8), np.pad(np.ones((200, 300), np.uint8), 150)]
+    cases.append(1 - cases[3])
+    for m in cases:
+        e = O.rle_encode(m)
+        assert e == R.encode(m)
+        assert np.array_equal(R.decode(e), m)
+        assert O.rle_encode(R.decode(e)) == e
+
+
+def _nms_bruteforce(boxes, scores, thr):
+    """Greedy NMS from the full IoU matrix: box i (in stable score order) is kept iff no KEPT earlier box overlaps it
+    by more than thr.  fp32 IoU with the same expression as mmcv's CPU kernel."""
+    f = np.float32
+    b = boxes.astype(f)
+    area = ((b[:, 2] - b[:, 0]).astype(f) * (b[:, 3] - b[:, 1]).astype(f)).astype(f)
+    n = len(b)
+    iou = np.zeros((n, n), f)
+    for i in range(n):
+        for j in range(n):
+            w = max(f(0), f(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0])))
+            h = max(f(0), f(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1])))
+            inter = f(w * h)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                iou[i, j] = f(inter / f(f(area[i] + area[j]) - inter))
+    order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+    keep = []
+    for i in order:
+        if not any(iou[k, i] > f(thr) for k in keep):
+            keep.append(i)
+    return keep
+
+
+def test_nms_against_bruteforce_with_ties():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = 120
+        c = rng.random((n, 2)) * 60
+        wh = rng.random((n, 2)) * 30 + 2
+        boxes = np.concatenate([c, c + wh], 1).astype(np.float32)
+        boxes[n // 2:n // 2 + 10] = boxes[:10]                       # exact duplicates
+        boxes[-3:, 2:] = boxes[-3:, :2]                              # zero-area boxes (0/0 IoU with themselves)
+        scores = np.round(rng.random(n), 1 if trial % 2 else 3).astype(np.float32)   # many exact score ties
+        for thr in (0.5, 0.7):
+            dets, keep = O.nms(boxes, scores, thr)
+            assert keep.tolist() == _nms_bruteforce(boxes, scores, thr)
+            assert np.array_equal(dets[:, :4], boxes[keep]) and np.array_equal(dets[:, 4], scores[keep])
+    # class-aware variant: boxes of different classes never suppress each other
+    labels = rng.integers(0, 3, n)
+    dets, keep = O.batched_nms(boxes, scores, labels, 0.5)
+    per_class = sorted(sum([[int(np.flatnonzero(labels == c)[k]) for k in
+                             _nms_bruteforce(boxes[labels == c], scores[labels == c], 0.5)] for c in range(3)], []),
+                       key=lambda i: (-float(scores[i]), i))
+    assert keep.tolist() == per_class
