@@ -81,12 +81,16 @@ def parse_args():
                          '(frozen backbone, like the reference) so that AP against the synthetic ground truth is not '
                          '0 vs 0, then score HIP and the CPU oracle with those weights; 0 = skip')
     ap.add_argument('--trained-eval-episodes', type=int, default=3, help='episodes scored by both paths with the trained heads')
-    ap.add_argument('--inflight', type=int, default=1, help='episodes queued ahead of result packing per GPU')
-    ap.add_argument('--streams', type=int, default=1,
-                    help='caller streams the steps alternate between: with 2, the low-occupancy tail of one episode '
-                         '(selection kernels, 100-RoI mask head) runs beside the backbone of the next')
-    ap.add_argument('--graphs', action='store_true', help='replay one captured hipGraph per step instead of launching from Python '
-                    '(same GPU time; host enqueue 0.2-0.8 ms instead of 1.4-2.4 ms)')
+    ap.add_argument('--inflight', type=int, default=2, help='episodes queued ahead of result packing per GPU')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='caller streams the steps alternate between: with 2, the low-occupancy phases of one episode '
+                         '(selection kernels, small-grid launches, transforms) run beside the GEMMs of the next.  Measured '
+                         '(r03, cfg3): 1 stream / 1 in flight 6.13 ms, 2 / 2 with graphs 5.76 ms; without graphs the host '
+                         'cannot keep two streams fed (6.10 ms)')
+    ap.add_argument('--graphs', dest='graphs', action='store_true', default=None,
+                    help='replay one captured hipGraph per step instead of launching from Python (same kernels, same '
+                         'bytes; host enqueue 0.2-0.8 ms instead of ~2.9 ms).  Default: on')
+    ap.add_argument('--no-graphs', dest='graphs', action='store_false')
     ap.add_argument('--batch', type=int, default=1, help='episodes per step per GPU (the reference evaluates with '
                     'batch 4, fgn_test.py:49; cfg4 of BASELINE.json is 8 per GPU); default 1 = cfg3 as surveyed')
     ap.add_argument('--no-winograd', action='store_true', help='direct implicit-GEMM form for every 3x3 convolution')
@@ -99,10 +103,95 @@ def parse_args():
     return ap.parse_args()
 
 
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into the profiled process (and, with --pmc, initialises the GPU before
+    main()): starting a launcher from such a process is the exec-after-GPU-init hop this pool forbids."""
+    blob = ' '.join(os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'ROCPROFILER_REGISTER_LIBRARY'))
+    return 'rocprof' in blob.lower() or any(k.startswith('ROCPROF') for k in os.environ)
+
+
+# ---- host placement of the ranks: each rank pins itself to the cores next to its GPU BEFORE any GPU call -----------
+def _cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_local_cpus() -> list:
+    """Per HIP device (KFD topology order, filtered by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those hold plain
+    indices): the CPU list local to that GPU's PCIe root (sysfs ``local_cpulist`` of its DRM render node; NUMA node
+    beside it).  Empty list for a device whose locality the kernel does not report.  Pure sysfs reads: no HIP call."""
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    gpus = []
+    try:
+        nodes = sorted(os.listdir(base), key=int)
+    except (OSError, ValueError):
+        return []
+    for n in nodes:
+        try:
+            props = dict(line.split() for line in open(f'{base}/{n}/properties') if len(line.split()) == 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', 0)) <= 0:
+            continue
+        cpus, numa = [], -1
+        try:
+            dev = f"/sys/class/drm/renderD{int(props['drm_render_minor'])}/device"
+            cpus = _cpulist(open(dev + '/local_cpulist').read())
+            numa = int(open(dev + '/numa_node').read())
+        except (OSError, KeyError, ValueError):
+            pass
+        gpus.append(dict(kfd_node=int(n), cpus=cpus, numa=numa))
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v and all(t.strip().isdigit() for t in v.split(',')):
+            gpus = [gpus[int(t)] for t in v.split(',') if int(t) < len(gpus)]
+    return gpus
+
+
+def pin_rank(local_rank: int, local_world: int) -> dict:
+    """Restrict this rank to its share of the host: the cores local to GPU ``local_rank``, split evenly among the
+    ranks whose GPUs share those cores (all ranks of one socket see the same ``local_cpulist``); when the kernel
+    reports no locality, an even contiguous split of the cores this process may use.  Also sizes the intra-op thread
+    pools to the share (<= 8).  Called before torch touches the GPU."""
+    allowed = sorted(os.sched_getaffinity(0))
+    info = dict(policy='none', cpus=len(allowed))
+    if local_world <= 1 or os.environ.get('FGN_BENCH_NO_PIN'):
+        return info
+    gpus = gpu_local_cpus()
+    mine = None
+    if local_rank < len(gpus) and gpus[local_rank]['cpus']:
+        local = [c for c in gpus[local_rank]['cpus'] if c in set(allowed)]
+        sharers = [r for r in range(min(local_world, len(gpus))) if gpus[r]['cpus'] == gpus[local_rank]['cpus']]
+        if local and local_rank in sharers:
+            k, n = sharers.index(local_rank), len(sharers)
+            per = max(1, len(local) // n)
+            mine = local[k * per:(k + 1) * per] or local
+            info = dict(policy='gpu-local', numa=gpus[local_rank]['numa'], sharers=n)
+    if mine is None:
+        per = max(1, len(allowed) // local_world)
+        mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        info = dict(policy='even-split')
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        return dict(policy='failed', error=str(e), cpus=len(allowed))
+    info.update(cpus=len(mine), first_cpu=mine[0])
+    os.environ['OMP_NUM_THREADS'] = str(min(8, len(mine)))
+    return info
+
+
 def self_launch(args) -> int:
     """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as a child job.  This
     process has not initialised the GPU (no HIP call so far), and it never does: it waits for the child and
     returns its exit code."""
+    if under_profiler():
+        raise SystemExit('bench.py --gpus N under rocprofv3 would start the launcher from the profiled process; '
+                         'profile one rank: rocprofv3 ... -- python3 bench.py --gpus 1 ...')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -130,10 +219,13 @@ def main():
     if 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
-    import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    placement = pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))   # before any GPU call
+    import torch
+    if placement.get('policy') in ('gpu-local', 'even-split'):
+        torch.set_num_threads(min(8, placement['cpus']))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     # FGN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share cuda:0 and
@@ -161,7 +253,7 @@ def main():
     cfg = with_caps(fgn_r50_c4_config(shape['n_ways'], shape['k_shots']), rpn_max=RPN_MAX_PER_IMG.get(args.workload))
     sd = init_state_dict(cfg, 0)
     model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
-    model.use_graphs = args.graphs
+    model.use_graphs = True if args.graphs is None else bool(args.graphs)
     model.use_winograd = False if args.no_winograd else (args.winograd or True)
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);
@@ -249,7 +341,8 @@ def main():
     # setup (not a warm-up step): pack the weights for the device, fill the caching allocator's pools,
     # pin the host slots and let every kernel set its LDS attribute once
     prime = ops.ConvProfile()
-    run(2, prof=prime, prof_steps=(1,))   # also creates the first timing events (a one-time ~40 ms in HIP)
+    n_setup = 2 * len(ep_streams)         # every caller stream captures its hipGraph here, not in a warm-up / timed step
+    run(n_setup + 1, prof=prime, prof_steps=(n_setup,))   # also creates the first timing events (a one-time ~40 ms in HIP)
     # timing events for the instrumented steps are created here, outside the timed region (HIP grows
     # its event pool in bursts that cost tens of ms)
     prof_steps = sorted({args.steps // 3, (2 * args.steps) // 3}) if args.steps >= 40 else [args.steps // 2]
@@ -271,10 +364,22 @@ def main():
     n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_dt = [dt]
+    rank_info = [dict(rank=rank, **placement)]
     if world > 1:
-        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own wall time of the K steps and its host placement, gathered after the timed region;
+        # `value` uses the MAX over ranks
+        t = torch.zeros(world, device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_dt = [float(v) for v in t.cpu()]
+        dt = max(per_rank_dt)
+        try:
+            gathered_info = [None] * world
+            dist.all_gather_object(gathered_info, dict(rank=rank, **placement))
+            rank_info = gathered_info
+        except Exception as e:       # diagnostics must never cost the bench line
+            rank_info = [dict(rank=rank, **placement), {'gather_error': f'{type(e).__name__}: {e}'}]
     n_prof_steps = len(prof_steps)
 
     # ---- roofline of the dominant kernel, from the HIP events recorded live ----------------------------------
@@ -334,6 +439,14 @@ def main():
                        'h2d_in_step': not args.resident_inputs, 'h2d_bytes_per_step': h2d_bytes,
                        'gt_mask_rle_in_step': True, 'gt_masks_per_step': n_gt / args.steps,
                        'world_size_seen': world, 'collective_backend': backend if world > 1 else None,
+                       # read back from the process group, not from the command line
+                       'rccl_world_size': (dist.get_world_size() if (world > 1 and dist.get_backend() == 'nccl') else None),
+                       'process_group': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
+                                         if world > 1 else None),
+                       'per_rank_ms_per_step': {'min': round(min(per_rank_dt) / args.steps * 1e3, 3),
+                                                'max': round(max(per_rank_dt) / args.steps * 1e3, 3),
+                                                'all': [round(v / args.steps * 1e3, 3) for v in per_rank_dt]},
+                       'rank_placement': rank_info,
                        'caller_streams': args.streams, 'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
                        'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,

@@ -54,6 +54,11 @@ struct ConvParams {
     // the slabs in a fixed order (deterministic) and applies the epilogue.
     float* ws;
     int splits, kt_per_split;
+    // last-arriver reduce (LDS-DMA kernel): one zero-initialised int32 per output tile.  Every split of a tile publishes
+    // its partial tile to its slab with write-through stores and takes a ticket; the workgroup that draws the last
+    // ticket sums the slabs in slab order (the order splitk_epilogue_kernel uses: bit-identical results), applies the
+    // epilogue and returns the ticket to zero.  nullptr: the reduce runs as splitk_epilogue_kernel.
+    int32_t* tickets;
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
     // grouped GEMM (Winograd; 64x64 kernel, point-wise mode): rows [g*grp_rows, (g+1)*grp_rows) use the weight
     // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
@@ -382,6 +387,12 @@ __device__ __forceinline__ void lds_dma16(const i32x4& rs, unsigned lds_base, un
         : "v"(voff), "s"(lds_base), "s"(rs)
         : "memory");
 }
+// 16-byte store that writes through the XCD's L2 to device-coherent memory (sc1 = agent scope): how a workgroup publishes
+// a split-K partial tile that a workgroup on another XCD will read (the L2s of the eight XCDs are not coherent with each
+// other for plain stores; a release fence instead would write back the whole L2).
+__device__ __forceinline__ void store_wt16(float* ptr, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
 __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
     i32x4 r;
@@ -656,6 +667,63 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         constexpr int RPP = 256 / C4;                 // rows per pass
         const int c4 = t % C4, rr = t / C4;
         const int n = n0 + c4 * 4;
+        if (BM == 64 && BN == 64 && p.splits > 1 && p.tickets) {      // (only the 64x64 tile is ever split)
+            // ---- split-K with the reduce inside the launch (see ConvParams::tickets)
+            const size_t slab = (size_t)p.n_img * HoWo * p.Cout;
+            if (n < p.Cout) {
+                float* dst = p.ws + (size_t)blockIdx.y * slab;
+#pragma unroll
+                for (int k = 0; k < BM / RPP; ++k) {
+                    const int row = rr + RPP * k;
+                    const int m = m0 + row;
+                    if (m >= M) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
+                    store_wt16(dst + (size_t)m * p.Cout + n, f32x4{v.x, v.y, v.z, v.w});
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's slab stores are acknowledged
+            // flag word behind the C tile (a static __shared__ variable would push dynamic + static LDS past the
+            // 160 KB the launcher allows the function)
+            volatile int* const s_last = reinterpret_cast<volatile int*>(smem + BM * PITCH);
+            __syncthreads();                                        // ... and every thread's
+            if (t == 0) {
+                int32_t* tk = p.tickets + (tile_m * p.n_tiles_n + tile_n);
+                const int got = atomicAdd(tk, 1);
+                *s_last = got == p.splits - 1;
+                if (got == p.splits - 1) *tk = 0;                   // ready for the next launch
+            }
+            __syncthreads();
+            if (!*s_last) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale lines: the other slabs come from memory
+            if (n < p.Cout) {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll 2
+                for (int k = 0; k < BM / RPP; ++k) {
+                    const int m = m0 + rr + RPP * k;
+                    if (m >= M) continue;
+                    const size_t o = (size_t)m * p.Cout + n;
+                    float4 a = *reinterpret_cast<const float4*>(p.ws + o);
+                    for (int z = 1; z < p.splits; ++z) {
+                        const float4 b = *reinterpret_cast<const float4*>(p.ws + (size_t)z * slab + o);
+                        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    }
+                    // same operation order as splitk_epilogue_kernel: scale, shift, residual, ReLU
+                    if (p.scale) { a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w; }
+                    if (p.shift) { a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w; }
+                    if (p.residual) {
+                        const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+                        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+                    }
+                    if (p.relu) {
+                        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(p.y + o) = a;
+                }
+            }
+            return;
+        }
         if (n < p.Cout) {
             const bool raw = p.splits > 1;
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1028,6 +1096,8 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
             if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
         }
     }
+    // the in-launch reduce lives in the LDS-DMA kernel's 16-byte epilogue
+    if (p.in_scale || p.x_bytes == 0 || cin4 || (p.Cout & 3) != 0 || p.splits <= 1) p.tickets = nullptr;
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static unsigned long long lds_ok[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>), &lds_ok[0]);
@@ -1071,7 +1141,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     else
         FGN_LAUNCH_TIMED((conv_igemm_kernel<BM, BN, WM, WN, false, MW>), grid, dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.tickets) {
         const size_t total4 = (size_t)M_max * p.Cout / 4;
         const int eg = (int)std::min<size_t>((total4 + 255) / 256, 2048);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(eg), dim3(256), 0, stream, p);
@@ -1130,12 +1200,21 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
+// int32 tickets the in-launch split-K reduce of this layer needs (one per 64x64 output tile; 0: the layer is not split)
+extern "C" int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                         int pad, int tile_hint) {
+    if (fgn_conv2d_workspace_bytes(n_img, H, W, Cin, Cout, KH, KW, stride, pad, tile_hint) == 0) return 0;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const long long M = (long long)n_img * Ho * Wo;
+    return (int)(((M + 63) / 64) * cdiv(Cout, 64));
+}
+
 extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                                    const float* shift, const float* residual, const float* in_scale,
                                    const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                                    int cout_pad, int KH, int KW, int stride, int pad, int a_img_div,
                                    int relu, int tile_hint, float* splitk_ws, size_t splitk_ws_bytes,
-                                   hipStream_t stream) {
+                                   int32_t* splitk_tickets, hipStream_t stream) {
     if (!x || !w_packed || !y) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const bool cin4 = (Cin == 4);
@@ -1144,7 +1223,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (a_img_div < 1 || stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.in_scale = in_scale; p.n_img_dev = n_img_dev;
+    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.tickets = splitk_tickets;
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -1217,7 +1296,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
-    p.n_img_dev = nullptr;
+    p.n_img_dev = nullptr; p.tickets = nullptr;
     p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = Cin / BK;

@@ -163,46 +163,87 @@ extern "C" int fgn_winograd_output_f32(const float* Mo, float* y, const float* s
 //         [ 0   1  -3/2  -2   3/2  1 ]      (G, with thirds and fifteenths, is applied to the weights on the host in fp64)
 // Tile t = (img * ty + y) * tx + x covers outputs [4y, 4y+4) x [4x, 4x+4) and reads inputs [4y-1, 4y+5) x [4x-1, 4x+5).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 f4fma(float k, float4 a, float4 acc) {
-    return make_float4(fmaf(k, a.x, acc.x), fmaf(k, a.y, acc.y), fmaf(k, a.z, acc.z), fmaf(k, a.w, acc.w));
+// The F(4x4) transform kernels are templated on the channel vector width VEC of a thread (1, 2 or 4 floats): a thread owns
+// (tile, VEC channels), loads the 6x6 patch / the 36 products and stores 36 / 16 values.  Most layers of an episode
+// are small (70 k .. 800 k (tile, channel) elements): with 16-byte vectors they start 17 k .. 200 k threads on a chip
+// that holds 524 k, and the kernel is a chain of dependent memory round trips - latency-bound at 2 TB/s.  With one
+// channel per thread the same layer runs 4x the waves (a wave still moves 256 contiguous bytes per instruction) at a
+// quarter of the registers; 16-byte vectors remain for the launches that fill the chip anyway (batched AG-RPN maps).
+template <int V>
+struct VF {
+    typedef float type __attribute__((ext_vector_type(V)));
+};
+template <int V>
+using vf = typename VF<V>::type;
+
+template <int V>
+__device__ __forceinline__ vf<V> vfma(float k, vf<V> a, vf<V> acc) {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = fmaf(k, a[i], acc[i]);
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> vzero() {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = 0.f;
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> vrelu(vf<V> a) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) a[i] = fmaxf(a[i], 0.f);
+    return a;
 }
 // r = B^T d for one column / row of six
-__device__ __forceinline__ void wg4_bt(const float4 (&d)[6], float4 (&r)[6]) {
-    r[0] = f4add(f4fma(1.5f, f4sub(d[3], d[1]), f4fma(-2.f, d[2], d[0])), d[4]);
-    r[1] = f4add(f4fma(2.5f, d[3], f4fma(0.5f, d[2], f4sub(d[4], d[1]))), make_float4(0.f, 0.f, 0.f, 0.f));
-    r[2] = f4fma(0.5f, d[3], f4fma(-2.5f, d[2], f4add(d[1], d[4])));
-    r[3] = f4fma(2.f, f4sub(d[3], d[1]), f4sub(d[4], d[2]));
-    r[4] = f4fma(0.5f, f4sub(d[1], d[3]), f4sub(d[4], d[2]));
-    r[5] = f4add(f4fma(1.5f, f4sub(d[4], d[2]), f4fma(-2.f, d[3], d[1])), d[5]);
+template <int V>
+__device__ __forceinline__ void wg4_bt(const vf<V> (&d)[6], vf<V> (&r)[6]) {
+    r[0] = (vfma<V>(1.5f, d[3] - d[1], vfma<V>(-2.f, d[2], d[0]))) + d[4];
+    r[1] = vfma<V>(2.5f, d[3], vfma<V>(0.5f, d[2], d[4] - d[1]));
+    r[2] = vfma<V>(0.5f, d[3], vfma<V>(-2.5f, d[2], d[1] + d[4]));
+    r[3] = vfma<V>(2.f, d[3] - d[1], d[4] - d[2]);
+    r[4] = vfma<V>(0.5f, d[1] - d[3], d[4] - d[2]);
+    r[5] = (vfma<V>(1.5f, d[4] - d[2], vfma<V>(-2.f, d[3], d[1]))) + d[5];
 }
 // r = A^T m for one column / row of six -> four
-__device__ __forceinline__ void wg4_at(const float4 (&m)[6], float4 (&r)[4]) {
-    const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]);
-    r[0] = f4add(f4add(m[0], s12), f4add(m[3], m[4]));
-    r[1] = f4fma(-2.f, m[4], f4fma(0.5f, m[3], d12));
-    r[2] = f4fma(4.f, m[4], f4fma(0.25f, m[3], s12));
-    r[3] = f4add(f4fma(-8.f, m[4], f4fma(0.125f, m[3], d12)), m[5]);
+template <int V>
+__device__ __forceinline__ void wg4_at(const vf<V> (&m)[6], vf<V> (&r)[4]) {
+    const vf<V> s12 = m[1] + m[2], d12 = m[1] - m[2];
+    r[0] = (m[0] + s12) + (m[3] + m[4]);
+    r[1] = vfma<V>(-2.f, m[4], vfma<V>(0.5f, m[3], d12));
+    r[2] = vfma<V>(4.f, m[4], vfma<V>(0.25f, m[3], s12));
+    r[3] = (vfma<V>(-8.f, m[4], vfma<V>(0.125f, m[3], d12))) + m[5];
 }
 
-template <bool EAGER>
-__global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict__ x, const float4* __restrict__ in_scale,
-                                                        float4* __restrict__ V, const int32_t* __restrict__ n_img_dev,
-                                                        int n_img, int a_img_div, int H, int W, int C4, int ty, int tx,
+template <int V, bool EAGER>
+__global__ __launch_bounds__(256) void wg4_input_kernel(const float* __restrict__ x_, const float* __restrict__ in_scale_,
+                                                        float* __restrict__ V_, const int32_t* __restrict__ n_img_dev,
+                                                        int n_img, int a_img_div, int H, int W, int CV, int ty, int tx,
                                                         int t_pad, long long total) {
+    typedef vf<V> T;
+    const T* __restrict__ x = reinterpret_cast<const T*>(x_);
+    const T* __restrict__ in_scale = reinterpret_cast<const T*>(in_scale_);
+    T* __restrict__ Vo = reinterpret_cast<T*>(V_);
     if (n_img_dev) n_img = min(n_img, *n_img_dev);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const int t = (int)(i / C4);
+        const int c = (int)(i % CV);
+        const int t = (int)(i / CV);
         const int xx = t % tx;
         const int r = t / tx;
         const int yy = r % ty;
         const int img = r / ty;
         if (img >= n_img) break;
-        const float4* src = x + (size_t)(img / a_img_div) * H * W * C4 + c;
+        const T* src = x + (size_t)(img / a_img_div) * H * W * CV + c;
         const int iy0 = 4 * yy - 1, ix0 = 4 * xx - 1;
-        const float4 s = in_scale ? in_scale[(size_t)img * C4 + c] : make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 tt[6][6];
+        T s;
+        if (in_scale) s = in_scale[(size_t)img * CV + c];
+        else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] = 1.f;
+        }
+        T tt[6][6];
         if (EAGER) {
             // all 36 loads are issued before the first use (small layers are latency-bound: six dependent batches
             // of six loads cost six memory round trips)
@@ -213,15 +254,15 @@ __global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict
                 for (int b = 0; b < 6; ++b) {
                     const int ix = ix0 + b;
                     tt[a][b] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                                   ? src[((size_t)iy * W + ix) * C4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                                   ? src[((size_t)iy * W + ix) * CV] : vzero<V>();
                 }
             }
 #pragma unroll
             for (int b = 0; b < 6; ++b) {             // tt[.][b] = B^T (d * s)[.][b], in place
-                float4 d[6], rr[6];
+                T d[6], rr[6];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) d[a] = f4mul(tt[a][b], s);
-                wg4_bt(d, rr);
+                for (int a = 0; a < 6; ++a) d[a] = tt[a][b] * s;
+                wg4_bt<V>(d, rr);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) tt[a][b] = rr[a];
             }
@@ -229,24 +270,24 @@ __global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const int ix = ix0 + b;
-                float4 d[6], rr[6];
+                T d[6], rr[6];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const int iy = iy0 + a;
                     d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                               ? f4mul(src[((size_t)iy * W + ix) * C4], s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                               ? src[((size_t)iy * W + ix) * CV] * s : vzero<V>();
                 }
-                wg4_bt(d, rr);
+                wg4_bt<V>(d, rr);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) tt[a][b] = rr[a];
             }
         }
-        float4* dst = V + (size_t)t * C4 + c;
-        const size_t gs = (size_t)t_pad * C4;
+        T* dst = Vo + (size_t)t * CV + c;
+        const size_t gs = (size_t)t_pad * CV;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            float4 rr[6];
-            wg4_bt(tt[a], rr);                         // (B^T d) B, row a
+            T rr[6];
+            wg4_bt<V>(tt[a], rr);                      // (B^T d) B, row a
 #pragma unroll
             for (int b = 0; b < 6; ++b) dst[(a * 6 + b) * gs] = rr[b];
         }
@@ -254,55 +295,87 @@ __global__ __launch_bounds__(256) void wg4_input_kernel(const float4* __restrict
 }
 
 // Mo [36][t_pad][C] -> y [n_img, H, W, C] = A^T Mo A + shift (ReLU); outputs beyond H / W are dropped
-__global__ __launch_bounds__(256) void wg4_output_kernel(const float4* __restrict__ Mo, float4* __restrict__ y,
-                                                         const float4* __restrict__ shift,
+template <int V>
+__global__ __launch_bounds__(256) void wg4_output_kernel(const float* __restrict__ Mo_, float* __restrict__ y_,
+                                                         const float* __restrict__ shift_,
                                                          const int32_t* __restrict__ n_img_dev, int n_img, int H, int W,
-                                                         int C4, int ty, int tx, int t_pad, int relu, long long total) {
+                                                         int CV, int ty, int tx, int t_pad, int relu, long long total) {
+    typedef vf<V> T;
+    const T* __restrict__ Mo = reinterpret_cast<const T*>(Mo_);
+    const T* __restrict__ shift = reinterpret_cast<const T*>(shift_);
+    T* __restrict__ y = reinterpret_cast<T*>(y_);
     if (n_img_dev) n_img = min(n_img, *n_img_dev);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const int t = (int)(i / C4);
+        const int c = (int)(i % CV);
+        const int t = (int)(i / CV);
         const int xx = t % tx;
         const int r = t / tx;
         const int yy = r % ty;
         const int img = r / ty;
         if (img >= n_img) break;
-        const float4* src = Mo + (size_t)t * C4 + c;
-        const size_t gs = (size_t)t_pad * C4;
-        float4 mm[6][6];                               // all 36 loads in flight at once
+        const T* src = Mo + (size_t)t * CV + c;
+        const size_t gs = (size_t)t_pad * CV;
+        T mm[6][6];                                    // all 36 loads in flight at once
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b) mm[a][b] = src[(a * 6 + b) * gs];
-        float4 st[4][6];                               // st[i][b] = (A^T m)[i][b]
+        T st[4][6];                                    // st[i][b] = (A^T m)[i][b]
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            float4 m[6], rr[4];
+            T m[6], rr[4];
 #pragma unroll
             for (int a = 0; a < 6; ++a) m[a] = mm[a][b];
-            wg4_at(m, rr);
+            wg4_at<V>(m, rr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) st[k][b] = rr[k];
         }
-        const float4 sh = shift ? shift[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const T sh = shift ? shift[c] : vzero<V>();
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int oy = 4 * yy + a;
-            float4 rr[4];
-            wg4_at(st[a], rr);
+            T rr[4];
+            wg4_at<V>(st[a], rr);
             if (oy >= H) continue;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int ox = 4 * xx + b;
                 if (ox >= W) continue;
-                float4 v = f4add(rr[b], sh);
-                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                y[(((size_t)img * H + oy) * W + ox) * C4 + c] = v;
+                T v = rr[b] + sh;
+                if (relu) v = vrelu<V>(v);
+                y[(((size_t)img * H + oy) * W + ox) * CV + c] = v;
             }
         }
     }
 }
+
+// Channel vector width of a thread for `elems` = tiles * channels (tile, channel) pairs, and whether the input transform
+// issues its 36 loads up front.  Measured on MI355X at the cfg3 layer shapes (tools/wg4_ab.py, r03): loads up front wins
+// at every size and width (AG-RPN map 55 -> 36 us at 16-byte vectors, shared_head on 300 RoIs 36 -> 20, layer1 31 -> 14:
+// the column-by-column form is a chain of six dependent memory round trips); with it, 8-byte vectors are best or within
+// 1.5 us of the best at every layer of an episode (34.0 / 21.7 / 16.5 / 13.7 us on the four large ones, 6-7 us - the
+// floor of a launch whose every thread does one load and one store round trip - on the rest); 16-byte vectors are kept
+// for launches with several million elements (batched AG-RPN maps).  FGN_WG4_VEC / FGN_WG4_EAGER force a choice (tuning).
+static int wg4_vec(long long elems) {
+    static const int forced = getenv("FGN_WG4_VEC") ? atoi(getenv("FGN_WG4_VEC")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return elems >= (4ll << 20) ? 4 : 2;
+}
+static bool wg4_eager(long long threads) {
+    static const long long eager_thr = getenv("FGN_WG4_EAGER") ? atoll(getenv("FGN_WG4_EAGER")) : (1ll << 40);
+    return threads < eager_thr;
+}
+// vec * 10 + eager of the input transform / vec * 10 of the output transform for a layer (lets a profiler name the
+// kernel instance a launch uses)
+extern "C" int fgn_winograd4_variant(int tiles_total, int C, int is_output) {
+    const int v = wg4_vec((long long)tiles_total * C);
+    return v * 10 + ((!is_output && wg4_eager((long long)tiles_total * (C / v))) ? 1 : 0);
+}
+
+#define WG4_IN_LAUNCH(VV, EE)                                                                                          \
+    FGN_LAUNCH_TIMED((wg4_input_kernel<VV, EE>), dim3(grid), dim3(256), 0, stream, x, in_scale, V, n_img_dev, n_img,  \
+                     a_img_div, H, W, C / VV, ty, tx, t_pad, total)
 
 extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev,
                                        int n_img, int a_img_div, int H, int W, int C, int t_pad, hipStream_t stream) {
@@ -310,22 +383,25 @@ extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, fl
     if (n_img <= 0) return FGN_OK;
     const int ty = (H + 3) / 4, tx = (W + 3) / 4;
     if (C % 4 != 0 || a_img_div < 1 || H < 1 || W < 1 || (long long)n_img * ty * tx > t_pad) return FGN_ERR_SHAPE;
-    const long long total = (long long)n_img * ty * tx * (C / 4);
+    const int vec = wg4_vec((long long)n_img * ty * tx * C);
+    const long long total = (long long)n_img * ty * tx * (C / vec);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
-    // small (latency-bound) layers issue all 36 loads first; large (bandwidth-bound) ones load column by column at twice
-    // the occupancy (measured, tools/wg4_ab.py: 10.3 -> 8.6 us on layer3, 39 -> 45 us on the AG-RPN map)
-    static const int eager_thr = getenv("FGN_WG4_EAGER") ? atoi(getenv("FGN_WG4_EAGER")) : 64000;
-    if (total < (long long)eager_thr)
-        FGN_LAUNCH_TIMED(wg4_input_kernel<true>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
-                         reinterpret_cast<const float4*>(in_scale), reinterpret_cast<float4*>(V), n_img_dev, n_img,
-                         a_img_div, H, W, C / 4, ty, tx, t_pad, total);
-    else
-        FGN_LAUNCH_TIMED(wg4_input_kernel<false>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
-                         reinterpret_cast<const float4*>(in_scale), reinterpret_cast<float4*>(V), n_img_dev, n_img,
-                         a_img_div, H, W, C / 4, ty, tx, t_pad, total);
+    const bool eager = wg4_eager(total);
+    switch (vec * 10 + (eager ? 1 : 0)) {
+        case 11: WG4_IN_LAUNCH(1, true); break;
+        case 10: WG4_IN_LAUNCH(1, false); break;
+        case 21: WG4_IN_LAUNCH(2, true); break;
+        case 20: WG4_IN_LAUNCH(2, false); break;
+        case 41: WG4_IN_LAUNCH(4, true); break;
+        default: WG4_IN_LAUNCH(4, false); break;
+    }
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
+
+#define WG4_OUT_LAUNCH(VV)                                                                                             \
+    FGN_LAUNCH_TIMED((wg4_output_kernel<VV>), dim3(grid), dim3(256), 0, stream, Mo, y, shift, n_img_dev, n_img, H, W, \
+                     C / VV, ty, tx, t_pad, relu, total)
 
 extern "C" int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev,
                                         int n_img, int H, int W, int C, int t_pad, int relu, hipStream_t stream) {
@@ -333,11 +409,14 @@ extern "C" int fgn_winograd4_output_f32(const float* Mo, float* y, const float* 
     if (n_img <= 0) return FGN_OK;
     const int ty = (H + 3) / 4, tx = (W + 3) / 4;
     if (C % 4 != 0 || (long long)n_img * ty * tx > t_pad) return FGN_ERR_SHAPE;
-    const long long total = (long long)n_img * ty * tx * (C / 4);
+    const int vec = wg4_vec((long long)n_img * ty * tx * C);
+    const long long total = (long long)n_img * ty * tx * (C / vec);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
-    FGN_LAUNCH_TIMED(wg4_output_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(Mo),
-                     reinterpret_cast<float4*>(y), reinterpret_cast<const float4*>(shift), n_img_dev, n_img, H, W,
-                     C / 4, ty, tx, t_pad, relu, total);
+    switch (vec) {
+        case 1: WG4_OUT_LAUNCH(1); break;
+        case 2: WG4_OUT_LAUNCH(2); break;
+        default: WG4_OUT_LAUNCH(4); break;
+    }
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -22,28 +22,35 @@ from . import episodes
 from .fsiseg_eval import FSISEGEval
 
 
-def get_new_shape(h, w, target_size=800, max_size=1333):
-    """Short side -> target_size, long side capped at max_size, aspect ratio kept
-    (cp_utils/create_img_from_chars.py:250-267; integer truncation as there)."""
+def get_new_shape(h, w, target_size=800, max_size=1333, check_ar: bool = True):
+    """Short side -> target_size, long side = target_size * aspect ratio (truncated), capped at max_size with the
+    short side re-derived (cp_utils/create_img_from_chars.py:250-267).  Like the reference, raises AssertionError
+    when the truncations move the aspect ratio by more than 0.015 (tiny inputs).  Pinned by
+    tests/golden/data_side.npz (the reference's own function on 506 shapes)."""
     old = np.array([h, w], dtype=np.float64)
     new = np.array([h, w], dtype=np.int64)
-    long_i = int(np.argmax(old))
+    long_i = int(np.argmax(np.array([h, w])))
     ar = old[long_i] / old[1 - long_i]
     new[1 - long_i] = target_size
     new[long_i] = int(target_size * ar)
     if new[long_i] > max_size:
         new[long_i] = max_size
         new[1 - long_i] = int(max_size / ar)
+    if check_ar:
+        assert abs(old[0] / old[1] - new[0] / float(new[1])) <= 0.015, f'Old {old[0] / old[1]} New {new[0] / float(new[1])}'
     return new
 
 
 def ar_grouped_order(aspect_ratios, batch, target_size=800, max_size=1333, sub_sample_ratio=16, shuffle=True,
-                     seed=0):
-    """Aspect-ratio-grouped batching (base_fst.py:626-727): round width/height to one decimal, one group
-    per value, pad each group to a multiple of ``batch`` by re-drawing its own members, cut into chunks
-    of ``batch``, shuffle the chunks.  Returns (order [n_chunks*batch], group index per entry,
-    per-group (h, w) rounded to multiples of ``sub_sample_ratio``)."""
-    rnd = random.Random(seed)
+                     seed=0, rnd=None):
+    """Aspect-ratio-grouped batching (``BaseFewShotISEG.reshuffle``, base_fst.py:626-727): width/height rounded to
+    one decimal, one group per value; per-group target (h, w) = get_new_shape(100 / ar, 100) rounded to multiples of
+    ``sub_sample_ratio``; every group is padded to a multiple of ``batch`` by re-drawing its own members
+    (``random.choices``, whether or not ``shuffle``), shuffled, cut into chunks of ``batch``; the chunks are shuffled.
+    Returns (order [n_chunks*batch], group index per entry, per-group (h, w)).  The reference draws from the global
+    ``random`` module; here from ``rnd`` (default ``random.Random(seed)``) in the same call order, so
+    ``random.seed(s)`` there and ``seed=s`` here give the same order (tests/golden/data_side.npz)."""
+    rnd = random.Random(seed) if rnd is None else rnd
     ars = np.around(np.asarray(aspect_ratios, np.float64), decimals=1)
     uniq = sorted(np.unique(ars))
     hws = []
@@ -66,6 +73,90 @@ def ar_grouped_order(aspect_ratios, batch, target_size=800, max_size=1333, sub_s
     if shuffle:
         rnd.shuffle(chunks)
     return order[chunks].reshape(-1), groups[chunks].reshape(-1), hws
+
+
+# ---- support crop geometry (BaseFewShotISEG.get_support, base_fst.py:1043-1167) ------------------------------------
+def spp_offset_ratio(spp_fill_ratio: float) -> float:
+    """base_fst.py:264-265: 1 / (1 + 2 * offset) = fill ratio, rounded to two decimals (0.8 -> 0.12)."""
+    return float(np.around(1 / (2 * spp_fill_ratio) - 0.5, decimals=2))
+
+
+def cut_algorithm(lo: int, hi: int, offset: int, max_shape: int) -> np.ndarray:
+    """``BaseFewShotISEG.cut_algorithm`` (base_fst.py:991-998): cut window [lo - offset, hi + offset] clipped to
+    [0, max_shape] and the object's extent inside it -> int32 [cut_lo, box_lo, cut_hi, box_hi]."""
+    cut_lo = max(0, lo - offset)
+    return np.array([cut_lo, lo - cut_lo, min(hi + offset, max_shape), hi - cut_lo], dtype=np.int32)
+
+
+def get_crop(img: np.ndarray, ymin, xmin, ymax, xmax, h_offset, w_offset, crop_square=True, mode='reflect'):
+    """``BaseFewShotISEG.get_crop`` (base_fst.py:1000-1040; pinned by tests/golden/data_side.npz): the crop of an
+    instance with ``offset`` pixels of context on every side.  Context beyond the image border comes from np.pad of
+    the WHOLE image at its top/left (pad = the offsets; bottom/right one more when the padded extent is odd), in
+    ``mode`` ('reflect' for the image, 'constant' for the mask); with ``crop_square`` the shorter side's offset grows
+    until the window is square; without it the padding is constant zeros.  Zero offsets: only the parity padding.
+    img [H,W,C] -> (crop, box int32 YXYX of the instance inside the crop)."""
+    h, w = ymax - ymin, xmax - xmin
+    if h_offset == 0 and w_offset == 0:
+        pads = ((0, h % 2), (0, w % 2))
+        box = (0, 0, h, w)
+    else:
+        if crop_square:
+            eh, ew = h + 2 * h_offset, w + 2 * w_offset
+            eh, ew = eh + eh % 2, ew + ew % 2
+            if eh > ew:
+                w_offset += (eh - ew) // 2
+            elif ew > eh:
+                h_offset += (ew - eh) // 2
+        else:
+            mode = 'constant'
+        pads = ((h_offset, h_offset + (h + 2 * h_offset) % 2), (w_offset, w_offset + (w + 2 * w_offset) % 2))
+        box = (h_offset, w_offset, h_offset + h, w_offset + w)
+    padded = np.pad(img, [list(pads[0]), list(pads[1]), [0, 0]], mode=mode)
+    crop = padded[ymin:ymax + sum(pads[0]), xmin:xmax + sum(pads[1])]
+    return crop, np.array(box, dtype=np.int32).reshape(4)
+
+
+def _resize(img: np.ndarray, nh: int, nw: int, binary: bool) -> np.ndarray:
+    """imgaug ``Resize`` stand-in (third party, not pinned): bicubic like its default interpolation; a mask is
+    resized as float and re-thresholded at 0.5 (imgaug's handling of bool arrays)."""
+    import torch.nn.functional as F
+    t = torch.from_numpy(np.ascontiguousarray(img)).float()
+    t = t[None, None] if t.dim() == 2 else t.permute(2, 0, 1)[None]
+    t = F.interpolate(t, size=(nh, nw), mode='bicubic', align_corners=False)
+    if binary:
+        return (t[0, 0] > 0.5).numpy()
+    return t[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).numpy()
+
+
+def support_from_instance(img: np.ndarray, bbox_yxyx, isegmap: np.ndarray, spp_img_size: int,
+                          spp_fill_ratio: float = 0.8, crop_square: bool = True):
+    """One support sample as ``BaseFewShotISEG.get_support`` builds it (base_fst.py:1104-1155): integer box ->
+    offsets ``floor(extent * offset_ratio)`` -> ``get_crop`` (image: reflect context, mask: zeros) ->
+    ``iaa.Resize({'longer-side': S, 'shorter-side': 'keep-aspect-ratio'})`` -> ``iaa.CenterPadToFixedSize(S, S,
+    pad_mode='constant')`` (base_fst.py:478-482) with the box carried along.  The crop geometry is pinned by the
+    reference's golden; the two imgaug operators are third-party and restated (bicubic resize, shorter side =
+    round(S * short / long), centre padding with the odd pixel on the bottom / right).
+    img [H,W,3] uint8, isegmap [H,W] bool -> (crop [S,S,3] uint8, box float32 YXYX in crop pixels, mask [S,S] bool)."""
+    ymin, xmin, ymax, xmax = np.array(bbox_yxyx).astype(np.int32)
+    r = spp_offset_ratio(spp_fill_ratio)
+    w_off, h_off = int(np.floor((xmax - xmin) * r)), int(np.floor((ymax - ymin) * r))
+    crop, box = get_crop(img, ymin, xmin, ymax, xmax, h_off, w_off, crop_square=crop_square)
+    mcrop, _ = get_crop(isegmap[:, :, None], ymin, xmin, ymax, xmax, h_off, w_off, crop_square=crop_square,
+                        mode='constant')
+    ch, cw = crop.shape[:2]
+    S = int(spp_img_size)
+    if ch >= cw:
+        nh, nw = S, max(1, int(np.round(S * cw / ch)))
+    else:
+        nh, nw = max(1, int(np.round(S * ch / cw))), S
+    crop_r, mask_r = _resize(crop, nh, nw, False), _resize(mcrop[:, :, 0], nh, nw, True)
+    box_r = box.astype(np.float32) * np.array([nh / ch, nw / cw, nh / ch, nw / cw], np.float32)
+    top, left = (S - nh) // 2, (S - nw) // 2
+    out = np.zeros((S, S, 3), np.uint8)
+    out[top:top + nh, left:left + nw] = crop_r
+    m = np.zeros((S, S), bool)
+    m[top:top + nh, left:left + nw] = mask_r
+    return out, (box_r + np.array([top, left, top, left], np.float32)).astype(np.float32), m
 
 
 class SyntheticFewShotISEG(Dataset):
@@ -118,8 +209,9 @@ def write_chunked(results_iter, out_dir, chunk=1000):
 
 class ClutteredCharsFewShotISEG(Dataset):
     """MNISTISEG / OMNIISEG-shaped episodes (cfg1 / cfg2 of BASELINE.json) over the numpy cluttered-
-    character generator: the sample dict of base_fst.py:1248-1266, class-major supports cropped around
-    one instance each (fill ratio 0.8), per-episode category ids 0..N-1, images normalised with the
+    character generator: the sample dict of base_fst.py:1248-1266, class-major supports built from one
+    instance each with the reference's crop geometry (``support_from_instance``: offset ratio from fill ratio 0.8,
+    square reflect-padded crop, resize of the longer side, centre pad), per-episode category ids 0..N-1, images normalised with the
     dataset mean/std (datasets/mnistiseg/ParamsMNISTISEG.json:1-5, datasets/omniiseg/ParamsOMNIISEG.json:1-5).
     Character datasets are batched without aspect-ratio grouping (base_fst.py:611-624)."""
     PARAMS = {'MNISTISEG': dict(mean=(0.9531239867210388, 0.9524800777435303, 0.9531603455543518),
@@ -184,8 +276,8 @@ class ClutteredCharsFewShotISEG(Dataset):
             for p in pick:
                 j, o = self.inst[p]
                 src = self.images[j]
-                crop, nb, m = cc.crop_support(src['img'], src['bboxes'][o], src['isegmaps'][o],
-                                              self.spp_img_size, self.spp_fill_ratio)
+                crop, nb, m = support_from_instance(src['img'], src['bboxes'][o], src['isegmaps'][o],
+                                                    self.spp_img_size, self.spp_fill_ratio)
                 spp_imgs.append(self._norm(crop)); spp_boxes.append(nb); spp_masks.append(m); spp_ids.append(p)
         return {
             'idx': int(idx),

@@ -21,13 +21,15 @@ SIGNATURES = {
     'fgn_profile_next_launch': (_i, [_p, _p]),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
     'fgn_conv2d_kernel_id': (_i, [_i] * 14),
-    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
+    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p, _p]),
+    'fgn_conv2d_splitk_tickets': (_i, [_i] * 10),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_t_pad': (_i, [_i]),
     'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd4_variant': (_i, [_i, _i, _i]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
     'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_group_norm_workspace_bytes': (C.c_size_t, [_i] * 4),
@@ -79,7 +81,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

@@ -27,6 +27,13 @@ from . import lib as _lib
 #   flop_*      per image: direct-convolution FLOPs of the layer / MFMA FLOPs actually issued (0 for the transforms)
 PROFILE = None
 
+# Split-K reduce by the last-arriving workgroup inside the conv launch instead of a second kernel.  Built and parity-tested
+# (tests/test_hip_conv.py), measured and left OFF: on the cfg3 episode (26 split layers) the step takes 6.02-6.09 ms
+# with it against 5.88-5.98 ms with the separate reduce kernel (three alternating runs on one box, r03) - the separate
+# kernel reduces a layer with 2048 workgroups at once, the in-launch form leaves it to one workgroup per tile behind
+# write-through stores, a ticket and an acquire fence, on the tail of the conv kernel.
+SPLITK_IN_LAUNCH = os.environ.get('FGN_SPLITK_IN_LAUNCH', '0') != '0'
+
 _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
 
 
@@ -249,10 +256,15 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
                                             layer.pad, tile_hint)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
+    tickets = None
+    if ws_bytes and SPLITK_IN_LAUNCH:
+        # zero-initialised tickets of the in-launch split-K reduce (from the episode's zero arena when one is open)
+        tickets = zeros((L.fgn_conv2d_splitk_tickets(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
+                                                     layer.pad, tile_hint),), x.device, torch.int32)
     rc = L.fgn_conv2d_nhwc_f32(
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
-        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _stream())
+        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _ptr(tickets), _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         kid = L.fgn_conv2d_kernel_id(n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw, layer.stride,
@@ -389,9 +401,11 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
         # record; the MFMA work actually issued is (m+2)^2 products per m x m output tile instead of 9 m^2
         shape = (n_img, H, W, cin, layer.cout, 3, 1)
         common = dict(n_img=n_img, n_img_dev=n_img_dev, shape=shape)
-        kin, kout = ('wg4_input_kernel', 'wg4_output_kernel') if layer.m == 4 else ('wg_input_kernel', 'wg_output_kernel')
-        if layer.m == 4:     # the two template instances of the F(4x4) input transform (csrc/winograd.hip)
-            kin = 'wg4_input_kernel<true>' if n_img * tiles * (cin // 4) < 64000 else 'wg4_input_kernel<false>'
+        kin, kout = 'wg_input_kernel', 'wg_output_kernel'
+        if layer.m == 4:     # the template instances of the F(4x4) transforms (csrc/winograd.hip): <vector width, eager>
+            vi, vo = L.fgn_winograd4_variant(n_img * tiles, cin, 0), L.fgn_winograd4_variant(n_img * tiles, layer.cout, 1)
+            kin = 'wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false')
+            kout = 'wg4_output_kernel<%d>' % (vo // 10)
         prof.append(dict(kind='wg_in', kernel=kin, e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0,
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows

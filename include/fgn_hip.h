@@ -52,8 +52,11 @@ int fgn_profile_next_launch(void* start_event, void* stop_event);
  *   tile_hint 0 = auto, 1..4 = force a tile configuration, negative = no split-K,
  *   +100 = register-staged loader instead of LDS-DMA (tests)
  *   splitk_ws: optional workspace of fgn_conv2d_workspace_bytes() bytes; when given and the plain
- *   grid would under-fill the GPU, K is split over blockIdx.y into slabs that a second kernel
- *   sums in a fixed order (bit-reproducible) before the epilogue.  NULL = never split. */
+ *   grid would under-fill the GPU, K is split over blockIdx.y into partial-tile slabs that are
+ *   summed in slab order (bit-reproducible) before the epilogue.  NULL = never split.
+ *   splitk_tickets: optional, fgn_conv2d_splitk_tickets() int32 values, ALL ZERO on entry (and
+ *   zero again when the launch has run): the workgroup that publishes the last slab of an
+ *   output tile reduces it inside the same launch.  NULL = the reduce runs as a second kernel. */
 size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                   int pad, int tile_hint);
 /* Which kernel the dispatcher launches for a layer (tile*10 + mode; 41 = conv_igemm_dma_kernel<64,64,32,32,2,4,1>):
@@ -64,7 +67,10 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
                         const float* shift, const float* residual, const float* in_scale,
                         const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                         int cout_pad, int KH, int KW, int stride, int pad, int a_img_div, int relu,
-                        int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+                        int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, int32_t* splitk_tickets,
+                        void* stream);
+int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                              int tile_hint);
 
 /* Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 convolution (same call sites as
  * fgn_conv2d_nhwc_f32: fgn_ag_rpn_head.py:48 rpn_conv, fgn_roi_head.py:236 shared_head conv2):
@@ -89,6 +95,10 @@ int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, con
                             int a_img_div, int H, int W, int C, int t_pad, void* stream);
 int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                              int H, int W, int C, int t_pad, int relu, void* stream);
+/* Which instance of the F(4x4) transform kernels a layer with `tiles_total` tiles and C channels launches: the
+ * channel vector width of a thread (1, 2 or 4 floats) * 10 + 1 when the input transform issues all 36 loads up front.
+ * Informational (lets a profiler name the kernel of a launch); the transforms choose it themselves. */
+int fgn_winograd4_variant(int tiles_total, int C, int is_output);
 
 /* NCHW [n,3,H,W] -> NHWC4 [n,H,W,4] (input side of fgn.py:212,215) */
 int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, void* stream);

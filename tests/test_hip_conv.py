@@ -142,6 +142,38 @@ def test_split_k_is_reproducible_and_honours_the_device_count(shape):
         assert float((got[n - 3:] + 3.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('shape', [(1, 50, 84, 1024, 256, 1), (9, 7, 7, 1024, 512, 1), (9, 7, 7, 512, 512, 3),
+                                   (9, 16, 16, 1024, 256, 1), (1, 25, 42, 512, 1024, 1)])
+def test_split_k_reduce_inside_the_launch_equals_the_two_kernel_form(shape):
+    """The workgroup that publishes the last partial tile of an output tile reduces it inside the conv launch
+    (write-through slab stores, one ticket per tile, slabs summed in slab order): byte-identical to the separate reduce
+    kernel, on every one of 300 back-to-back launches that reuse the same slabs and tickets (layer shapes of the cfg3
+    episode that are split: layer3 1x1s on the query / support maps, the 9-RoI support shared head)."""
+    from fgn_amd import ops
+    n, h, w, cin, cout, k = shape
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    res = torch.randn(n, h, w, cout, generator=g).cuda()
+    layer = ops.pack_conv(wt, bias=torch.randn(cout, generator=g), pad=k // 2, relu=True).to('cuda')
+    L = ops._lib.load()
+    assert L.fgn_conv2d_splitk_tickets(n, h, w, cin, cout, k, k, 1, k // 2, 0) > 0, 'shape is not split: test is vacuous'
+    keep = ops.SPLITK_IN_LAUNCH
+    try:
+        ops.SPLITK_IN_LAUNCH = False
+        two = ops.conv2d(x, layer, residual=res).clone()
+        ops.SPLITK_IN_LAUNCH = True
+        for i in range(300):
+            got = ops.conv2d(x, layer, residual=res)
+            assert torch.equal(got, two), f'launch {i} differs from the two-kernel reduce'
+    finally:
+        ops.SPLITK_IN_LAUNCH = keep
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double(),
+                                                layer.shift.double().cpu(), padding=k // 2)
+                     + res.permute(0, 3, 1, 2).double().cpu()).float()
+    assert (two.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+
+
 def test_repeated_runs_are_bit_identical_at_full_occupancy():
     """Regression: a 1x1 conv with 1840 workgroups of the 64x64 kernel (4-5 per CU) gave, about once in
     40 launches, one wave a stale last k-slice of a K-tile: the loop barrier was signalled while that wave's

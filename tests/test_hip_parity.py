@@ -169,7 +169,7 @@ def test_input_shim_and_result_packing_match_reference_fgn_py(golden_dir):
     ins = glue_inputs()
     before = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in ins.items()}
     z = np.load(os.path.join(golden_dir, 'fgn_glue.npz'))
-    cfg = tiny_config(3, 2, width_div=8)
+    cfg = tiny_config(3, 2, width_div=2)
     model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
                 test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
     dev = torch.device('cuda', torch.cuda.current_device())

@@ -330,7 +330,9 @@ def test_cluttered_chars_dataset_contract():
     for i, p in enumerate(s['spp_insts_ids']):
         assert ds.inst_cat[p] == s['cats_ids_to_sample_real'][i // 2]
         side = max(s['spp_bboxes'][i][2] - s['spp_bboxes'][i][0], s['spp_bboxes'][i][3] - s['spp_bboxes'][i][1])
-        assert abs(side / 128 - 0.8) < 1e-3 and s['spp_isegmaps'][i].sum() > 0
+        # base_fst.py:264-265: offset ratio 0.12 for fill ratio 0.8 -> the longer side fills 1 / 1.24 of the crop
+        # (integer offsets / parity padding move it by a pixel or two of the source crop)
+        assert abs(side / 128 - 1 / 1.24) < 0.06 and s['spp_isegmaps'][i].sum() > 0
     assert ds[4]['qry_img'].equal(s['qry_img'])                         # deterministic
     b = collate([ds[0], ds[1], ds[2]])
     assert b['qry_img'].shape == (3, 3, 256, 256) and isinstance(b['qry_cat_ids_real'], list)
@@ -344,20 +346,72 @@ def test_cluttered_chars_dataset_contract():
         assert all(c in set(small.inst_cat.tolist()) for c in smp['cats_ids_to_sample_real'])
 
 
-def test_ar_grouped_batching():
-    """base_fst.py:626-727 and create_img_from_chars.py:250-267."""
-    from fgn_amd.fewshot_ds import ar_grouped_order, get_new_shape
-    assert get_new_shape(480, 640).tolist() == [800, 1066]
-    assert get_new_shape(375, 500).tolist() == [800, 1066]
-    assert get_new_shape(333, 1000).tolist() == [443, 1333]         # long side capped
-    assert get_new_shape(640, 480).tolist() == [1066, 800]
-    ars = [1.33, 1.5, 0.75, 1.34, 1.49, 1.3, 0.66, 1.0, 1.31]
-    order, groups, hws = ar_grouped_order(ars, batch=2, seed=1)
-    assert len(order) % 2 == 0 and set(order.tolist()) == set(range(len(ars)))
-    rounded = np.around(ars, 1)
-    for c in range(0, len(order), 2):            # every chunk holds one aspect-ratio group
-        assert rounded[order[c]] == rounded[order[c + 1]] and groups[c] == groups[c + 1]
-    assert (hws % 16 == 0).all() and hws.min() >= 800 - 8 and hws.max() <= 1344
+def _golden_data_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_data', os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), 'golden', 'make_golden_data.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)             # seeded input builders only: nothing reads /root/reference at import
+    return m
+
+
+def test_episode_geometry_matches_the_reference_data_side_goldens(golden_dir):
+    """tests/golden/data_side.npz = the reference's own ``get_new_shape`` (create_img_from_chars.py:250-267),
+    ``BaseFewShotISEG.cut_algorithm`` / ``get_crop`` (base_fst.py:991-1040) and the aspect-ratio-grouped branch of
+    ``reshuffle`` (base_fst.py:626-727), run by tests/golden/make_golden_data.py.  Bit-exact."""
+    from fgn_amd import fewshot_ds as F
+    G = _golden_data_module()
+    z = np.load(os.path.join(golden_dir, 'data_side.npz'))
+    n_assert = 0
+    for (h, w), want in zip(z['new_shape_hw'], z['new_shape_out']):
+        try:
+            got = F.get_new_shape(int(h), int(w))
+        except AssertionError:               # the reference asserts on the aspect-ratio drift, so does the build
+            got, n_assert = np.array([-1, -1]), n_assert + 1
+        assert np.array_equal(got, want), (h, w, got, want)
+    assert n_assert == int((z['new_shape_out'][:, 0] < 0).sum()) > 0
+    assert np.array_equal(np.stack([F.get_new_shape(h, w, 128, 256) for h, w in ((100, 100), (64, 200), (300, 100))]),
+                          z['new_shape_small'])
+    assert F.get_new_shape(480, 640).tolist() == [800, 1066] and F.get_new_shape(333, 1000).tolist() == [443, 1333]
+    assert np.array_equal(np.stack([F.cut_algorithm(*c) for c in G.cut_cases()]), z['cut_out'])
+    assert int(z['crop_n']) == len(G.crop_cases())
+    for i, (img, y0, x0, y1, x1, ho, wo, sq, mode) in enumerate(G.crop_cases()):
+        crop, box = F.get_crop(img, y0, x0, y1, x1, ho, wo, crop_square=sq, mode=mode)
+        mask, _ = F.get_crop(img[..., :1] > 127, y0, x0, y1, x1, ho, wo, crop_square=sq, mode='constant')
+        assert np.array_equal(crop, z[f'crop{i}_out']) and np.array_equal(box, z[f'crop{i}_box']), i
+        assert np.array_equal(mask, z[f'crop{i}_mask']) and mask.dtype == z[f'crop{i}_mask'].dtype, i
+    sizes = G.ar_sizes()
+    for tag in 'abc':
+        shuffle, batch, seed = (int(v) for v in z[f'ar_{tag}_cfg'])
+        order, groups, hws = F.ar_grouped_order([w / h for w, h in sizes], batch, shuffle=bool(shuffle), seed=seed)
+        assert np.array_equal(order, z[f'ar_{tag}_order']) and np.array_equal(groups, z[f'ar_{tag}_groups'])
+        assert np.array_equal(hws, z[f'ar_{tag}_hws'])
+        rounded = np.around([w / h for w, h in sizes], 1)
+        for c in range(0, len(order), batch):        # every chunk holds one aspect-ratio group
+            assert len(set(rounded[order[c:c + batch]].tolist())) == 1 and len(set(groups[c:c + batch].tolist())) == 1
+    assert F.spp_offset_ratio(0.8) == 0.12 and F.spp_offset_ratio(1.0) == 0.0 and F.spp_offset_ratio(0.5) == 0.5
+
+
+def test_support_from_instance_follows_get_support_geometry():
+    """``get_support`` (base_fst.py:1104-1155) on a synthetic instance: the golden-pinned crop, then the restated
+    imgaug resize (longer side -> S) and centre pad; the box travels with the pixels."""
+    from fgn_amd import fewshot_ds as F
+    img = np.full((60, 90, 3), 255, np.uint8)
+    mask = np.zeros((60, 90), bool)
+    img[20:40, 10:70] = (10, 200, 30)
+    mask[20:40, 10:70] = True
+    crop, box, m = F.support_from_instance(img, [20., 10., 40., 70.], mask, 64, 0.8)
+    assert crop.shape == (64, 64, 3) and m.shape == (64, 64) and box.dtype == np.float32
+    # offsets floor(20 * .12) = 2, floor(60 * .12) = 7 -> 74 wide; squared: 74 x 74 -> scale 64 / 74
+    sc = 64 / 74.0
+    assert np.allclose(box, [(2 + 25) * sc, 7 * sc, (2 + 25 + 20) * sc, 67 * sc], atol=1e-4)
+    y0, x0, y1, x1 = np.round(box).astype(int)
+    inner = m[y0 + 1:y1 - 1, x0 + 1:x1 - 1]
+    assert inner.all() and m.sum() <= (y1 - y0 + 2) * (x1 - x0 + 2)            # the mask fills its box, nothing outside
+    assert (np.abs(crop[y0 + 2:y1 - 2, x0 + 2:x1 - 2].astype(int) - [10, 200, 30]) <= 2).all()
+    # a tall instance at the image border: reflect context for the image, zeros for the mask, padding left / right
+    crop2, box2, m2 = F.support_from_instance(img, [0., 0., 60., 20.], np.ones((60, 90), bool), 32, 0.8, crop_square=False)
+    assert crop2.shape == (32, 32, 3) and (box2[2] - box2[0]) > (box2[3] - box2[1]) and not m2[:, :4].any()
 
 
 def test_resnet18_extension_config_weights_and_reference_style_dict():
