@@ -313,16 +313,27 @@ def main():
         return model.pack_results(dets, args.batch, qry_bboxes=e['qry_bboxes'], qry_cat_ids=e['qry_cat_ids'],
                                   qry_isegmaps=e['qry_isegmaps'], img_shape=e['img_shape'], idx=e['idx'])
 
-    def run(n_steps, prof=None, prof_steps=()):
+    def run(n_steps, prof=None, prof_steps=(), alone=None, alone_steps=()):
         """Software-pipelined: episode i+1 is queued before the results of episode i are packed,
-        so host-side result packing overlaps device work.  Every result is still delivered."""
+        so host-side result packing overlaps device work.  Every result is still delivered.
+        ``prof`` / ``prof_steps``: steps whose conv launches are event-stamped while the pipeline runs as usual;
+        ``alone`` / ``alone_steps``: steps that are event-stamped after the episodes in flight have been packed, so
+        their kernels share the GPU with nothing but their own side stream."""
         n_det = n_gt = 0
         pending = []
         last = None
         stamps = [] if os.environ.get('FGN_BENCH_STEPTIMES') else None
         for i in range(n_steps):
             t_a = time.perf_counter()
-            pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None))
+            if alone is not None and i in alone_steps:
+                while pending:
+                    last = finish(pending.pop(0))
+                    n_det += sum(len(r['dt_scores']) for r in last)
+                    n_gt += sum(len(r['qry_isegmaps_rle']) for r in last)
+                torch.cuda.synchronize()
+                pending.append(launch(i, alone))
+            else:
+                pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None))
             t_b = time.perf_counter()
             if len(pending) > args.inflight:
                 last = finish(pending.pop(0))
@@ -345,9 +356,18 @@ def main():
     run(n_setup + 1, prof=prime, prof_steps=(n_setup,))   # also creates the first timing events (a one-time ~40 ms in HIP)
     # timing events for the instrumented steps are created here, outside the timed region (HIP grows
     # its event pool in bursts that cost tens of ms)
-    prof_steps = sorted({args.steps // 3, (2 * args.steps) // 3}) if args.steps >= 40 else [args.steps // 2]
-    prof = ops.ConvProfile().reserve(len(prof_steps) * (2 * len(prime) + 16))
-    for ev in prof.pool:
+    # Two timed steps are instrumented.  The LAST one runs alone (the episodes in flight are packed first): its kernel
+    # durations are those of a kernel that has the GPU to itself and its own side stream - what `roofline` reports and
+    # what a rocprofv3 kernel trace (which serialises dispatches) shows.  One step in the middle is instrumented while
+    # two episodes overlap on the two caller streams, the way every other step runs: kernels of different episodes
+    # then share the CUs, each launch takes longer and the step takes less (`roofline.overlapped`).
+    alone_steps = [args.steps - 1]
+    prof_steps = [args.steps // 2] if args.steps >= 4 else []
+    if os.environ.get('FGN_BENCH_NO_ISOLATED'):      # tuning aid: what the isolated instrumented step costs
+        alone_steps = []
+    prof = ops.ConvProfile().reserve(2 * len(prime) + 16)            # overlapped step
+    prof_alone = ops.ConvProfile().reserve(2 * len(prime) + 16)      # isolated step -> roofline
+    for ev in prof.pool + prof_alone.pool:
         ev.record()
     run(args.warmup)
 
@@ -358,10 +378,9 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    # one of the timed steps (two from K = 40) has every convolution kernel launch stamp a start/stop HIP event pair
-    # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on), in the normal two-stream
-    # execution mode of every other step (= what a rocprofv3 kernel trace of this command sees)
-    n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps)
+    # in the instrumented steps every convolution kernel launch stamps a start/stop HIP event pair
+    # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on)
+    n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps, alone=prof_alone, alone_steps=alone_steps)
     barrier()
     dt = time.perf_counter() - t0
     per_rank_dt = [dt]
@@ -380,18 +399,22 @@ def main():
             rank_info = gathered_info
         except Exception as e:       # diagnostics must never cost the bench line
             rank_info = [dict(rank=rank, **placement), {'gather_error': f'{type(e).__name__}: {e}'}]
-    n_prof_steps = len(prof_steps)
+    n_prof_steps = 1
 
     # ---- roofline of the dominant kernel, from the HIP events recorded live ----------------------------------
-    by_kernel = {}
-    for rec in prof:
-        ms = rec['e0'].elapsed_time(rec['e1'])
-        n = rec['n_img'] if rec['n_img_dev'] is None else min(rec['n_img'], int(rec['n_img_dev'].item()))
-        k = by_kernel.setdefault(rec['kernel'], dict(ms=0.0, launches=0, issued=0.0, direct=0.0))
-        k['ms'] += ms
-        k['launches'] += 1
-        k['issued'] += rec['flop_issued'] * n
-        k['direct'] += rec['flop_direct'] * n
+    def per_kernel(records):
+        out = {}
+        for rec in records:
+            ms = rec['e0'].elapsed_time(rec['e1'])
+            n = rec['n_img'] if rec['n_img_dev'] is None else min(rec['n_img'], int(rec['n_img_dev'].item()))
+            k = out.setdefault(rec['kernel'], dict(ms=0.0, launches=0, issued=0.0, direct=0.0))
+            k['ms'] += ms
+            k['launches'] += 1
+            k['issued'] += rec['flop_issued'] * n
+            k['direct'] += rec['flop_direct'] * n
+        return out
+    by_kernel_overlapped = per_kernel(prof)
+    by_kernel = per_kernel(prof_alone) if len(prof_alone) else by_kernel_overlapped
     tot = dict(ms=sum(k['ms'] for k in by_kernel.values()), launches=sum(k['launches'] for k in by_kernel.values()),
                issued=sum(k['issued'] for k in by_kernel.values()), direct=sum(k['direct'] for k in by_kernel.values()))
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]['ms']) if by_kernel else 'none'
@@ -466,7 +489,21 @@ def main():
                          'share_of_conv_time': round(dom['ms'] / tot['ms'], 3) if tot['ms'] else None,
                          'profiled_steps': n_prof_steps,
                          'timing': 'start/stop HIP events stamped by each launch of the kernel itself (hipExtLaunchKernelGGL) on '
-                                   'its own stream, inside the timed region, in the normal two-stream execution mode',
+                                   'its own stream, in the last step of the timed region, which runs with no other episode '
+                                   'in flight (its own side stream beside it): the duration a rocprofv3 kernel trace reports',
+                         # the same kernel in a mid-run step, while two episodes overlap on the two caller streams (the
+                         # way the other steps run): launches share the CUs with another episode's kernels
+                         'overlapped': (lambda k: None if not k or not k['ms'] else {
+                             'avg_launch_us': round(k['ms'] * 1e3 / max(k['launches'], 1), 2),
+                             'achieved': round(tf(k['issued'], k['ms']), 2),
+                             'frac': round(tf(k['issued'], k['ms']) / PEAK_FP32_MFMA_TFLOPS, 4),
+                             'all_conv_ms_per_step': round(sum(v['ms'] for v in by_kernel_overlapped.values()), 3),
+                             'what': 'per-launch durations while another episode runs on the second caller stream: '
+                                     'not a kernel-quality figure'})(by_kernel_overlapped.get(dom_name)),
+                         # every MFMA FLOP issued in a step over the wall time of a step (all kernels, all gaps)
+                         'whole_step': {'issued_gflop': round(tot['issued'] / 1e9, 1),
+                                        'tflops': round(tot['issued'] / (dt / args.steps) / 1e12, 2),
+                                        'frac': round(tot['issued'] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
                          'all_conv_launches': {
                              'what': 'every convolution-family kernel of a step (implicit-GEMM kernels, Winograd transforms, '
                                      'split-K reduces)',
