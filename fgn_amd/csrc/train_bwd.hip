@@ -690,6 +690,38 @@ __global__ void adagrad_kernel(float* __restrict__ p, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small products the MFMA kernels do not take (an operand dimension that is not a multiple of 4 / 32: the 6-row fc
+// weight gradient, the data gradient through the 6-row fc and through the 75-channel AG-RPN head).  One thread per
+// output element, the reduction index walked in order (bit-reproducible), fp32 fma.  A few MFLOP each.
+//   trans_a = 0 :  C[M,N] = A[M,K]   * B[K,N]
+//   trans_a = 1 :  C[M,N] = A[K,M]^T * B[K,N]      (lda / ldb / ldc = row strides in floats)
+// ------------------------------------------------------------------------------------------------
+__global__ void gemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+                                  int N, int K, int lda, int ldb, int ldc, int trans_a) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    float acc = 0.f;
+    if (trans_a)
+        for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)k * lda + m], B[(size_t)k * ldb + n], acc);
+    else
+        for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)m * lda + k], B[(size_t)k * ldb + n], acc);
+    C[(size_t)m * ldc + n] = acc;
+}
+
+extern "C" int fgn_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                  int trans_a, hipStream_t stream) {
+    if (!A || !B || !C) return FGN_ERR_ARG;
+    if (M < 0 || N < 0 || K < 0 || ldb < N || ldc < N || lda < (trans_a ? M : K)) return FGN_ERR_SHAPE;
+    if (M == 0 || N == 0) return FGN_OK;
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A, B, C, M, N, K,
+                       lda, ldb, ldc, trans_a);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
 extern "C" int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr,
                                     float weight_decay, float eps, hipStream_t stream) {
     if (n > 0 && (!param || !grad || !state_sum)) return FGN_ERR_ARG;

@@ -41,7 +41,9 @@ SIGNATURES = {
     'fgn_scale_channels_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_support_kmean_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_gather_support_vectors_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p, _p]),
+    'fgn_relation_gn_head_f32': (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _f, _p, _p, _p]),
+    'fgn_relation_gn_head_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_gemm_small_f32': (_i, [_p, _p, _p] + [_i] * 7 + [_p]),
     'fgn_rpn_merge_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'fgn_rpn_proposals_scratch_bytes': (C.c_size_t, [_i, _i, _i]),
     'fgn_rpn_proposals_zeroed_bytes': (C.c_size_t, [_i]),
@@ -81,7 +83,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 

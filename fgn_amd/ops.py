@@ -586,9 +586,11 @@ def relation_gn_head(q: torch.Tensor, s: torch.Tensor, rois: torch.Tensor, gn_w,
             raise _lib.FgnHipError('relation_gn_head: rel_out must be [R*N,P,P,C]')
     cls = zeros((r * n_ways, 2), q.device)
     reg = zeros((r * n_ways, 4), q.device)
-    rc = _lib.load().fgn_relation_gn_head_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
-                                              _ptr(fc_b), _ptr(cls), _ptr(reg), _ptr(n_rois_dev), r, n_ways, c,
-                                              gn_groups, p, float(eps), _ptr(rel_out), _stream())
+    L = _lib.load()
+    scratch = torch.empty(L.fgn_relation_gn_head_scratch_bytes(r, n_ways, c), device=q.device, dtype=torch.uint8)
+    rc = L.fgn_relation_gn_head_f32(_ptr(q), _ptr(s), _ptr(rois), _ptr(gn_w), _ptr(gn_b), _ptr(fc_w),
+                                    _ptr(fc_b), _ptr(cls), _ptr(reg), _ptr(n_rois_dev), r, n_ways, c,
+                                    gn_groups, p, float(eps), _ptr(rel_out), _ptr(scratch), _stream())
     _lib.check(rc, 'fgn_relation_gn_head_f32')
     return cls, reg
 
@@ -1041,6 +1043,25 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(wsb, device=a.device, dtype=torch.uint8) if wsb else None
     rc = L.fgn_gemm_tn_f32(_ptr(a), _ptr(b), _ptr(out), r, m, n, _ptr(ws), _stream())
     _lib.check(rc, 'fgn_gemm_tn_f32')
+    return out
+
+
+def gemm_small(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False) -> torch.Tensor:
+    """a [M,K] (or [K,M] with ``trans_a``) x b [K,N] -> [M,N] on the one-thread-per-output kernel: the products whose
+    shapes the MFMA kernels do not take (a dimension that is not a multiple of 4 / 32).  Operands may be row-strided
+    2-D views (unit stride along the last dimension)."""
+    for t, nm in ((a, 'a'), (b, 'b')):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+            raise _lib.FgnHipError(f'gemm_small: {nm} must be a 2-D fp32 device tensor with unit inner stride')
+    k, m = (a.shape[0], a.shape[1]) if trans_a else (a.shape[1], a.shape[0])
+    if b.shape[0] != k:
+        raise _lib.FgnHipError('gemm_small: inner dimensions differ')
+    n = b.shape[1]
+    out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    lda = a.stride(0) if a.shape[0] > 1 else a.shape[1]
+    ldb = b.stride(0) if b.shape[0] > 1 else n
+    rc = _lib.load().fgn_gemm_small_f32(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, n, int(trans_a), _stream())
+    _lib.check(rc, 'fgn_gemm_small_f32')
     return out
 
 

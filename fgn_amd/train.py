@@ -18,8 +18,8 @@ trainable heads, the Adagrad update and the re-pack of the kernel layouts itself
     target gathers run there in numpy, the selected indices go back as small index tensors
   * backward: loss gradients, BatchNorm(train) / relation-GroupNorm / mask-logit backward, im2col, column sums, the
     weight-gradient GEMM (``fgn_gemm_tn_f32``, fp32 MFMA), Adagrad: ``csrc/train_bwd.hip``; data gradients: the forward
-    convolution kernel with transposed (1x1) / flipped (3x3) weights; rocBLAS only for the 6-row fc products and the
-    75-channel AG-RPN head
+    convolution kernel with transposed (1x1) / flipped (3x3) weights; the 6-row fc products and the 75-channel
+    AG-RPN head (shapes the MFMA kernels do not take) on ``fgn_gemm_small_f32`` - no rocBLAS call in the step
 """
 from __future__ import annotations
 
@@ -434,9 +434,11 @@ def _mask_head_taped(model, mf, vmask):
 # ------------------------------------------------------------------------------------------
 def _mm_tn(a2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     """a2 [rows, M], b2 [rows, K] -> a2^T b2 [M, K]: the weight-gradient product (reduction over the rows) on the
-    MFMA kernel ``fgn_gemm_tn_f32``; the 6-row fc gradient (M not a multiple of 4) goes through rocBLAS."""
-    if a2.shape[1] % 4 or b2.shape[1] % 4 or a2.shape[0] == 0:
-        return torch.matmul(a2.t(), b2)
+    MFMA kernel ``fgn_gemm_tn_f32``; the 6-row fc gradient (M not a multiple of 4) on ``fgn_gemm_small_f32``."""
+    if a2.shape[0] == 0:
+        return torch.zeros((a2.shape[1], b2.shape[1]), device=a2.device, dtype=torch.float32)
+    if a2.shape[1] % 4 or b2.shape[1] % 4:
+        return ops.gemm_small(a2.contiguous(), b2.contiguous(), trans_a=True)
     return ops.gemm_tn(a2.contiguous(), b2.contiguous())
 
 
@@ -445,7 +447,7 @@ def _dgrad_1x1(dy: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     kernel with the transposed weight (Cout is the reduction, a multiple of 32 for every trainable 1x1 layer)."""
     cout, cin = w2.shape
     if cout % 32:
-        return torch.matmul(dy.reshape(-1, cout), w2).view(tuple(dy.shape[:-1]) + (cin,))
+        return ops.gemm_small(dy.reshape(-1, cout).contiguous(), w2.contiguous()).view(tuple(dy.shape[:-1]) + (cin,))
     x = dy.contiguous().view(1, -1, 1, cout)
     return ops.conv2d(x, ops.pack_conv(w2.t().contiguous().view(cin, cout, 1, 1))).view(tuple(dy.shape[:-1]) + (cin,))
 
@@ -654,7 +656,7 @@ def _backward_rpn_stage(model, W: dict, tape: dict, grads: dict) -> None:
     grads['rpn_head.rpn_cls.weight'] = dwh[:A].reshape(W['rpn_head.rpn_cls.weight'].shape).contiguous()
     grads['rpn_head.rpn_reg.weight'] = dwh[A:].reshape(W['rpn_head.rpn_reg.weight'].shape).contiguous()
     grads['rpn_head.rpn_cls.bias'], grads['rpn_head.rpn_reg.bias'] = dbh[:A].contiguous(), dbh[A:].contiguous()
-    dpre = ops.relu_backward(torch.matmul(dH[:, :5 * A], wh), X.contiguous())  # through the ReLU of rpn_conv
+    dpre = ops.relu_backward(ops.gemm_small(dH[:, :5 * A], wh.contiguous()), X.contiguous())  # through the ReLU of rpn_conv
     # rpn_conv weight gradient: only the active pixels contribute; their 3x3 neighbourhoods of the guided map
     qf, vec = t['qry_fmap'], t['vec']                                        # [B,h,w,C], [B*N,C]
     Cin = qf.shape[-1]

@@ -155,7 +155,9 @@ int fgn_scale_channels_f32(const float* x, const float* v, float* out, int n_out
 int fgn_relation_gn_head_f32(const float* Q, const float* S, const float* rois, const float* gn_weight,
                              const float* gn_bias, const float* fc_weight, const float* fc_bias, float* cls_out,
                              float* reg_out, const int32_t* n_rois_dev, int n_rois, int n_ways, int C,
-                             int gn_groups, int roi_size, float eps, float* rel_out_debug, void* stream);
+                             int gn_groups, int roi_size, float eps, float* rel_out_debug, float* scratch, void* stream);
+/* scratch of fgn_relation_gn_head_f32: per (RoI, 256-channel chunk, class) partial fc products, summed in chunk order */
+size_t fgn_relation_gn_head_scratch_bytes(int n_rois, int n_ways, int C);
 
 /* AG-RPN merge: per-anchor arg-max over the N guided passes (fgn_ag_rpn_head.py:81-113) + sigmoid.
  * head [B*N,HW,head_channels]: channels [0,A) objectness, [A,5A) deltas. Outputs in (y,x,a) order. */
@@ -302,6 +304,12 @@ int fgn_im2col3x3_f32(const float* x, float* out, int n, int H, int W, int C, vo
  * MFMA; M % 4 == 0, N % 4 == 0; slabs of rows reduced in a fixed order.  workspace: fgn_gemm_tn_workspace_bytes() */
 size_t fgn_gemm_tn_workspace_bytes(int R, int M, int N);
 int fgn_gemm_tn_f32(const float* A, const float* B, float* C, int R, int M, int N, void* workspace, void* stream);
+
+/* Products too narrow for the MFMA kernels (a dimension that is not a multiple of 4 / 32): C[M,N] = A[M,K] B[K,N]
+ * (trans_a = 0) or A[K,M]^T B[K,N] (trans_a = 1), one thread per output element, reduction in index order.  Training
+ * only: the 6-row fc weight / data gradients and the 75-channel AG-RPN head (torch.matmul in round 2). */
+int fgn_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int trans_a, void* stream);
 
 /* torch.optim.Adagrad step (fgn_train_schedule.py:5-13): g += wd*p; state += g*g; p -= lr*g/(sqrt(state)+eps) */
 int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr, float weight_decay,

@@ -677,6 +677,23 @@ def test_step_without_positives_keeps_every_gradient_and_torch_optimizer_layout(
     assert torch.equal(fresh[name], t.W[name].cpu())   # the model's state dict is the trainer's
 
 
+def test_small_gemm_matches_fp64():
+    """``fgn_gemm_small_f32``: the three products of a training step whose shapes the MFMA kernels do not take (6-row fc
+    weight gradient, data gradient through the fc, the 75-channel AG-RPN head with a row-strided operand)."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for (m, k, n, trans, stride_pad) in ((6, 384, 1024, True, 0), (384, 6, 1024, False, 0), (190, 75, 1024, False, 1),
+                                         (1, 1, 5, False, 0), (7, 33, 3, True, 0)):
+        a_full = torch.randn((k, m + stride_pad) if trans else (m, k + stride_pad), generator=g).cuda()
+        a = a_full[:, :m] if trans else a_full[:, :k]
+        b = torch.randn(k, n, generator=g).cuda()
+        got = ops.gemm_small(a, b, trans_a=trans)
+        ref = ((a.t() if trans else a).double() @ b.double())
+        assert got.shape == (m, n)
+        assert (got.double() - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), 1.0) * max(k, 1) ** 0.5
+        assert torch.equal(got, ops.gemm_small(a, b, trans_a=trans))
+
+
 @pytest.mark.parametrize('R,M,N', [(6272, 1024, 512), (441, 512, 4608), (200, 1024, 9216), (1000, 76, 1024), (37, 8, 12),
                                    (300, 1024, 4), (5000, 4, 256), (33, 64, 64)])
 def test_weight_gradient_gemm_matches_fp64(R, M, N):
