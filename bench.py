@@ -81,15 +81,20 @@ def parse_args():
                          '(frozen backbone, like the reference) so that AP against the synthetic ground truth is not '
                          '0 vs 0, then score HIP and the CPU oracle with those weights; 0 = skip')
     ap.add_argument('--trained-eval-episodes', type=int, default=3, help='episodes scored by both paths with the trained heads')
-    ap.add_argument('--inflight', type=int, default=2, help='episodes queued ahead of result packing per GPU')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--inflight', type=int, default=None, help='episodes queued ahead of result packing per GPU '
+                    '(default: 2 with hipGraph replay, 1 without)')
+    ap.add_argument('--streams', type=int, default=None,
                     help='caller streams the steps alternate between: with 2, the low-occupancy phases of one episode '
                          '(selection kernels, small-grid launches, transforms) run beside the GEMMs of the next.  Measured '
                          '(r03, cfg3): 1 stream / 1 in flight 6.13 ms, 2 / 2 with graphs 5.76 ms; without graphs the host '
                          'cannot keep two streams fed (6.10 ms)')
     ap.add_argument('--graphs', dest='graphs', action='store_true', default=None,
                     help='replay one captured hipGraph per step instead of launching from Python (same kernels, same '
-                         'bytes; host enqueue 0.2-0.8 ms instead of ~2.9 ms).  Default: on')
+                         'bytes; host enqueue 0.2-0.8 ms instead of ~2.9 ms).  Default: on for batches of 1-2 episodes per '
+                         'step; larger batches launch eagerly on one stream (measured r03, cfg4 with 8 episodes per step: '
+                         'eager 202.8 img/s, graph replay 190 / 198 on one / two streams - a step is 40 ms of GPU work '
+                         'against 3 ms of launches, and a captured graph pins every intermediate of the step at its own '
+                         'address instead of reusing freed blocks)')
     ap.add_argument('--no-graphs', dest='graphs', action='store_false')
     ap.add_argument('--batch', type=int, default=1, help='episodes per step per GPU (the reference evaluates with '
                     'batch 4, fgn_test.py:49; cfg4 of BASELINE.json is 8 per GPU); default 1 = cfg3 as surveyed')
@@ -100,7 +105,14 @@ def parse_args():
                     help='not the headline: park the inputs in HBM before timing (no host->device copy in the step)')
     ap.add_argument('--cache-supports', action='store_true',
                     help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.graphs is None:
+        args.graphs = args.batch <= 2
+    if args.streams is None:
+        args.streams = 2 if args.graphs else 1
+    if args.inflight is None:
+        args.inflight = 2 if args.graphs else 1
+    return args
 
 
 def under_profiler() -> bool:
@@ -253,7 +265,7 @@ def main():
     cfg = with_caps(fgn_r50_c4_config(shape['n_ways'], shape['k_shots']), rpn_max=RPN_MAX_PER_IMG.get(args.workload))
     sd = init_state_dict(cfg, 0)
     model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
-    model.use_graphs = True if args.graphs is None else bool(args.graphs)
+    model.use_graphs = bool(args.graphs)
     model.use_winograd = False if args.no_winograd else (args.winograd or True)
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfgn_hip.so')
+LIB_PATH = os.environ.get('FGN_HIP_LIB') or os.path.join(_HERE, 'libfgn_hip.so')     # FGN_HIP_LIB: A/B builds (tools/)
 
 _p = C.c_void_p
 _i = C.c_int
