@@ -1071,7 +1071,16 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
     const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
     static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
     if (forced > 0) return std::max(1, std::min(forced, KT / 2));
-    if (blocks >= 512 || KT < 8) return 1;
+    // Measured on the point-wise layers of a cfg3 episode (tools/split_time.py, r03): a 16-deep K loop (Cin 512) never
+    // repays the slabs and the reduce launch (support layer2 conv1 22.3 us unsplit / 26.9 split 4, the 9-RoI shared
+    // head's conv3 14.1 / 15.2); with 32 K-tiles a split pays only below ~320 workgroups (query layer3 conv1, 264
+    // workgroups: 40.0 us unsplit, 36.0 split 3, 36.7 split 4; AG-RPN head conv, 394 workgroups: 41.1 unsplit, 43.7 split 3).
+    if (blocks >= 512 || KT < 32) return 1;
+    if (KT == 32) {
+        if (blocks >= 320) return 1;
+        const int s32 = std::min((int)((768 + blocks - 1) / blocks), 8);
+        return s32 < 2 ? 1 : s32;
+    }
     int s = (int)((1024 + blocks - 1) / blocks);
     s = std::min(s, KT / 4);
     s = std::min(s, 16);
