@@ -243,7 +243,8 @@ def main():
     # FGN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share cuda:0 and
     # the collectives go through gloo): it checks the multi-rank control flow, not the scaling
     backend = os.environ.get('FGN_BENCH_BACKEND', 'nccl')
-    dev_index = local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1)
+    n_vis = max(torch.cuda.device_count(), 1)      # (a launcher may restrict every rank to its own GPU)
+    dev_index = local_rank if (backend == 'nccl' and local_rank < n_vis) else local_rank % n_vis
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
@@ -338,12 +339,15 @@ def main():
         for i in range(n_steps):
             t_a = time.perf_counter()
             if alone is not None and i in alone_steps:
-                while pending:
+                while pending:                      # (nothing is pending when the isolated step is step 0)
                     last = finish(pending.pop(0))
                     n_det += sum(len(r['dt_scores']) for r in last)
                     n_gt += sum(len(r['qry_isegmaps_rle']) for r in last)
-                torch.cuda.synchronize()
                 pending.append(launch(i, alone))
+                # the following steps are queued at once (no host wait), but their compute waits on the GPU for this
+                # episode: its kernels share the chip with nothing but their own side stream
+                for st in ep_streams:
+                    (st if st is not None else torch.cuda.current_stream()).wait_event(pending[-1][1][0]['host_ready'])
             else:
                 pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None))
             t_b = time.perf_counter()
@@ -368,12 +372,13 @@ def main():
     run(n_setup + 1, prof=prime, prof_steps=(n_setup,))   # also creates the first timing events (a one-time ~40 ms in HIP)
     # timing events for the instrumented steps are created here, outside the timed region (HIP grows
     # its event pool in bursts that cost tens of ms)
-    # Two timed steps are instrumented.  The LAST one runs alone (the episodes in flight are packed first): its kernel
-    # durations are those of a kernel that has the GPU to itself and its own side stream - what `roofline` reports and
-    # what a rocprofv3 kernel trace (which serialises dispatches) shows.  One step in the middle is instrumented while
+    # Two timed steps are instrumented.  The FIRST one runs alone (the pipeline is empty after the warm-up barrier, and
+    # the compute of the following steps waits on the GPU for it): its kernel durations are those of a kernel that has
+    # the GPU to itself and its own side stream - what `roofline` reports and what a rocprofv3 kernel trace (which
+    # serialises dispatches) shows.  One step in the middle is instrumented while
     # two episodes overlap on the two caller streams, the way every other step runs: kernels of different episodes
     # then share the CUs, each launch takes longer and the step takes less (`roofline.overlapped`).
-    alone_steps = [args.steps - 1]
+    alone_steps = [0]
     prof_steps = [args.steps // 2] if args.steps >= 4 else []
     if os.environ.get('FGN_BENCH_NO_ISOLATED'):      # tuning aid: what the isolated instrumented step costs
         alone_steps = []
@@ -501,8 +506,9 @@ def main():
                          'share_of_conv_time': round(dom['ms'] / tot['ms'], 3) if tot['ms'] else None,
                          'profiled_steps': n_prof_steps,
                          'timing': 'start/stop HIP events stamped by each launch of the kernel itself (hipExtLaunchKernelGGL) on '
-                                   'its own stream, in the last step of the timed region, which runs with no other episode '
-                                   'in flight (its own side stream beside it): the duration a rocprofv3 kernel trace reports',
+                                   'its own stream, in the first step of the timed region, which runs with no other episode '
+                                   'beside it (its own side stream only; the next steps are queued behind it on the GPU): '
+                                   'the duration a rocprofv3 kernel trace reports',
                          # the same kernel in a mid-run step, while two episodes overlap on the two caller streams (the
                          # way the other steps run): launches share the CUs with another episode's kernels
                          'overlapped': (lambda k: None if not k or not k['ms'] else {
