@@ -336,6 +336,48 @@ def test_hip_graph_replay_is_identical():
     assert len(model._graphs) == 3
 
 
+def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager():
+    """bench.py's execution mode (round 3): hipGraph replay, steps alternating between two caller streams, two episodes
+    queued before the first is packed - one captured graph, one set of static buffers, one side / upload / copy stream
+    and one ring of pinned result slots per caller stream.  Twelve steps over five distinct episodes must give, step by
+    step, the bytes of a serial eager run (boxes, scores, labels, detection RLE, ground-truth RLE)."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+    eps = [make_batch(11 * q, 1, 3, 2, 160, 224, 64) for q in range(5)]
+    eps = [{k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in e.items()} for e in eps]
+    want = [model.simple_test(**e, rescale=True) for e in eps]
+    assert all(len(w[0]['dt_scores']) > 0 for w in want)
+    model.use_graphs = True
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pending, got = [], []
+
+    def finish(item):
+        e, dets = item
+        return model.pack_results(dets, 1, qry_isegmaps=e['qry_isegmaps'], img_shape=e['img_shape'])
+    for i in range(12):
+        e = eps[i % 5]
+        with torch.cuda.stream(streams[i % 2]):
+            dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'],
+                                       qry_isegmaps=e['qry_isegmaps'])
+        pending.append((e, dets))
+        if len(pending) > 2:
+            got.append(finish(pending.pop(0)))
+    while pending:
+        got.append(finish(pending.pop(0)))
+    assert len(model._graphs) == 2                                 # one graph per caller stream
+    for i, g in enumerate(got):
+        w = want[i % 5]
+        for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+            assert np.array_equal(w[0][key], g[0][key]), (i, key)
+        assert w[0]['dt_isegmaps_rle'] == g[0]['dt_isegmaps_rle'] and w[0]['qry_isegmaps_rle'] == g[0]['qry_isegmaps_rle'], i
+    assert all(not s_['busy'] for ring in model._pinned.values() for s_ in ring)
+
+
 def test_winograd_and_direct_paths_agree():
     """`use_winograd=False`, `use_roi_commute=False` (direct form for every 3x3, shared_head conv1 on the RoIs: the
     reference's formulation op for op) and the default path give the same detections within the tolerance of
