@@ -133,11 +133,11 @@ def _cpulist(text: str) -> list:
     return out
 
 
-def gpu_local_cpus() -> list:
+def gpu_local_cpus(sysfs: str = '/sys') -> list:
     """Per HIP device (KFD topology order, filtered by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those hold plain
     indices): the CPU list local to that GPU's PCIe root (sysfs ``local_cpulist`` of its DRM render node; NUMA node
     beside it).  Empty list for a device whose locality the kernel does not report.  Pure sysfs reads: no HIP call."""
-    base = '/sys/class/kfd/kfd/topology/nodes'
+    base = f'{sysfs}/class/kfd/kfd/topology/nodes'
     gpus = []
     try:
         nodes = sorted(os.listdir(base), key=int)
@@ -152,7 +152,7 @@ def gpu_local_cpus() -> list:
             continue
         cpus, numa = [], -1
         try:
-            dev = f"/sys/class/drm/renderD{int(props['drm_render_minor'])}/device"
+            dev = f"{sysfs}/class/drm/renderD{int(props['drm_render_minor'])}/device"
             cpus = _cpulist(open(dev + '/local_cpulist').read())
             numa = int(open(dev + '/numa_node').read())
         except (OSError, KeyError, ValueError):
@@ -165,7 +165,7 @@ def gpu_local_cpus() -> list:
     return gpus
 
 
-def pin_rank(local_rank: int, local_world: int) -> dict:
+def pin_rank(local_rank: int, local_world: int, sysfs: str = '/sys', apply: bool = True) -> dict:
     """Restrict this rank to its share of the host: the cores local to GPU ``local_rank``, split evenly among the
     ranks whose GPUs share those cores (all ranks of one socket see the same ``local_cpulist``); when the kernel
     reports no locality, an even contiguous split of the cores this process may use.  Also sizes the intra-op thread
@@ -174,7 +174,7 @@ def pin_rank(local_rank: int, local_world: int) -> dict:
     info = dict(policy='none', cpus=len(allowed))
     if local_world <= 1 or os.environ.get('FGN_BENCH_NO_PIN'):
         return info
-    gpus = gpu_local_cpus()
+    gpus = gpu_local_cpus(sysfs)
     mine = None
     if local_rank < len(gpus) and gpus[local_rank]['cpus']:
         local = [c for c in gpus[local_rank]['cpus'] if c in set(allowed)]
@@ -188,11 +188,14 @@ def pin_rank(local_rank: int, local_world: int) -> dict:
         per = max(1, len(allowed) // local_world)
         mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
         info = dict(policy='even-split')
+    info.update(cpus=len(mine), first_cpu=mine[0])
+    if not apply:                 # tests: report the choice without changing this process
+        info['cpu_list'] = mine
+        return info
     try:
         os.sched_setaffinity(0, mine)
     except OSError as e:
         return dict(policy='failed', error=str(e), cpus=len(allowed))
-    info.update(cpus=len(mine), first_cpu=mine[0])
     os.environ['OMP_NUM_THREADS'] = str(min(8, len(mine)))
     return info
 

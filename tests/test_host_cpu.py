@@ -522,3 +522,41 @@ def test_backbone_only_pretrained_checkpoint_loads_into_backbone_only(tmp_path):
         c2['test_cfg']['rcnn']['mask_thr_binary'] = 0.3
         FGN(3, 1, backbone=c2['backbone'], rpn_head=c2['rpn_head'], roi_head=c2['roi_head'], test_cfg=c2['test_cfg'])
     assert any('mask_thr_binary' in str(x.message) for x in w)
+
+
+def test_rank_placement_from_a_kfd_topology(tmp_path):
+    """bench.pin_rank: ranks are pinned to the cores local to their GPU (sysfs ``local_cpulist`` of the GPU's DRM render
+    node, found through the KFD topology), split evenly among the ranks whose GPUs share that list; a node without
+    locality information falls back to an even split of the allowed cores.  Fake sysfs tree: 2 CPU nodes + 4 GPUs."""
+    import os
+    import bench
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip('needs 4 cores')
+    half = len(allowed) // 2
+    lists = [allowed[:half], allowed[half:]]
+    fmt = lambda cpus: ','.join(str(c) for c in cpus)
+    nodes = tmp_path / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    for n in range(6):                                   # nodes 0, 1: CPUs (simd_count 0); 2..5: GPUs
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        gpu = n >= 2
+        (d / 'properties').write_text(f'cpu_cores_count {0 if gpu else 64}\nsimd_count {1024 if gpu else 0}\n'
+                                      f'drm_render_minor {126 + n if gpu else 0}\nname x\n')
+        if gpu:
+            dev = tmp_path / 'class' / 'drm' / f'renderD{126 + n}' / 'device'
+            dev.mkdir(parents=True)
+            (dev / 'local_cpulist').write_text(fmt(lists[(n - 2) // 2]) + '\n')
+            (dev / 'numa_node').write_text(f'{(n - 2) // 2}\n')
+    gpus = bench.gpu_local_cpus(str(tmp_path))
+    assert [g['numa'] for g in gpus] == [0, 0, 1, 1] and gpus[0]['cpus'] == lists[0] and gpus[3]['cpus'] == lists[1]
+    got = [bench.pin_rank(r, 4, sysfs=str(tmp_path), apply=False) for r in range(4)]
+    assert all(g['policy'] == 'gpu-local' and g['sharers'] == 2 for g in got)
+    sets = [set(g['cpu_list']) for g in got]
+    assert sets[0] | sets[1] <= set(lists[0]) and sets[2] | sets[3] <= set(lists[1])
+    assert not (sets[0] & sets[1]) and not (sets[2] & sets[3]) and all(len(s_) == half // 2 for s_ in sets)
+    # no topology at all -> even contiguous split of the allowed cores; one rank -> untouched
+    got = [bench.pin_rank(r, 4, sysfs=str(tmp_path / 'nothing'), apply=False) for r in range(4)]
+    assert all(g['policy'] == 'even-split' for g in got) and not (set(got[0]['cpu_list']) & set(got[1]['cpu_list']))
+    assert bench.pin_rank(0, 1, sysfs=str(tmp_path))['policy'] == 'none'
+    assert bench._cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
