@@ -148,8 +148,24 @@ def _choose(cand: np.ndarray, num: int, perm_fn) -> np.ndarray:
     """RandomSampler._sample_pos/_sample_neg + the ``unique()`` of BaseSampler.sample: at most ``num`` of ``cand``
     (ascending indices), drawn with the CPU permutation mmdet draws (my_random_sampler.py:58-59)."""
     if cand.size > num:
-        cand = np.sort(cand[perm_fn(cand.size)[:num].numpy()])
+        cand = np.sort(cand[_perm(perm_fn, cand.size)[:num].numpy()])
     return cand
+
+
+def _perm(perm_fn, n: int) -> torch.Tensor:
+    """``perm_fn(n)``; ``torch.randperm`` of more than 32768 elements on ONE intra-op thread.  torch fills the
+    identity permutation with ``at::parallel_for`` (grain 32768) before its sequential Fisher-Yates shuffle; on a
+    128-thread host waking the sleeping OpenMP pool for that fill costs 4.5-5 ms per call (0.19 ms on one thread,
+    tools/micro/randperm_probe.py) - six draws of ~60 000 anchors were 34 of the 43 ms of a ``forward_train`` call.
+    The permutation does not depend on the thread count (tests/test_host_cpu.py), so seed parity with mmdet holds."""
+    if perm_fn is torch.randperm and n > 32768 and torch.get_num_threads() > 1:
+        k = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return perm_fn(n)
+        finally:
+            torch.set_num_threads(k)
+    return perm_fn(n)
 
 
 def _sample(gt_inds: np.ndarray, num: int, pos_fraction: float, perm_fn):

@@ -560,3 +560,19 @@ def test_rank_placement_from_a_kfd_topology(tmp_path):
     assert all(g['policy'] == 'even-split' for g in got) and not (set(got[0]['cpu_list']) & set(got[1]['cpu_list']))
     assert bench.pin_rank(0, 1, sysfs=str(tmp_path))['policy'] == 'none'
     assert bench._cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_single_thread_randperm_draws_the_same_permutation():
+    """fgn_amd.train._perm runs large ``torch.randperm`` draws on one intra-op thread (the parallel identity fill costs
+    ms on a many-core host); the permutation - and with it seed parity with mmdet's RandomSampler - must not change."""
+    from fgn_amd.train import _perm
+    k = torch.get_num_threads()
+    for n in (100, 32768, 32769, 63000, 200000):
+        torch.manual_seed(n)
+        want = torch.randperm(n)
+        torch.manual_seed(n)
+        got = _perm(torch.randperm, n)
+        assert torch.equal(want, got), n
+    assert torch.get_num_threads() == k
+    g = torch.Generator().manual_seed(3)
+    assert _perm(lambda m: torch.randperm(m, generator=g), 5).numel() == 5        # any callable passes through
