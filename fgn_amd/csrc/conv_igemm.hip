@@ -841,6 +841,19 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
     // tile -> (m0, n0): XCD-contiguous runs of logical tiles (the grid is a multiple of 8), optional banded raster
     const int nq = total_tiles >> 3, nr = total_tiles & 7;
     auto coords = [&](int tile, int& m0, int& n0) -> bool {
+        if (p.band_nt < 0) {
+            // experiment (FGN_WG_POS_INNER=1, tools/gemm_time.py): the raster a GEMM with a FUSED Winograd output
+            // transform would be forced into - one workgroup per (row block, channel block) walking the 36 tile
+            // positions; the grid is band_mt * n_tiles_n workgroups and `tile` advances by the grid, i.e. by one position
+            const int per_pos = p.band_mt * p.n_tiles_n;
+            const int g = tile / per_pos, rest = tile - g * per_pos;
+            const int mi = rest / p.n_tiles_n;
+            m0 = (g * p.band_mt + mi) * BM;
+            n0 = (rest - mi * p.n_tiles_n) * BN;
+            if (m0 >= M) return false;
+            if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
+            return true;
+        }
         const int xcd = tile & 7, idx = tile >> 3;
         const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
         int tile_m = bid / p.n_tiles_n;
@@ -1135,6 +1148,15 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
             if (attr == hipSuccess) attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel<true>), &pk16_ok);
             if (attr != hipSuccess) return (int)attr;
             const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float);
+            static const int pos_inner = getenv("FGN_WG_POS_INNER") ? atoi(getenv("FGN_WG_POS_INNER")) : 0;
+            if (pos_inner && p.grp_rows) {
+                p.band_nt = -1;
+                p.band_mt = p.grp_rows / 64;
+                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<true>, dim3(p.band_mt * p.n_tiles_n), dim3(256), plds, stream, p,
+                                 (int)grid.x);
+                FGN_LAUNCH_CHECK();
+                return FGN_OK;
+            }
             if (m16)
                 FGN_LAUNCH_TIMED(conv_pw_persist_kernel<true>, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
             else
