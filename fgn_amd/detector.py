@@ -914,7 +914,9 @@ class FGN(torch.nn.Module):
                         rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
             ring.append(slot)
         if n_gt > slot['gt_cap']:
-            cap = max(8, 2 * n_gt)
+            # generous from the start: growing a slot is a pinned allocation (~5 ms of host time) in the middle of a
+            # pipelined run - with caps of 2 x the first count seen, slots kept growing for dozens of steps
+            cap = max(64, 2 * n_gt)
             slot.update(gt_cap=cap, gt_rle=pin(cap, ops.RLE_BYTE_CAP, dtype=torch.uint8),
                         gt_len=pin(cap, dtype=torch.int32), gt_ovf=pin(cap, dtype=torch.int32))
         slot['busy'] = True
