@@ -152,6 +152,56 @@ class _Bottleneck:
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
 
 
+class _Pair:
+    """Two NHWC tensors (query map, support maps) that live in ONE [M_q + M_s, C] buffer, so that the layers whose
+    work does not depend on the spatial structure (1x1 / stride 1 convolutions, the grouped Winograd GEMM) run as one
+    launch over all rows."""
+
+    def __init__(self, q_shape, s_shape, c, device):
+        self.mq = q_shape[0] * q_shape[1] * q_shape[2]
+        self.ms = s_shape[0] * s_shape[1] * s_shape[2]
+        self.buf = torch.empty((self.mq + self.ms, c), device=device, dtype=torch.float32)
+        self.q = self.buf[:self.mq].view(*q_shape, c)
+        self.s = self.buf[self.mq:].view(*s_shape, c)
+
+    @property
+    def flat(self):
+        return self.buf.view(1, self.mq + self.ms, 1, self.buf.shape[1])
+
+    def like(self, c, q_hw=None, s_hw=None):
+        qs = self.q.shape[:3] if q_hw is None else (self.q.shape[0],) + tuple(q_hw)
+        ss = self.s.shape[:3] if s_hw is None else (self.s.shape[0],) + tuple(s_hw)
+        return _Pair(tuple(qs), tuple(ss), c, self.buf.device)
+
+
+def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
+    """``_Bottleneck.__call__`` on a query / support pair: merged launches for conv1, conv3 (+ residual), the
+    stride-1 downsample and the Winograd GEMM; per-branch launches for the strided convolutions and the transforms."""
+    stride = blk.conv2.stride
+    out_hw = lambda t: ((t.shape[1] - 1) // stride + 1, (t.shape[2] - 1) // stride + 1)
+    if blk.down is None:
+        idt = x
+    else:
+        idt = x.like(blk.down.cout, out_hw(x.q), out_hw(x.s))
+        if blk.down.stride == 1:
+            ops.conv2d(x.flat, blk.down, out=idt.flat)
+        else:
+            ops.conv2d(x.q, blk.down, out=idt.q)
+            ops.conv2d(x.s, blk.down, out=idt.s)
+    y1 = x.like(blk.conv1.cout)
+    ops.conv2d(x.flat, blk.conv1, out=y1.flat)
+    y2 = x.like(blk.conv2.cout, out_hw(x.q), out_hw(x.s))
+    wg = blk.conv2_wg
+    if wg is not None and ops.winograd_pays(1, (y1.mq + y1.ms) // 64 + 1, 64, wg.cin, wg.cout, wg.m):
+        ops.conv3x3_winograd_multi([y1.q, y1.s], wg, [y2.q, y2.s])
+    else:
+        ops.conv2d(y1.q, blk.conv2, out=y2.q)
+        ops.conv2d(y1.s, blk.conv2, out=y2.s)
+    out = y2.like(blk.conv3.cout)
+    ops.conv2d(y2.flat, blk.conv3, residual=idt.flat, out=out.flat)
+    return out
+
+
 class _BasicBlock:
     """mmdet BasicBlock of the ResNet-18 extension (config.fgn_r18_c4_config): conv3x3(stride)+BN+ReLU, conv3x3+BN,
     + identity, ReLU.  conv1 takes the Winograd form when it has stride 1 and pays; conv2 carries the residual in
@@ -308,6 +358,13 @@ class FGN(torch.nn.Module):
         self.use_graphs = False                   # replay a captured hipGraph per input geometry
         self._use_winograd = ops.WINOGRAD_M       # Winograd form of the 3x3 / stride 1 convs: 4 = F(4x4,3x3), 2 = F(2x2,3x3), 0 = direct
         self.use_roi_commute = True               # shared_head conv1 on the feature map, RoIAlign after (set before first use)
+        # query + support maps through SHARED backbone launches (1x1 / stride 1 convolutions and the grouped Winograd GEMM
+        # over all rows of both; frozen-BN bottleneck backbones): half the launches of the two passes, no support-only
+        # split-K.  Round 2 measured this 5 % slower with one episode in flight (the support stream filled the query
+        # branch's idle phases); with two episodes in flight the other episode does that, and it is 5 % faster
+        # (same-box A/B, r03: 6.09 -> 5.77 ms).  Results differ from the separate passes in the last bits only
+        # (split-K plans and Winograd-vs-direct choices depend on the row count).
+        self.use_merged_backbone = True
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
@@ -543,6 +600,25 @@ class FGN(torch.nn.Module):
                 x = blk(x)
         return x
 
+    def extract_feat_pair(self, qry_nchw: torch.Tensor, spp_nchw: torch.Tensor):
+        """Both backbone passes of an episode (fgn.py:212-215) through SHARED launches wherever a layer does not look at
+        the spatial structure (``use_merged_backbone``; frozen-BN bottleneck backbones only)."""
+        P = self._P
+        outs = []
+        for img in (qry_nchw, spp_nchw):
+            x = ops.nchw3_to_nhwc4(img.contiguous())
+            for conv, _ in P['stem']:
+                x = ops.conv2d(x, conv)
+            outs.append(x)
+        hw = lambda t: ((t.shape[1] - 1) // 2 + 1, (t.shape[2] - 1) // 2 + 1)
+        x = _Pair((outs[0].shape[0],) + hw(outs[0]), (outs[1].shape[0],) + hw(outs[1]), outs[0].shape[3], outs[0].device)
+        ops.maxpool3x3s2(outs[0], out=x.q)
+        ops.maxpool3x3s2(outs[1], out=x.s)
+        for stage in P['stages']:
+            for blk in stage:
+                x = _bottleneck_pair(blk, x)
+        return x.q, x.s
+
     def _shared_head(self, x, n_img_dev=None, y1=None):
         for bi, blk in enumerate(self._P['shared']):
             x = blk(x, n_img_dev, y1=y1 if bi == 0 else None)
@@ -607,7 +683,7 @@ class FGN(torch.nn.Module):
                                  idx=idx)
 
     # --- support branch (fgn.py:212-215 backbone pass; fgn_ag_rpn_head.py:38-41; fgn_roi_head.py:419-449) ---
-    def _support_front(self, spp_imgs, spp_bboxes, spp_isegmaps, B, dev, stream) -> dict:
+    def _support_front(self, spp_imgs, spp_bboxes, spp_isegmaps, B, dev, stream, defer_backbone: bool = False) -> dict:
         """modify_input for the supports (fgn.py:79-108: H2D, YXYX -> XYXY on private copies), their
         backbone pass and the AG-RPN class vectors."""
         N, K = self.n_ways, self.k_shots
@@ -616,9 +692,14 @@ class FGN(torch.nn.Module):
         spp_xyxy = torch.stack((b[:, 1], b[:, 0], b[:, 3], b[:, 2]), 1)      # no host-built index tensor: graph-capturable
         m = spp_isegmaps.to(dev, non_blocking=True).reshape(B * N * K, *spp_isegmaps.shape[-2:])
         spp_masks = (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
-        spp_fmaps = self.extract_feat(spp)                                      # [B*N*K,s,s,C]
-        vec = ops.support_class_vectors(spp_fmaps, None, B * N, K)              # [B*N,C]
-        return dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp_fmaps=spp_fmaps, vec=vec)
+        sc = dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp=spp)
+        if not defer_backbone:
+            self._support_vectors(sc, self.extract_feat(spp))                   # [B*N*K,s,s,C]
+        return sc
+
+    def _support_vectors(self, sc: dict, spp_fmaps) -> None:
+        sc['spp_fmaps'] = spp_fmaps
+        sc['vec'] = ops.support_class_vectors(spp_fmaps, None, sc['B'] * self.n_ways, self.k_shots)   # [B*N,C]
 
     def _support_back(self, sc: dict, B, dev, shared=None) -> None:
         """count_spp (fgn_roi_head.py:419-449) and the support half of the relation conv.  ``shared``: the shared-head
@@ -742,7 +823,7 @@ class FGN(torch.nn.Module):
         main = torch.cuda.current_stream()
         dev = torch.device('cuda', torch.cuda.current_device())
         hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
-        key = (main.cuda_stream, dev.index, hw, support_code is not None) + \
+        key = (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone)) + \
             tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
         ge = self._graphs.get(key)
         if ge is None:
@@ -781,8 +862,22 @@ class FGN(torch.nn.Module):
             side = self._stream_for('side', main)              # one side stream per caller stream
         else:
             side = main
+        merged = (not cached) and self.use_merged_backbone and self.cfg['backbone'].get('norm', 'BN') == 'BN' and \
+            self.cfg['backbone'].get('block', 'bottleneck') == 'bottleneck'
+        qry_fmap = None
         if cached:
             sc = support_code
+        elif merged:
+            sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, main, defer_backbone=True)
+            qry_fmap, spp_fmaps = self.extract_feat_pair(qry, sc['spp'])
+            backbone_done = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(backbone_done)
+                self._support_vectors(sc, spp_fmaps)
+                vec_ready = side.record_event()
+                self._support_back(sc, B, dev)
+            if side is not main and not torch.cuda.is_current_stream_capturing():
+                spp_fmaps.record_stream(side)
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -794,7 +889,8 @@ class FGN(torch.nn.Module):
                 self._support_back(sc, B, dev)
         vec = sc['vec']
 
-        qry_fmap = self.extract_feat(qry)                       # [B,h,w,C]
+        if qry_fmap is None:
+            qry_fmap = self.extract_feat(qry)                   # [B,h,w,C]
         fh, fw, C = qry_fmap.shape[1:]
         if tr is not None:
             tr['qry_fmap'], tr['spp_fmaps'] = qry_fmap, sc.get('spp_fmaps')

@@ -418,6 +418,45 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     return y
 
 
+def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
+    """The F(4x4) / F(2x2) convolution of SEVERAL inputs with one weight set through ONE grouped GEMM: every input
+    [n_i, H_i, W_i, Cin] is transformed into its own tile range of a shared V, the GEMM runs over all tiles, every
+    output ``outs[i]`` [n_i, H_i, W_i, Cout] (views of a caller-owned buffer) is transformed out of its range of Mo.
+    (The transforms address tile t of position g at ((g * t_pad + t) * C): a tile offset is a pointer offset.)"""
+    L = _lib.load()
+    f_in, f_out = (L.fgn_winograd4_input_f32, L.fgn_winograd4_output_f32) if layer.m == 4 else \
+        (L.fgn_winograd_input_f32, L.fgn_winograd_output_f32)
+    cin, cout, G = layer.cin, layer.cout, layer.groups
+    tiles = []
+    for x, y in zip(xs, outs):
+        _chk(x, 'x')
+        _chk(y, 'out')
+        if x.shape[-1] != cin or tuple(y.shape) != tuple(x.shape[:-1]) + (cout,):
+            raise _lib.FgnHipError('conv3x3_winograd_multi: operand shapes inconsistent')
+        tiles.append(x.shape[0] * _wg_tiles(x.shape[1], x.shape[2], layer.m))
+    total = sum(tiles)
+    t_pad = L.fgn_winograd_t_pad(total)
+    if G * t_pad * max(cin, cout) * 4 >= 0x7fffff00:
+        raise _lib.FgnHipError('conv3x3_winograd_multi: V / Mo exceed the 2 GiB descriptors')
+    dev = xs[0].device
+    V = torch.empty((G, t_pad, cin), device=dev, dtype=torch.float32)
+    Mo = torch.empty((G, t_pad, cout), device=dev, dtype=torch.float32)
+    st = _stream()
+    off = 0
+    for x, n_t in zip(xs, tiles):
+        n, H, W, _ = x.shape
+        _lib.check(f_in(_ptr(x), None, V.data_ptr() + off * cin * 4, None, n, 1, H, W, cin, t_pad, st), 'fgn_winograd_input_f32')
+        off += n_t
+    _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
+                                       G, st), 'fgn_winograd_gemm_f32')
+    off = 0
+    for y, n_t in zip(outs, tiles):
+        n, H, W, _ = y.shape
+        _lib.check(f_out(Mo.data_ptr() + off * cout * 4, _ptr(y), _ptr(layer.shift), None, n, H, W, cout, t_pad,
+                         int(layer.relu), st), 'fgn_winograd_output_f32')
+        off += n_t
+
+
 # --------------------------------------------------------------------------------------
 # spatial ops
 # --------------------------------------------------------------------------------------
@@ -432,10 +471,17 @@ def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, 'x')
     n, h, w, c = x.shape
-    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    shape = (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
+    if out is None:
+        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        if tuple(out.shape) != shape:
+            raise _lib.FgnHipError('maxpool3x3s2: bad out shape')
+        y = out
     _lib.check(_lib.load().fgn_maxpool3x3s2_nhwc_f32(_ptr(x), _ptr(y), n, h, w, c, _stream()),
                'fgn_maxpool3x3s2_nhwc_f32')
     return y
