@@ -271,8 +271,10 @@ def main():
     model = FGN(cfg['n_ways'], cfg['k_shots'], test_cfg=cfg['test_cfg'], state_dict=sd)
     model.use_graphs = bool(args.graphs)
     model.use_winograd = False if args.no_winograd else (args.winograd or True)
-    if os.environ.get('FGN_MERGED_BACKBONE'):        # experiment knob
+    if os.environ.get('FGN_MERGED_BACKBONE'):        # A/B knobs
         model.use_merged_backbone = os.environ['FGN_MERGED_BACKBONE'] != '0'
+    if os.environ.get('FGN_MERGED_SUPPORT_HEAD'):
+        model.use_merged_support_head = os.environ['FGN_MERGED_SUPPORT_HEAD'] != '0'
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);
     # every step copies its episode to the device (--resident-inputs: parked in HBM instead, not the headline)

@@ -365,6 +365,10 @@ class FGN(torch.nn.Module):
         # (same-box A/B, r03: 6.09 -> 5.77 ms).  Results differ from the separate passes in the last bits only
         # (split-K plans and Winograd-vs-direct choices depend on the row count).
         self.use_merged_backbone = True
+        # option: the support RoIs ride through the shared head in the box head's RoI batch (same weights; eval-mode
+        # BatchNorm is per sample), so the ~30 tiny launches of count_spp's own shared-head pass disappear.  Measured
+        # neutral (same-box A/B, r03: 5.75 vs 5.75 ms - those launches were already hidden on the side stream): off.
+        self.use_merged_support_head = False
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
@@ -716,6 +720,28 @@ class FGN(torch.nn.Module):
         sc['cat_mean_mp'] = ops.support_class_vectors(sfeat, sc['masks7'], B * N, K)  # [B*N,C]
         sc['S'] = ops.conv2d(sc['cat_mean'], P['rel_s'])                              # Ws*support + bias
 
+    def _support_rois(self, sc: dict, B, dev, x_out, y1_out) -> None:
+        """First half of count_spp for the MERGED shared head: the support masks and maps are pooled (into the first rows
+        of the RoI batch the box head will run, ``x_out``), and - the first 1x1 conv of the shared head being taken on
+        the feature map for the query's RoIs - the same conv on the pooled support features fills their rows of
+        ``y1_out``."""
+        P, rh = self._P, self.cfg['roi_head']
+        N, K, PS = self.n_ways, self.k_shots, rh['roi_out_size']
+        bidx = torch.arange(B * N * K, device=dev, dtype=torch.float32)[:, None]
+        spp_rois = torch.cat([bidx, sc['spp_xyxy']], 1).contiguous()
+        sc['masks7'] = ops.roi_align_mask(sc['spp_masks'], spp_rois, PS, 1.0, -1, False)
+        ops.roi_align(sc['spp_fmaps'], spp_rois, PS, 1.0 / rh['featmap_stride'], -1, False, out=x_out)
+        if y1_out is not None:
+            ops.conv2d(x_out, P['shared'][0].conv1, out=y1_out)
+
+    def _support_finish(self, sc: dict, sfeat, B) -> None:
+        """Second half of count_spp (fgn_roi_head.py:439-447) + the support half of the relation conv, on the support
+        rows of the shared head's output."""
+        P, N, K = self._P, self.n_ways, self.k_shots
+        sc['cat_mean'] = ops.support_kmean(sfeat, B * N, K)                           # [B*N,7,7,C]
+        sc['cat_mean_mp'] = ops.support_class_vectors(sfeat, sc['masks7'], B * N, K)  # [B*N,C]
+        sc['S'] = ops.conv2d(sc['cat_mean'], P['rel_s'])                              # Ws*support + bias
+
     @torch.no_grad()
     def encode_supports(self, spp_imgs, spp_bboxes, spp_isegmaps) -> dict:
         """Support-feature caching across queries: everything the path derives
@@ -864,6 +890,25 @@ class FGN(torch.nn.Module):
             side = main
         merged = (not cached) and self.use_merged_backbone and self.cfg['backbone'].get('norm', 'BN') == 'BN' and \
             self.cfg['backbone'].get('block', 'bottleneck') == 'bottleneck'
+        # merged shared head: rows [0, ns) of the box head's RoI batch are the support RoIs
+        msh = (not cached) and self.use_merged_support_head
+        ns = B * N * K
+        x_all = y1_all = None
+        if msh:
+            c4 = rh['shared_head']['inplanes']
+            x_all = torch.empty((ns + B * tc['rpn']['max_per_img'], PS, PS, c4), device=dev, dtype=torch.float32)
+            if P['sh0_lin'] is not None:
+                y1_all = torch.empty(tuple(x_all.shape[:3]) + (P['sh0_lin'].cout,), device=dev, dtype=torch.float32)
+            if side is not main and not torch.cuda.is_current_stream_capturing():
+                x_all.record_stream(side)
+                if y1_all is not None:
+                    y1_all.record_stream(side)
+
+        def support_tail():       # on the side stream, right behind the support maps
+            if msh:
+                self._support_rois(sc, B, dev, x_all[:ns], None if y1_all is None else y1_all[:ns])
+            else:
+                self._support_back(sc, B, dev)
         qry_fmap = None
         if cached:
             sc = support_code
@@ -875,7 +920,7 @@ class FGN(torch.nn.Module):
                 side.wait_event(backbone_done)
                 self._support_vectors(sc, spp_fmaps)
                 vec_ready = side.record_event()
-                self._support_back(sc, B, dev)
+                support_tail()
             if side is not main and not torch.cuda.is_current_stream_capturing():
                 spp_fmaps.record_stream(side)
         else:
@@ -886,7 +931,7 @@ class FGN(torch.nn.Module):
                 # count_spp (fgn_roi_head.py:419-449) follows at once: its ~30 tiny 9-RoI launches run beside the
                 # second half of the query backbone.  (Released later, at the AG-RPN conv, they were starved by that
                 # conv's persistent workgroups and the RoI head waited ~0.1 ms for them.)
-                self._support_back(sc, B, dev)
+                support_tail()
         vec = sc['vec']
 
         if qry_fmap is None:
@@ -921,13 +966,11 @@ class FGN(torch.nn.Module):
                     g_map = ops.conv2d(qry_fmap, P['sh0_lin'])
                 spp_ready = side.record_event()
             if not torch.cuda.is_current_stream_capturing():
-                for key in ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):   # produced on side, consumed on main
-                    sc[key].record_stream(main)
+                for key in ('spp_fmaps', 'vec', 'masks7') if msh else ('spp_fmaps', 'vec', 'S', 'cat_mean', 'cat_mean_mp', 'masks7'):
+                    sc[key].record_stream(main)                                   # produced on side, consumed on main
                 if g_map is not None:
                     g_map.record_stream(main)
                     qry_fmap.record_stream(side)
-        S, cat_mean, cat_mean_mp, masks7 = sc['S'], sc['cat_mean'], sc['cat_mean_mp'], sc['masks7']
-
         ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
         if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
             raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
@@ -939,7 +982,7 @@ class FGN(torch.nn.Module):
             main.wait_event(spp_ready)
         if tr is not None:
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
-                      n_props=n_props, spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
+                      n_props=n_props)
 
         # ---- box head on the proposals of all B images at once (fgn_roi_head.py:531-616); a RoI carries its
         # image index in column 0 (bbox2roi), which selects the feature map in RoIAlign and the support set
@@ -951,7 +994,22 @@ class FGN(torch.nn.Module):
         cnt_all = n_props[0:1] if B == 1 else None
         if g_map is None and P['sh0_lin'] is not None:
             g_map = ops.conv2d(qry_fmap, P['sh0_lin'])                                # [B,h,w,planes]
-        roi_in, feats = self._roi_feats(qry_fmap, g_map, rois_all, cnt_all)
+        if msh:
+            # support RoIs (pooled on the side stream) and proposals through the shared head as ONE RoI batch
+            inv = 1.0 / rh['featmap_stride']
+            ops.roi_align(qry_fmap, rois_all, PS, inv, rh['roi_sampling_ratio'], True, cnt_all, out=x_all[ns:])
+            if y1_all is not None:
+                ops.roi_align(g_map, rois_all, PS, inv, rh['roi_sampling_ratio'], True, cnt_all,
+                              post_shift=P['sh0_shift'], relu=True, out=y1_all[ns:])
+            cnt_plus = None if cnt_all is None else cnt_all + ns
+            feats_all = self._shared_head(x_all, cnt_plus, y1=y1_all)
+            self._support_finish(sc, feats_all[:ns], B)
+            feats = feats_all[ns:]
+        else:
+            _, feats = self._roi_feats(qry_fmap, g_map, rois_all, cnt_all)
+        S, cat_mean, cat_mean_mp, masks7 = sc['S'], sc['cat_mean'], sc['cat_mean_mp'], sc['masks7']
+        if tr is not None:
+            tr.update(spp_masks7=masks7, spp_cat_mean=cat_mean, spp_cat_mean_mp=cat_mean_mp)
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'], cnt_all)

@@ -521,7 +521,8 @@ def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
 
 def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
               sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None,
-              post_shift: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+              post_shift: Optional[torch.Tensor] = None, relu: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fmap [B,H,W,C], rois [R,5] -> [R,P,P,C] (+ post_shift[C], ReLU)."""
     _chk(fmap, 'fmap')
     _chk(rois, 'rois')
@@ -533,7 +534,12 @@ def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_sca
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise _lib.FgnHipError('roi_align: rois must be [R,5]')
     r = rois.shape[0]
-    out = torch.empty((r, out_size, out_size, c), device=fmap.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((r, out_size, out_size, c), device=fmap.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        if tuple(out.shape) != (r, out_size, out_size, c):
+            raise _lib.FgnHipError('roi_align: bad out shape')
     if n_rois_dev is not None:
         _chk(n_rois_dev, 'n_rois_dev', torch.int32)
     rc = _lib.load().fgn_roi_align_nhwc_f32(_ptr(fmap), _ptr(rois), _ptr(out), _ptr(n_rois_dev), r, b, h, w, c,

@@ -388,6 +388,32 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
     assert all(not s_['busy'] for ring in model._pinned.values() for s_ in ring)
 
 
+def test_merged_support_head_option_matches_the_default():
+    """``use_merged_support_head`` (support RoIs in the box head's RoI batch): same detections as the default within
+    the tolerance of the metric, with and without the RoIAlign-commuted first conv, batch 1 (device-side proposal count
+    shifted by the support rows) and batch 2."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    sd = init_state_dict(cfg, 0)
+    for nb, commute in ((1, True), (2, True), (1, False)):
+        batch = make_batch(5, nb, 3, 2, 160, 224, 64)
+        res = []
+        for msh in (False, True):
+            model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                        test_cfg=cfg['test_cfg'], state_dict=sd)
+            model.use_roi_commute = commute
+            model.use_merged_support_head = msh
+            res.append(model.simple_test(**batch, rescale=True))
+        for a, c in zip(*res):
+            assert len(a['dt_scores']) > 0
+            pairs, only_a, only_c = match_detections(a['dt_bboxes'], a['dt_cat_ids'], c['dt_bboxes'], c['dt_cat_ids'])
+            ia, ic = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+            assert len(only_a) <= 2 and len(only_c) <= 2 and np.abs(a['dt_scores'][ia] - c['dt_scores'][ic]).max() <= TOL
+
+
 def test_winograd_and_direct_paths_agree():
     """`use_winograd=False`, `use_roi_commute=False` (direct form for every 3x3, shared_head conv1 on the RoIs: the
     reference's formulation op for op) and the default path give the same detections within the tolerance of
