@@ -216,11 +216,19 @@ __device__ __forceinline__ void wg4_at(const vf<V> (&m)[6], vf<V> (&r)[4]) {
     r[3] = (vfma<V>(-8.f, m[4], vfma<V>(0.125f, m[3], d12))) + m[5];
 }
 
+// A second tensor (`seg`: its own image count and size, no input scale, no device count) may follow the first in the
+// tile index space - tiles [tiles0, ...) of V: the query and the support maps of one backbone layer share one launch.
+struct WgSeg {
+    const float* x;       // second input / output tensor (nullptr: none)
+    int n_img, H, W, ty, tx;
+    int tiles0;           // tiles of the first tensor
+};
+
 template <int V, bool EAGER>
 __global__ __launch_bounds__(256) void wg4_input_kernel(const float* __restrict__ x_, const float* __restrict__ in_scale_,
                                                         float* __restrict__ V_, const int32_t* __restrict__ n_img_dev,
                                                         int n_img, int a_img_div, int H, int W, int CV, int ty, int tx,
-                                                        int t_pad, long long total) {
+                                                        int t_pad, long long total, const WgSeg seg) {
     typedef vf<V> T;
     const T* __restrict__ x = reinterpret_cast<const T*>(x_);
     const T* __restrict__ in_scale = reinterpret_cast<const T*>(in_scale_);
@@ -230,11 +238,20 @@ __global__ __launch_bounds__(256) void wg4_input_kernel(const float* __restrict_
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % CV);
         const int t = (int)(i / CV);
-        const int xx = t % tx;
-        const int r = t / tx;
+        const bool second = seg.x && t >= seg.tiles0;
+        if (second) {
+            x = reinterpret_cast<const T*>(seg.x);
+            H = seg.H; W = seg.W; ty = seg.ty; tx = seg.tx; n_img = seg.n_img; a_img_div = 1;
+        }
+        const int tl = second ? t - seg.tiles0 : t;
+        const int xx = tl % tx;
+        const int r = tl / tx;
         const int yy = r % ty;
         const int img = r / ty;
-        if (img >= n_img) break;
+        if (img >= n_img) {
+            if (seg.x) continue;
+            break;                                    // single tensor: images are the slowest index, nothing is left
+        }
         const T* src = x + (size_t)(img / a_img_div) * H * W * CV + c;
         const int iy0 = 4 * yy - 1, ix0 = 4 * xx - 1;
         T s;
@@ -299,7 +316,8 @@ template <int V>
 __global__ __launch_bounds__(256) void wg4_output_kernel(const float* __restrict__ Mo_, float* __restrict__ y_,
                                                          const float* __restrict__ shift_,
                                                          const int32_t* __restrict__ n_img_dev, int n_img, int H, int W,
-                                                         int CV, int ty, int tx, int t_pad, int relu, long long total) {
+                                                         int CV, int ty, int tx, int t_pad, int relu, long long total,
+                                                         const WgSeg seg) {
     typedef vf<V> T;
     const T* __restrict__ Mo = reinterpret_cast<const T*>(Mo_);
     const T* __restrict__ shift = reinterpret_cast<const T*>(shift_);
@@ -309,11 +327,20 @@ __global__ __launch_bounds__(256) void wg4_output_kernel(const float* __restrict
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % CV);
         const int t = (int)(i / CV);
-        const int xx = t % tx;
-        const int r = t / tx;
+        const bool second = seg.x && t >= seg.tiles0;
+        if (second) {
+            y = reinterpret_cast<T*>(const_cast<float*>(seg.x));
+            H = seg.H; W = seg.W; ty = seg.ty; tx = seg.tx; n_img = seg.n_img;
+        }
+        const int tl = second ? t - seg.tiles0 : t;
+        const int xx = tl % tx;
+        const int r = tl / tx;
         const int yy = r % ty;
         const int img = r / ty;
-        if (img >= n_img) break;
+        if (img >= n_img) {
+            if (seg.x) continue;
+            break;
+        }
         const T* src = Mo + (size_t)t * CV + c;
         const size_t gs = (size_t)t_pad * CV;
         T mm[6][6];                                    // all 36 loads in flight at once
@@ -375,16 +402,22 @@ extern "C" int fgn_winograd4_variant(int tiles_total, int C, int is_output) {
 
 #define WG4_IN_LAUNCH(VV, EE)                                                                                          \
     FGN_LAUNCH_TIMED((wg4_input_kernel<VV, EE>), dim3(grid), dim3(256), 0, stream, x, in_scale, V, n_img_dev, n_img,  \
-                     a_img_div, H, W, C / VV, ty, tx, t_pad, total)
+                     a_img_div, H, W, C / VV, ty, tx, t_pad, total, seg)
 
-extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev,
-                                       int n_img, int a_img_div, int H, int W, int C, int t_pad, hipStream_t stream) {
+static int wg4_input_launch(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev, int n_img,
+                            int a_img_div, int H, int W, int C, int t_pad, const float* x1, int n_img1, int H1, int W1,
+                            hipStream_t stream) {
     if (!x || !V) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const int ty = (H + 3) / 4, tx = (W + 3) / 4;
-    if (C % 4 != 0 || a_img_div < 1 || H < 1 || W < 1 || (long long)n_img * ty * tx > t_pad) return FGN_ERR_SHAPE;
-    const int vec = wg4_vec((long long)n_img * ty * tx * C);
-    const long long total = (long long)n_img * ty * tx * (C / vec);
+    WgSeg seg;
+    seg.x = x1; seg.n_img = n_img1; seg.H = H1; seg.W = W1; seg.ty = (H1 + 3) / 4; seg.tx = (W1 + 3) / 4;
+    seg.tiles0 = n_img * ty * tx;
+    const long long tiles_all = (long long)seg.tiles0 + (x1 ? (long long)n_img1 * seg.ty * seg.tx : 0);
+    if (C % 4 != 0 || a_img_div < 1 || H < 1 || W < 1 || tiles_all > t_pad) return FGN_ERR_SHAPE;
+    if (x1 && (in_scale || n_img_dev || a_img_div != 1 || n_img1 < 1 || H1 < 1 || W1 < 1)) return FGN_ERR_SHAPE;
+    const int vec = wg4_vec(tiles_all * C);
+    const long long total = tiles_all * (C / vec);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
     const bool eager = wg4_eager(total);
     switch (vec * 10 + (eager ? 1 : 0)) {
@@ -399,18 +432,34 @@ extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, fl
     return FGN_OK;
 }
 
+extern "C" int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev,
+                                       int n_img, int a_img_div, int H, int W, int C, int t_pad, hipStream_t stream) {
+    return wg4_input_launch(x, in_scale, V, n_img_dev, n_img, a_img_div, H, W, C, t_pad, nullptr, 0, 1, 1, stream);
+}
+// two tensors (e.g. the query map and the support maps of a backbone layer) into consecutive tile ranges of one V
+extern "C" int fgn_winograd4_input2_f32(const float* x0, int n_img0, int H0, int W0, const float* x1, int n_img1, int H1,
+                                        int W1, float* V, int C, int t_pad, hipStream_t stream) {
+    if (!x1) return FGN_ERR_ARG;
+    return wg4_input_launch(x0, nullptr, V, nullptr, n_img0, 1, H0, W0, C, t_pad, x1, n_img1, H1, W1, stream);
+}
+
 #define WG4_OUT_LAUNCH(VV)                                                                                             \
     FGN_LAUNCH_TIMED((wg4_output_kernel<VV>), dim3(grid), dim3(256), 0, stream, Mo, y, shift, n_img_dev, n_img, H, W, \
-                     C / VV, ty, tx, t_pad, relu, total)
+                     C / VV, ty, tx, t_pad, relu, total, seg)
 
-extern "C" int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev,
-                                        int n_img, int H, int W, int C, int t_pad, int relu, hipStream_t stream) {
+static int wg4_output_launch(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img, int H,
+                             int W, int C, int t_pad, int relu, float* y1, int n_img1, int H1, int W1, hipStream_t stream) {
     if (!Mo || !y) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const int ty = (H + 3) / 4, tx = (W + 3) / 4;
-    if (C % 4 != 0 || (long long)n_img * ty * tx > t_pad) return FGN_ERR_SHAPE;
-    const int vec = wg4_vec((long long)n_img * ty * tx * C);
-    const long long total = (long long)n_img * ty * tx * (C / vec);
+    WgSeg seg;
+    seg.x = y1; seg.n_img = n_img1; seg.H = H1; seg.W = W1; seg.ty = (H1 + 3) / 4; seg.tx = (W1 + 3) / 4;
+    seg.tiles0 = n_img * ty * tx;
+    const long long tiles_all = (long long)seg.tiles0 + (y1 ? (long long)n_img1 * seg.ty * seg.tx : 0);
+    if (C % 4 != 0 || tiles_all > t_pad) return FGN_ERR_SHAPE;
+    if (y1 && (n_img_dev || n_img1 < 1 || H1 < 1 || W1 < 1)) return FGN_ERR_SHAPE;
+    const int vec = wg4_vec(tiles_all * C);
+    const long long total = tiles_all * (C / vec);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
     switch (vec) {
         case 1: WG4_OUT_LAUNCH(1); break;
@@ -419,4 +468,15 @@ extern "C" int fgn_winograd4_output_f32(const float* Mo, float* y, const float* 
     }
     FGN_LAUNCH_CHECK();
     return FGN_OK;
+}
+
+extern "C" int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev,
+                                        int n_img, int H, int W, int C, int t_pad, int relu, hipStream_t stream) {
+    return wg4_output_launch(Mo, y, shift, n_img_dev, n_img, H, W, C, t_pad, relu, nullptr, 0, 1, 1, stream);
+}
+extern "C" int fgn_winograd4_output2_f32(const float* Mo, const float* shift, float* y0, int n_img0, int H0, int W0,
+                                         float* y1, int n_img1, int H1, int W1, int C, int t_pad, int relu,
+                                         hipStream_t stream) {
+    if (!y1) return FGN_ERR_ARG;
+    return wg4_output_launch(Mo, y0, shift, nullptr, n_img0, H0, W0, C, t_pad, relu, y1, n_img1, H1, W1, stream);
 }

@@ -30,6 +30,8 @@ SIGNATURES = {
     'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_variant': (_i, [_i, _i, _i]),
+    'fgn_winograd4_input2_f32': (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _i, _i, _p]),
+    'fgn_winograd4_output2_f32': (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),
     'fgn_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_group_norm_workspace_bytes': (C.c_size_t, [_i] * 4),
@@ -83,7 +85,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 

@@ -442,19 +442,30 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
     V = torch.empty((G, t_pad, cin), device=dev, dtype=torch.float32)
     Mo = torch.empty((G, t_pad, cout), device=dev, dtype=torch.float32)
     st = _stream()
-    off = 0
-    for x, n_t in zip(xs, tiles):
-        n, H, W, _ = x.shape
-        _lib.check(f_in(_ptr(x), None, V.data_ptr() + off * cin * 4, None, n, 1, H, W, cin, t_pad, st), 'fgn_winograd_input_f32')
-        off += n_t
+    pair = layer.m == 4 and len(xs) == 2          # one transform launch for both tensors
+    if pair:
+        (n0, h0, w0, _), (n1, h1, w1, _) = xs[0].shape, xs[1].shape
+        _lib.check(L.fgn_winograd4_input2_f32(_ptr(xs[0]), n0, h0, w0, _ptr(xs[1]), n1, h1, w1, _ptr(V), cin, t_pad, st),
+                   'fgn_winograd4_input2_f32')
+    else:
+        off = 0
+        for x, n_t in zip(xs, tiles):
+            n, H, W, _ = x.shape
+            _lib.check(f_in(_ptr(x), None, V.data_ptr() + off * cin * 4, None, n, 1, H, W, cin, t_pad, st),
+                       'fgn_winograd_input_f32')
+            off += n_t
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
                                        G, st), 'fgn_winograd_gemm_f32')
-    off = 0
-    for y, n_t in zip(outs, tiles):
-        n, H, W, _ = y.shape
-        _lib.check(f_out(Mo.data_ptr() + off * cout * 4, _ptr(y), _ptr(layer.shift), None, n, H, W, cout, t_pad,
-                         int(layer.relu), st), 'fgn_winograd_output_f32')
-        off += n_t
+    if pair:
+        _lib.check(L.fgn_winograd4_output2_f32(_ptr(Mo), _ptr(layer.shift), _ptr(outs[0]), n0, h0, w0, _ptr(outs[1]), n1, h1,
+                                               w1, cout, t_pad, int(layer.relu), st), 'fgn_winograd4_output2_f32')
+    else:
+        off = 0
+        for y, n_t in zip(outs, tiles):
+            n, H, W, _ = y.shape
+            _lib.check(f_out(Mo.data_ptr() + off * cout * 4, _ptr(y), _ptr(layer.shift), None, n, H, W, cout, t_pad,
+                             int(layer.relu), st), 'fgn_winograd_output_f32')
+            off += n_t
 
 
 # --------------------------------------------------------------------------------------

@@ -95,6 +95,13 @@ int fgn_winograd4_input_f32(const float* x, const float* in_scale, float* V, con
                             int a_img_div, int H, int W, int C, int t_pad, void* stream);
 int fgn_winograd4_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                              int H, int W, int C, int t_pad, int relu, void* stream);
+/* The F(4x4) transforms of TWO tensors of one layer (the query map and the support maps of a backbone layer, each with
+ * its own image count and size) in one launch: tensor 0 fills tiles [0, n0*tiles(H0,W0)) of V / reads them from Mo,
+ * tensor 1 the tiles behind them; no input scale, no device-side count.  t_pad >= all tiles. */
+int fgn_winograd4_input2_f32(const float* x0, int n_img0, int H0, int W0, const float* x1, int n_img1, int H1, int W1,
+                             float* V, int C, int t_pad, void* stream);
+int fgn_winograd4_output2_f32(const float* Mo, const float* shift, float* y0, int n_img0, int H0, int W0, float* y1,
+                              int n_img1, int H1, int W1, int C, int t_pad, int relu, void* stream);
 /* Which instance of the F(4x4) transform kernels a layer with `tiles_total` tiles and C channels launches: the
  * channel vector width of a thread (1, 2 or 4 floats) * 10 + 1 when the input transform issues all 36 loads up front.
  * Informational (lets a profiler name the kernel of a launch); the transforms choose it themselves. */

@@ -91,3 +91,28 @@ def test_full_size_linearity_and_guidance_equivalence():
     assert (pre - y1).abs().max().item() <= 1e-4 * rng
     direct = ops.conv2d(ops.scale_channels(x1, s, 3), ops.pack_conv(wt, pad=1).to('cuda'))
     assert (direct - y1).abs().max().item() <= 1e-4 * rng
+
+
+def test_two_tensor_winograd_launches_match_the_single_tensor_form():
+    """``ops.conv3x3_winograd_multi``: the query map and the support maps of a backbone layer through ONE input
+    transform launch, ONE grouped GEMM and ONE output transform launch (consecutive tile ranges of V / Mo) against
+    ``conv3x3_winograd`` on each tensor alone, F(4x4) (two-tensor kernels) and F(2x2) (per-tensor launches): the same
+    products summed by whichever GEMM kernel the row count selects (persistent 16x16x4 / one-shot 32x32x2 MFMA: the
+    K order differs), so equal to a few ulp, not always bit for bit."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for m in (4, 2):
+        for (q_shape, s_shape, cin, cout) in (((1, 50, 84), (9, 16, 16), 256, 256), ((2, 13, 10), (3, 7, 9), 64, 128),
+                                              ((1, 100, 167), (9, 32, 32), 128, 128)):
+            wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+            layer = ops.pack_winograd(wt, bias=torch.randn(cout, generator=g), relu=True, m=m).to('cuda')
+            xq = torch.randn(*q_shape, cin, generator=g).cuda()
+            xs = torch.randn(*s_shape, cin, generator=g).cuda()
+            buf = torch.full((xq[..., 0].numel() + xs[..., 0].numel(), cout), -7.0, device='cuda')
+            yq = buf[:xq[..., 0].numel()].view(*q_shape, cout)
+            ys = buf[xq[..., 0].numel():].view(*s_shape, cout)
+            ops.conv3x3_winograd_multi([xq, xs], layer, [yq, ys])
+            for got, x in ((yq, xq), (ys, xs)):
+                want = ops.conv3x3_winograd(x, layer)
+                assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), (m, tuple(x.shape))
+            assert float(buf.min()) >= 0.0                        # every row of the shared buffer was written (ReLU output)
