@@ -443,6 +443,10 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
     Mo = torch.empty((G, t_pad, cout), device=dev, dtype=torch.float32)
     st = _stream()
     pair = layer.m == 4 and len(xs) == 2          # one transform launch for both tensors
+    prof = PROFILE if pair else None              # (the per-tensor form is not instrumented: tests / F(2x2) only)
+    ev = []
+    if prof is not None:
+        ev.append(prof.arm())
     if pair:
         (n0, h0, w0, _), (n1, h1, w1, _) = xs[0].shape, xs[1].shape
         _lib.check(L.fgn_winograd4_input2_f32(_ptr(xs[0]), n0, h0, w0, _ptr(xs[1]), n1, h1, w1, _ptr(V), cin, t_pad, st),
@@ -454,8 +458,12 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             _lib.check(f_in(_ptr(x), None, V.data_ptr() + off * cin * 4, None, n, 1, H, W, cin, t_pad, st),
                        'fgn_winograd_input_f32')
             off += n_t
+    if prof is not None:
+        ev.append(prof.arm())
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
                                        G, st), 'fgn_winograd_gemm_f32')
+    if prof is not None:
+        ev.append(prof.arm())
     if pair:
         _lib.check(L.fgn_winograd4_output2_f32(_ptr(Mo), _ptr(layer.shift), _ptr(outs[0]), n0, h0, w0, _ptr(outs[1]), n1, h1,
                                                w1, cout, t_pad, int(layer.relu), st), 'fgn_winograd4_output2_f32')
@@ -466,6 +474,17 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             _lib.check(f_out(Mo.data_ptr() + off * cout * 4, _ptr(y), _ptr(layer.shift), None, n, H, W, cout, t_pad,
                              int(layer.relu), st), 'fgn_winograd_output_f32')
             off += n_t
+    if prof is not None:
+        pixels = sum(x.shape[0] * x.shape[1] * x.shape[2] for x in xs)
+        common = dict(n_img=1, n_img_dev=None, shape=(len(xs), pixels, 1, cin, cout, 3, 1))
+        vi, vo = L.fgn_winograd4_variant(total, cin, 0), L.fgn_winograd4_variant(total, cout, 1)
+        prof.append(dict(kind='wg_in', kernel='wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false'),
+                         e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
+        gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
+        prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
+                         flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin, **common))
+        prof.append(dict(kind='wg_out', kernel='wg4_output_kernel<%d>' % (vo // 10), e0=ev[2][0], e1=ev[2][1],
+                         flop_direct=0.0, flop_issued=0.0, **common))
 
 
 # --------------------------------------------------------------------------------------
