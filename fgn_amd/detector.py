@@ -361,8 +361,8 @@ class FGN(torch.nn.Module):
         # query + support maps through SHARED backbone launches (1x1 / stride 1 convolutions and the grouped Winograd GEMM
         # over all rows of both; frozen-BN bottleneck backbones): half the launches of the two passes, no support-only
         # split-K.  Round 2 measured this 5 % slower with one episode in flight (the support stream filled the query
-        # branch's idle phases); with two episodes in flight the other episode does that, and it is 5 % faster
-        # (same-box A/B, r03: 6.09 -> 5.77 ms).  Results differ from the separate passes in the last bits only
+        # branch's idle phases); with two episodes in flight the other episode does that, and it is 7 % faster
+        # (same-box A/B, r03: 6.07 -> 5.72 ms).  Results differ from the separate passes in the last bits only
         # (split-K plans and Winograd-vs-direct choices depend on the row count).
         self.use_merged_backbone = True
         # option: the support RoIs ride through the shared head in the box head's RoI batch (same weights; eval-mode
@@ -698,7 +698,7 @@ class FGN(torch.nn.Module):
         spp_masks = (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
         sc = dict(B=B, device=dev, spp_xyxy=spp_xyxy, spp_masks=spp_masks, spp=spp)
         if not defer_backbone:
-            self._support_vectors(sc, self.extract_feat(spp))                   # [B*N*K,s,s,C]
+            self._support_vectors(sc, self.extract_feat(sc.pop('spp')))         # [B*N*K,s,s,C]
         return sc
 
     def _support_vectors(self, sc: dict, spp_fmaps) -> None:
@@ -849,7 +849,8 @@ class FGN(torch.nn.Module):
         main = torch.cuda.current_stream()
         dev = torch.device('cuda', torch.cuda.current_device())
         hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
-        key = (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone)) + \
+        key = (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone),
+               bool(self.use_merged_support_head)) + \
             tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
         ge = self._graphs.get(key)
         if ge is None:
@@ -914,7 +915,7 @@ class FGN(torch.nn.Module):
             sc = support_code
         elif merged:
             sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, main, defer_backbone=True)
-            qry_fmap, spp_fmaps = self.extract_feat_pair(qry, sc['spp'])
+            qry_fmap, spp_fmaps = self.extract_feat_pair(qry, sc.pop('spp'))
             backbone_done = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(backbone_done)
