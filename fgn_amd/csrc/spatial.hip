@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ n_rois_dev, int n_rois,
                                                         int H, int W, int C, int P, float spatial_scale,
                                                         int sampling_ratio, int aligned,
-                                                        const float* __restrict__ post_shift, int relu) {
+                                                        const float* __restrict__ post_shift, int relu,
+                                                        const float* __restrict__ fmap2, float* __restrict__ out2, int C2,
+                                                        const float* __restrict__ post_shift2, int relu2) {
+    // (fmap2 / out2: an optional second map of the same spatial size pooled at the same RoIs by the same launch - the C4
+    // map and the map of the shared head's commuted first conv; channel quads [C/4, (C + C2)/4) of the thread loop)
     const int bin = blockIdx.x;
     const int r = bin / (P * P);
     int nr = n_rois;
@@ -142,9 +146,17 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
     const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
     const float count = (float)max(gh * gw, 1);
-    const float* base = fmap + (size_t)b * H * W * C;
+    const float* base1 = fmap + (size_t)b * H * W * C;
+    const float* base2 = fmap2 ? fmap2 + (size_t)b * H * W * C2 : nullptr;
+    const int c_all = C + (fmap2 ? C2 : 0);
+    const int C1 = C;
 
-    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+    for (int cc = threadIdx.x * 4; cc < c_all; cc += blockDim.x * 4) {
+        const bool snd = cc >= C1;
+        const float* base = snd ? base2 : base1;
+        const int c = snd ? cc - C1 : cc;
+        C = snd ? C2 : C1;
+        if (snd) { out = out2; post_shift = post_shift2; relu = relu2; }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int iy = 0; iy < gh; ++iy) {
             const float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
@@ -235,7 +247,27 @@ extern "C" int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, floa
     const int threads = C >= 1024 ? 256 : (C >= 512 ? 128 : 64);
     hipLaunchKernelGGL(roi_align_kernel, dim3(n_rois * out_size * out_size), dim3(threads), 0, stream, fmap,
                        rois, out, n_rois_dev, n_rois, H, W, C, out_size, spatial_scale, sampling_ratio,
-                       aligned, post_shift, relu);
+                       aligned, post_shift, relu, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, 0);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+// Two maps of the same spatial size pooled at the same RoIs by one launch (fgn_roi_head.py:331,366 with the shared
+// head's first 1x1 conv commuted in front of the pooling): out [R,P,P,C] from fmap, out2 [R,P,P,C2] from fmap2
+// (+ post_shift2 [C2], ReLU).  Same arithmetic per channel as two fgn_roi_align_nhwc_f32 calls: identical bytes.
+extern "C" int fgn_roi_align2_nhwc_f32(const float* fmap, const float* fmap2, const float* rois, float* out, float* out2,
+                                       const int32_t* n_rois_dev, int n_rois, int n_img, int H, int W, int C, int C2,
+                                       int out_size, float spatial_scale, int sampling_ratio, int aligned,
+                                       const float* post_shift2, int relu2, hipStream_t stream) {
+    if (!fmap || !fmap2 || !rois || !out || !out2) return FGN_ERR_ARG;
+    if (C % 4 || C2 % 4 || out_size <= 0) return FGN_ERR_SHAPE;
+    (void)n_img;
+    if (n_rois == 0) return FGN_OK;
+    const int quads = (C + C2) / 4;
+    const int threads = quads >= 256 ? 256 : (quads >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(n_rois * out_size * out_size), dim3(threads), 0, stream, fmap,
+                       rois, out, n_rois_dev, n_rois, H, W, C, out_size, spatial_scale, sampling_ratio,
+                       aligned, (const float*)nullptr, 0, fmap2, out2, C2, post_shift2, relu2);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -634,11 +634,11 @@ class FGN(torch.nn.Module):
         50x84 pixels instead of 49 per RoI) and only its BN shift + ReLU follow the pooling."""
         P, rh = self._P, self.cfg['roi_head']
         PS, inv = rh['roi_out_size'], 1.0 / rh['featmap_stride']
-        x = ops.roi_align(fmap, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev)
-        y1 = None
-        if g_map is not None:
-            y1 = ops.roi_align(g_map, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev,
-                               post_shift=P['sh0_shift'], relu=True)
+        if g_map is not None:       # both maps at the same sampling points: one launch
+            x, y1 = ops.roi_align2(fmap, g_map, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev,
+                                   post_shift2=P['sh0_shift'], relu2=True)
+        else:
+            x, y1 = ops.roi_align(fmap, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev), None
         return x, self._shared_head(x, n_dev, y1=y1)
 
     def _mask_head(self, mf, vmask, n_dev=None):

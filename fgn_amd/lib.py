@@ -38,6 +38,7 @@ SIGNATURES = {
     'fgn_group_norm_nhwc_f32': (_i, [_p] * 6 + [C.c_size_t, _i, _i, _i, _i, _f, _i, _p]),
     'fgn_avgpool2x2_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'fgn_roi_align_nhwc_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p]),
+    'fgn_roi_align2_nhwc_f32': (_i, [_p] * 6 + [_i] * 7 + [_f, _i, _i, _p, _i, _p]),
     'fgn_roi_align_mask_u8': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     'fgn_support_class_vectors_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_scale_channels_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -85,7 +86,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 

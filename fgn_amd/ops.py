@@ -579,6 +579,34 @@ def roi_align(fmap: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_sca
     return out
 
 
+def roi_align2(fmap: torch.Tensor, fmap2: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
+               sampling_ratio: int, aligned: bool, n_rois_dev: Optional[torch.Tensor] = None,
+               post_shift2: Optional[torch.Tensor] = None, relu2: bool = False):
+    """Two maps of one spatial size pooled at the same RoIs by ONE launch: -> ([R,P,P,C], [R,P,P,C2] (+ post_shift2,
+    ReLU)); identical bytes to two ``roi_align`` calls."""
+    _chk(fmap, 'fmap')
+    _chk(fmap2, 'fmap2')
+    _chk(rois, 'rois')
+    b, h, w, c = fmap.shape
+    c2 = fmap2.shape[3]
+    if tuple(fmap2.shape[:3]) != (b, h, w) or rois.dim() != 2 or rois.shape[1] != 5:
+        raise _lib.FgnHipError('roi_align2: operand shapes inconsistent')
+    if post_shift2 is not None:
+        _chk(post_shift2, 'post_shift2')
+        if post_shift2.numel() != c2:
+            raise _lib.FgnHipError('roi_align2: post_shift2 must be [C2]')
+    if n_rois_dev is not None:
+        _chk(n_rois_dev, 'n_rois_dev', torch.int32)
+    r = rois.shape[0]
+    out = torch.empty((r, out_size, out_size, c), device=fmap.device, dtype=torch.float32)
+    out2 = torch.empty((r, out_size, out_size, c2), device=fmap.device, dtype=torch.float32)
+    rc = _lib.load().fgn_roi_align2_nhwc_f32(_ptr(fmap), _ptr(fmap2), _ptr(rois), _ptr(out), _ptr(out2), _ptr(n_rois_dev),
+                                             r, b, h, w, c, c2, out_size, float(spatial_scale), sampling_ratio,
+                                             int(aligned), _ptr(post_shift2), int(relu2), _stream())
+    _lib.check(rc, 'fgn_roi_align2_nhwc_f32')
+    return out, out2
+
+
 def roi_align_mask(mask_u8: torch.Tensor, rois: torch.Tensor, out_size: int, spatial_scale: float,
                    sampling_ratio: int, aligned: bool) -> torch.Tensor:
     """mask [B,H,W] uint8 -> [R,P,P] fp32."""

@@ -135,6 +135,13 @@ int fgn_avgpool2x2_nhwc_f32(const float* x, float* y, int n_img, int H, int W, i
 int fgn_roi_align_nhwc_f32(const float* fmap, const float* rois, float* out, const int32_t* n_rois_dev,
                            int n_rois, int n_img, int H, int W, int C, int out_size, float spatial_scale,
                            int sampling_ratio, int aligned, const float* post_shift, int relu, void* stream);
+/* The same pooling of TWO maps of one spatial size at the same RoIs in one launch: out [R,P,P,C] from fmap, out2
+ * [R,P,P,C2] from fmap2 (+ post_shift2 [C2], ReLU) - the C4 map and the map of the shared head's first 1x1 conv taken
+ * in front of the pooling (fgn_roi_head.py:331-336, 366-369).  Identical bytes to two single-map calls. */
+int fgn_roi_align2_nhwc_f32(const float* fmap, const float* fmap2, const float* rois, float* out, float* out2,
+                            const int32_t* n_rois_dev, int n_rois, int n_img, int H, int W, int C, int C2,
+                            int out_size, float spatial_scale, int sampling_ratio, int aligned,
+                            const float* post_shift2, int relu2, void* stream);
 /* same for a single-channel uint8/bool map [n_img,H,W] -> [R,P,P] (support masks,
  * fgn_roi_head.py:429) */
 int fgn_roi_align_mask_u8(const uint8_t* mask, const float* rois, float* out, int n_rois, int n_img, int H,

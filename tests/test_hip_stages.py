@@ -51,6 +51,26 @@ def test_roi_align_matches_oracle(aligned, sr):
     _close(_nchw(out[:3].cpu()), ref[:3], 2e-6)
 
 
+def test_two_map_roi_align_is_identical_to_two_launches():
+    """``ops.roi_align2``: the C4 map and the map of the shared head's commuted first conv pooled at the same RoIs by
+    one launch (+ shift and ReLU on the second): the bytes of two single-map launches, incl. a device-side RoI count."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(8)
+    f1 = torch.randn(2, 13, 17, 1024, generator=g).cuda()
+    f2 = torch.randn(2, 13, 17, 512, generator=g).cuda()
+    sh = torch.randn(512, generator=g).cuda()
+    rois = torch.tensor([[0, 10.3, 20.7, 150.2, 140.9], [1, -30.0, -20.0, 90.0, 100.0], [0, 200.0, 150.0, 290.0, 230.0],
+                         [1, 40.0, 40.0, 41.0, 42.0], [0, 0.0, 0.0, 272.0, 208.0], [1, 5.5, 3.25, 300.0, 260.0]]).cuda()
+    for cnt in (None, torch.tensor([4], dtype=torch.int32, device='cuda')):
+        a, b = ops.roi_align2(f1, f2, rois, 7, 1 / 16, 0, True, cnt, post_shift2=sh, relu2=True)
+        n = 6 if cnt is None else 4
+        assert torch.equal(a[:n], ops.roi_align(f1, rois, 7, 1 / 16, 0, True, cnt)[:n])
+        assert torch.equal(b[:n], ops.roi_align(f2, rois, 7, 1 / 16, 0, True, cnt, post_shift=sh, relu=True)[:n])
+    c, d = ops.roi_align2(f1[..., :64].contiguous(), f2[..., :32].contiguous(), rois, 7, 1 / 16, 2, False)
+    assert torch.equal(c, ops.roi_align(f1[..., :64].contiguous(), rois, 7, 1 / 16, 2, False))
+    assert torch.equal(d, ops.roi_align(f2[..., :32].contiguous(), rois, 7, 1 / 16, 2, False))
+
+
 def test_roi_align_mask_matches_oracle():
     from fgn_amd import ops
     from oracle import fgn_ref_cpu as O
