@@ -86,14 +86,17 @@ def collate(samples: list) -> dict:
     """Restatement of ``collate_fn_new`` (main.py:62-76): ragged query
     annotations stay lists of tensors, everything else is stacked."""
     batch = {}
-    for key in samples[0]:
-        vals = [s[key] for s in samples]
+    for key in samples[0]:                       # default_collate of everything that stacks, in sample-dict order ...
         if key in _LIST_KEYS:
-            batch[key] = [torch.as_tensor(v) for v in vals]
-        elif isinstance(vals[0], torch.Tensor):
+            continue
+        vals = [s[key] for s in samples]
+        if isinstance(vals[0], torch.Tensor):
             batch[key] = torch.stack(vals)
         else:
             batch[key] = torch.as_tensor(np.stack([np.asarray(v) for v in vals]))
+    for key in _LIST_KEYS:                       # ... then the ragged keys as lists of tensors, in the reference's order
+        if key in samples[0]:
+            batch[key] = [torch.as_tensor(s[key]) for s in samples]
     return batch
 
 

@@ -7,6 +7,8 @@
   datasets/fewshotiseg/base_fst.py:605-732       BaseFewShotISEG.reshuffle, aspect-ratio-grouped branch (groups by
                                                  rounded w/h, per-group size via get_new_shape rounded to x16,
                                                  padding of groups by re-drawing members, chunking, chunk shuffle)
+  subprojects/sp02_omniiseg_fgn_mmdet/main.py:62-76   collate_fn_new (the batch dict the hot path receives: stacked
+                                                 tensors first, the four ragged query keys as lists of tensors last)
 
 Run in the build container only (needs /root/reference):   python tests/golden/make_golden_data.py
 
@@ -125,9 +127,53 @@ def ar_sizes(n=57, seed=3):
     return sizes
 
 
+def collate_samples():
+    """Two sample dicts shaped like ``BaseFewShotISEG.__getitem__`` yields them (base_fst.py:1248-1266): tensors for the
+    images, numpy arrays / ints for the rest, ragged query annotations."""
+    import torch
+    g = torch.Generator().manual_seed(77)
+    rng = np.random.RandomState(77)
+    out = []
+    for i in range(2):
+        n = 1 + 2 * i
+        out.append({'idx': 40 + i, 'qry_child_idx': 3 + i, 'qry_img': torch.randn(3, 8, 10, generator=g),
+                    'qry_cat_ids_real': rng.randint(0, 20, n), 'qry_cat_ids': rng.randint(0, 3, n),
+                    'qry_bboxes': rng.rand(n, 4).astype(np.float32), 'qry_isegmaps': rng.rand(n, 8, 10) > 0.5,
+                    'spp_imgs': torch.randn(6, 3, 4, 4, generator=g), 'spp_bboxes': rng.rand(6, 4).astype(np.float32),
+                    'spp_isegmaps': rng.rand(6, 4, 4) > 0.5, 'cats_ids_to_sample_real': rng.randint(0, 20, 3),
+                    'cats_ids_to_sample': np.arange(3), 'spp_insts_ids': rng.randint(0, 99, 6),
+                    'img_shape': np.array([8, 10, 3], dtype=np.int32)})
+    return out
+
+
+def import_reference_main():
+    """subprojects/sp02_omniiseg_fgn_mmdet/main.py for its ``collate_fn_new`` (main.py:62-76): mmcv / mmdet and the
+    dataset / detector modules it imports at the top are stand-ins (none is reached by the function)."""
+    for name in ('mmcv', 'mmcv.runner', 'mmcv.runner.hooks', 'mmcv.runner.hooks.logger', 'mmcv.runner.base_module',
+                 'mmdet.utils', 'mmdet.models', 'datasets.fewshotiseg.mnistiseg_fst', 'datasets.fewshotiseg.omniiseg_fst',
+                 'datasets.fewshotiseg.coco_fst', 'datasets.fewshotiseg.voc_fst', 'subprojects.sp02_omniiseg_fgn_mmdet.fgn'):
+        sys.modules[name] = _AnyModule(name)
+    from subprojects.sp02_omniiseg_fgn_mmdet import main as ref_main
+    return ref_main
+
+
 def main():
     cic, base_fst = import_reference()
     store = {}
+    # ---- collate_fn_new (main.py:62-76)
+    import torch
+    ref_main = import_reference_main()
+    batch = ref_main.collate_fn_new(collate_samples())
+    store['collate_keys'] = np.array(list(batch))
+    for k, v in batch.items():
+        if isinstance(v, list):
+            store[f'collate__{k}__n'] = np.array(len(v))
+            for j, t in enumerate(v):
+                assert isinstance(t, torch.Tensor)
+                store[f'collate__{k}__{j}'] = t.numpy()
+        else:
+            assert isinstance(v, torch.Tensor)
+            store[f'collate__{k}'] = v.numpy()
     # ---- get_new_shape
     out = []
     for h, w in new_shape_cases():

@@ -576,3 +576,23 @@ def test_single_thread_randperm_draws_the_same_permutation():
     assert torch.get_num_threads() == k
     g = torch.Generator().manual_seed(3)
     assert _perm(lambda m: torch.randperm(m, generator=g), 5).numel() == 5        # any callable passes through
+
+
+def test_collate_matches_the_reference_collate_fn_new(golden_dir):
+    """tests/golden/data_side.npz holds the batch the reference's own ``collate_fn_new`` (main.py:62-76) builds from two
+    seeded sample dicts: ``episodes.collate`` must give the same keys in the same order, the same container types,
+    dtypes, shapes and values."""
+    from fgn_amd.episodes import collate
+    G = _golden_data_module()
+    z = np.load(os.path.join(golden_dir, 'data_side.npz'))
+    got = collate(G.collate_samples())
+    assert list(got) == [str(k) for k in z['collate_keys']]
+    for k, v in got.items():
+        if isinstance(v, list):
+            assert len(v) == int(z[f'collate__{k}__n'])
+            for j, t in enumerate(v):
+                want = z[f'collate__{k}__{j}']
+                assert isinstance(t, torch.Tensor) and t.numpy().dtype == want.dtype and np.array_equal(t.numpy(), want), (k, j)
+        else:
+            want = z[f'collate__{k}']
+            assert isinstance(v, torch.Tensor) and v.numpy().dtype == want.dtype and np.array_equal(v.numpy(), want), k
