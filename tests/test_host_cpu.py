@@ -596,3 +596,46 @@ def test_collate_matches_the_reference_collate_fn_new(golden_dir):
         else:
             want = z[f'collate__{k}']
             assert isinstance(v, torch.Tensor) and v.numpy().dtype == want.dtype and np.array_equal(v.numpy(), want), k
+
+
+def test_evaluator_records_and_summary_match_the_reference_fsisegeval(tmp_path):
+    """tests/golden/fsiseg_eval.npz holds what the reference's FSISEGEval builds from seeded result pickles
+    (records, parameters, (image, category) grouping) and its summarize_short on a synthetic eval; everything
+    evaluate()/accumulate() do is pycocotools and stays unpinned."""
+    import pickle
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import make_golden_eval as G
+    from fgn_amd.fsiseg_eval import FSISEGEval
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fsiseg_eval.npz'))
+    results = G.make_results()
+    for name, chunk in (('00.pkl', results[:3]), ('01.pkl', results[3:])):
+        with open(tmp_path / name, 'wb') as fh:
+            pickle.dump(chunk, fh)
+    for kind in ('segm', 'bbox'):
+        ev = FSISEGEval(results_pkl_dir_fp=str(tmp_path), n_ways=3, iou_type=kind)
+        imgs, gts, dts = ev.annotations()
+        pre = kind + '__'
+        np.testing.assert_array_equal(np.array([[im['height'], im['width']] for im in imgs]), z[pre + 'imgs'])
+        for tag, recs in (('gt', gts), ('dt', dts)):
+            for key in ('image_id', 'id', 'category_id', 'area'):
+                np.testing.assert_array_equal(np.array([r[key] for r in recs]), z[pre + tag + '_' + key], err_msg=tag + key)
+            np.testing.assert_array_equal(np.array([r['bbox'] for r in recs]).reshape(-1, 4), z[pre + tag + '_bbox'])
+        np.testing.assert_array_equal(np.array([r['score'] for r in dts]), z[pre + 'dt_score'])
+        assert all(r['iscrowd'] == 0 and not r['ignore'] for r in gts) and not z[pre + 'gt_flags'].any()
+        np.testing.assert_array_equal(ev.rec_thrs, z[pre + 'recThrs'])
+        np.testing.assert_array_equal([ev.iou_thr, ev.max_dets, ev.area_rng[0], ev.area_rng[1], 1], z[pre + 'scalars'])
+        np.testing.assert_array_equal(ev.img_ids, z[pre + 'imgIds'])
+        np.testing.assert_array_equal(ev.cat_ids, z[pre + 'catIds'])
+        g, d = ev.groups()
+        n_g = int(z[pre + 'n_gt_groups'])
+        keys, sizes = z[pre + 'group_keys'], z[pre + 'group_sizes']
+        assert sorted(g) == [tuple(k) for k in keys[:n_g]] and [g[k] for k in sorted(g)] == list(sizes[:n_g])
+        assert sorted(d) == [tuple(k) for k in keys[n_g:]] and [d[k] for k in sorted(d)] == list(sizes[n_g:])
+    p, r = G.eval_arrays()
+    ev.eval = {'precision': p[0, :, :, 0, 0], 'recall': r[0, :, 0, 0]}
+    out = ev.summarize_short()
+    np.testing.assert_array_equal([out['mAP'], out['mAR']], z['summary'])
+    ev.eval = {'precision': -np.ones((11, 3)), 'recall': -np.ones(3)}
+    out = ev.summarize_short()
+    np.testing.assert_array_equal([out['mAP'], out['mAR']], z['summary_empty'])
