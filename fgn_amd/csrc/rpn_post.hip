@@ -58,6 +58,7 @@ extern "C" int fgn_rpn_merge_f32(const float* head, float* logits, float* scores
 constexpr int RPN_EPT = 64;
 constexpr int RPN_FAST_SEL = 1536;   // candidates ranked by the fast first attempt
 constexpr int RPN_FAST_CAP = 2048;   // its sort buffer   // scores cached per thread: n_total <= 65536
+constexpr int RPN_MT_WORDS = RPN_FAST_CAP / 64;   // u64 words of one row of the suppression matrix
 
 struct ProposalParams {
     const float* scores;     // [B][n_total]
@@ -72,7 +73,12 @@ struct ProposalParams {
     // multi-workgroup pre-selection (rpn_hist16 / rpn_thresh / rpn_compact / rpn_ranksort kernels): the best
     // pre_info[b][3] <= RPN_FAST_CAP keys of image b, sorted, in pre_sorted[b]; pre_info[b][4] = 1 when valid
     const uint64_t* pre_sorted;   // [B][RPN_FAST_CAP] or null
-    const int32_t* pre_info;      // [B][8]: b1, count before b1, b2, candidate count, ok flag
+    int32_t* pre_info;            // [B][8]: b1, count before b1, b2, candidate count, ok flag, [5] = finished by rpn_matrix_nms_kernel
+    // ... and, from rpn_ranksort / rpn_iou_matrix, their decoded boxes and the suppression bits between them
+    // (null: the proposal kernel decodes and tests the boxes itself)
+    const float4* pre_boxes;      // [B][RPN_FAST_CAP] box of the candidate of each rank
+    const int32_t* pre_valid;     // [B][RPN_FAST_CAP] 1 = passes the min-size test
+    const unsigned long long* pre_mt;   // [B][RPN_FAST_CAP][RPN_MT_WORDS] bit j of row c: the EARLIER candidate j suppresses c
     int n_total, A, feat_w, stride;
     int nms_pre, cap;        // cap = pow2 >= min(nms_pre, n_total)
     float img_h, img_w;
@@ -194,7 +200,11 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
     // RPN_FAST_SEL candidates (sort of 2048 instead of 8192 keys); if NMS cannot fill max_out from
     // them, attempt 1 redoes the stage with the full nms_pre - identical output either way.
     int n_keep = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // rpn_matrix_nms_kernel ran in front on the ranked prefix: finished this image, or could not fill max_out from the
+    // prefix - then attempt 0 here would fail the same way and the stage starts at the full nms_pre
+    if (p.pre_mt && p.pre_info[b * 8 + 5] == 1) return;
+    const int first_attempt = (p.pre_mt && p.pre_info[b * 8 + 4] == 1 && n_sel_full > RPN_FAST_SEL) ? 1 : 0;
+    for (int attempt = first_attempt; attempt < 2; ++attempt) {
         const bool fast = attempt == 0 && n_sel_full > RPN_FAST_SEL;
         if (attempt == 1 && !(n_sel_full > RPN_FAST_SEL)) break;
         int n_sel = fast ? RPN_FAST_SEL : n_sel_full;
@@ -376,6 +386,137 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_proposals_kernel(const Propo
 }
 
 
+// The proposal stage of an image whose best candidates arrive ranked, decoded and IoU-tested from the multi-workgroup
+// kernels in front (rpn_hist / rpn_compact / rpn_ranksort / rpn_iou_matrix): the greedy resolution and the outputs,
+// nothing else - ONE WAVEFRONT, no LDS, no barrier.  (The single workgroup of rpn_proposals_kernel spent 60 of its
+// 76 us on 330 000 IoU tests on one CU and on a walk that took 125 cycles per kept box.)
+// Candidates are taken 64 at a time, one per lane, in rank order:
+//   - lane c is dead when a box kept in an EARLIER chunk suppresses it: its row of `mt` AND the kept bitsets
+//     (uniform: scalar registers; the chunk loop is fully unrolled so every index is static),
+//   - inside the chunk the greedy order is resolved by passes over the whole wavefront: an undecided lane is dead
+//     when a kept lane before it suppresses it, kept when every lane before it that overlaps it is decided dead; the
+//     first undecided lane is always decided, so a pass per link of the longest suppression chain (2-4 in practice,
+//     64 at worst) instead of a step per kept box,
+//   - the kept lanes write their proposal rows at once: slot = boxes kept before.
+// Rows, box and key of a chunk are loaded three chunks ahead (the matrix was written by other XCDs: 1-2 us away).
+// Greedy NMS is a prefix computation, so cutting the last chunk at max_out kept boxes is exact.
+// When the ranked prefix fills max_out (or is the whole nms_pre) the image is finished (pre_info[5] = 1) and
+// rpn_proposals_kernel behind it returns at once; otherwise that kernel redoes the stage on the full nms_pre.
+constexpr int MN_CHUNKS = RPN_FAST_CAP / 64;
+constexpr int MN_AHEAD = 3;
+struct MnChunk {
+    ulonglong2 w[MN_CHUNKS / 2];   // words [0, chunk] of the candidate's row of mt
+    float4 box;
+    uint64_t key;
+    int ok;
+};
+template <int K>
+__device__ __forceinline__ void mn_fetch(MnChunk& o, const unsigned long long* __restrict__ mt, const float4* __restrict__ boxes,
+                                         const uint64_t* __restrict__ keys, const int32_t* __restrict__ valid, int lane) {
+    if (K >= MN_CHUNKS) return;
+    const int c = K * 64 + lane;
+    const ulonglong2* row = reinterpret_cast<const ulonglong2*>(mt + (size_t)c * RPN_MT_WORDS);
+#pragma unroll
+    for (int i = 0; i < MN_CHUNKS / 2; ++i)
+        if (2 * i <= K) o.w[i] = row[i];
+    o.box = boxes[c];
+    o.key = keys[c];
+    o.ok = valid[c];
+}
+__device__ __forceinline__ unsigned long long mn_word(const MnChunk& c, int w) { return (w & 1) ? c.w[w >> 1].y : c.w[w >> 1].x; }
+
+struct MnState {
+    unsigned long long kept[MN_CHUNKS];
+    int kept_cnt;
+    bool stop;
+};
+template <int K>
+__device__ __forceinline__ void mn_chunk(MnState& st, const MnChunk& c, const ProposalParams& p, int b, int n, int lane) {
+    if (K >= MN_CHUNKS || st.stop) return;
+    if (K * 64 >= n || st.kept_cnt >= p.max_out) { st.stop = true; return; }
+    unsigned long long hit = 0ull;
+#pragma unroll
+    for (int w = 0; w < K; ++w) hit |= mn_word(c, w) & st.kept[w];
+    const bool alive = c.ok != 0 && K * 64 + lane < n && hit == 0ull;
+    const unsigned long long E = mn_word(c, K);        // the lanes before this one that overlap it
+    unsigned long long U = __ballot(alive), Kp = 0ull;
+    while (U != 0ull) {
+        const bool und = ((U >> lane) & 1ull) != 0ull;
+        const bool dead = (E & Kp) != 0ull;
+        const bool keep = !dead && (E & U) == 0ull;
+        const unsigned long long nk = __ballot(und && keep), nd = __ballot(und && dead);
+        Kp |= nk;
+        U &= ~(nk | nd);
+    }
+    const int before = __popcll(Kp & ((1ull << lane) - 1ull));
+    const bool mine = ((Kp >> lane) & 1ull) != 0ull && st.kept_cnt + before < p.max_out;
+    Kp = __ballot(mine);
+    if (mine) {
+        const int i = st.kept_cnt + before;
+        float* o = p.proposals + ((size_t)b * p.max_out + i) * 5;
+        o[0] = c.box.x; o[1] = c.box.y; o[2] = c.box.z; o[3] = c.box.w;
+        o[4] = key_score(c.key);
+        if (p.rois) {
+            float* r = p.rois + ((size_t)b * p.max_out + i) * 5;
+            r[0] = (float)b; r[1] = c.box.x; r[2] = c.box.y; r[3] = c.box.z; r[4] = c.box.w;
+        }
+    }
+    st.kept[K] = Kp;
+    st.kept_cnt += __popcll(Kp);
+}
+// chunks K, K+1, K+2 on the three ring slots, then the next three (compile-time recursion: static indices everywhere)
+template <int K>
+__device__ __forceinline__ void mn_run(MnState& st, MnChunk& r0, MnChunk& r1, MnChunk& r2, const ProposalParams& p,
+                                       const unsigned long long* mt, const float4* boxes, const uint64_t* keys,
+                                       const int32_t* valid, int b, int n, int lane) {
+    if constexpr (K < MN_CHUNKS) {
+        mn_chunk<K>(st, r0, p, b, n, lane);
+        if (!st.stop) mn_fetch<K + MN_AHEAD>(r0, mt, boxes, keys, valid, lane);
+        mn_chunk<K + 1>(st, r1, p, b, n, lane);
+        if (!st.stop) mn_fetch<K + 1 + MN_AHEAD>(r1, mt, boxes, keys, valid, lane);
+        mn_chunk<K + 2>(st, r2, p, b, n, lane);
+        if (!st.stop) mn_fetch<K + 2 + MN_AHEAD>(r2, mt, boxes, keys, valid, lane);
+        if (!st.stop) mn_run<K + 3>(st, r0, r1, r2, p, mt, boxes, keys, valid, b, n, lane);
+    }
+}
+
+__global__ __launch_bounds__(64) void rpn_matrix_nms_kernel(const ProposalParams p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    RPN_STAMP(5);
+    if (p.pre_info[b * 8 + 4] != 1) return;
+    const int n = min(p.pre_info[b * 8 + 3], p.nms_pre);
+    const unsigned long long* mt = p.pre_mt + (size_t)b * RPN_FAST_CAP * RPN_MT_WORDS;
+    const float4* boxes = p.pre_boxes + (size_t)b * RPN_FAST_CAP;
+    const uint64_t* keys = p.pre_sorted + (size_t)b * RPN_FAST_CAP;
+    const int32_t* valid = p.pre_valid + (size_t)b * RPN_FAST_CAP;
+    MnState st;
+#pragma unroll
+    for (int w = 0; w < MN_CHUNKS; ++w) st.kept[w] = 0ull;
+    st.kept_cnt = 0;
+    st.stop = false;
+    MnChunk r0, r1, r2;
+    mn_fetch<0>(r0, mt, boxes, keys, valid, lane);
+    mn_fetch<1>(r1, mt, boxes, keys, valid, lane);
+    mn_fetch<2>(r2, mt, boxes, keys, valid, lane);
+    mn_run<0>(st, r0, r1, r2, p, mt, boxes, keys, valid, b, n, lane);
+    const int n_keep = st.kept_cnt;
+    if (n_keep < p.max_out && n < min(p.nms_pre, p.n_total)) return;   // the prefix ran dry: the full stage follows
+    for (int i = n_keep + lane; i < p.max_out; i += 64) {             // zero rows after the kept ones
+        float* o = p.proposals + ((size_t)b * p.max_out + i) * 5;
+        o[0] = o[1] = o[2] = o[3] = o[4] = 0.f;
+        if (p.rois) {
+            float* r = p.rois + ((size_t)b * p.max_out + i) * 5;
+            r[0] = (float)b; r[1] = r[2] = r[3] = r[4] = 0.f;
+        }
+    }
+    if (lane == 0) {
+        p.n_props[b] = n_keep;
+        p.pre_info[b * 8 + 5] = 1;
+        if (p.dbg_topk_idx) p.dbg_topk_idx[(size_t)b * 8192 + 8192 - 16 + 9] = 1;
+    }
+    RPN_STAMP(6);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Multi-workgroup pre-selection for attempt 0 of rpn_proposals_kernel (the single-workgroup radix select,
 // compaction and bitonic sort of ~63 000 scores were 90 us of that kernel's 170 us).  Two histogram levels over the
@@ -493,8 +634,11 @@ __global__ __launch_bounds__(POST_THREADS) void rpn_compact_kernel(const float* 
 // 8 threads per candidate, each counting the smaller keys in its eighth of the list (n^2 = 2.5 M comparisons spread
 // over 64 workgroups; one thread per candidate took 68 us)
 constexpr int RANK_SPLIT = 8;
+// The thread that learns a candidate's rank also decodes its box (delta2bbox + min-size test) to that rank:
+// boxes[rank], valid[rank] feed rpn_iou_matrix_kernel and the proposal kernel (null: keys only).
 __global__ __launch_bounds__(256) void rpn_ranksort_kernel(const uint64_t* __restrict__ cand, const int32_t* __restrict__ info,
-                                                           uint64_t* __restrict__ sorted, int cap) {
+                                                           uint64_t* __restrict__ sorted, int cap, const ProposalParams p,
+                                                           float4* __restrict__ boxes, int32_t* __restrict__ valid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);
     const int b = blockIdx.y;
@@ -517,7 +661,52 @@ __global__ __launch_bounds__(256) void rpn_ranksort_kernel(const uint64_t* __res
     rank += __shfl_xor(rank, 1, 64);
     rank += __shfl_xor(rank, 2, 64);
     rank += __shfl_xor(rank, 4, 64);
-    if (part == 0 && i < n) sorted[(size_t)b * cap + rank] = k;
+    if (part == 0 && i < n) {
+        sorted[(size_t)b * cap + rank] = k;
+        if (boxes) {
+            bool ok = false;
+            boxes[(size_t)b * cap + rank] = rpn_decode_box(p, key_index(k), p.deltas + (size_t)b * p.n_total, &ok);
+            valid[(size_t)b * cap + rank] = ok ? 1 : 0;
+        }
+    }
+}
+
+// Pairwise suppression bits of the ranked candidates of an image: thread (c, w) tests candidate c against the 64
+// candidates j of word w and sets bit j of mt[c][w] when the EARLIER candidate j < c suppresses c (both pass the
+// min-size test).  Grid (word, row block of 64, image); blocks above the diagonal leave at once.
+// iou_gt(earlier, later) as in nms_sorted_block.
+__global__ __launch_bounds__(64) void rpn_iou_matrix_kernel(const int32_t* __restrict__ info, const float4* __restrict__ boxes,
+                                                            const int32_t* __restrict__ valid,
+                                                            unsigned long long* __restrict__ mt, int cap, int nms_pre,
+                                                            float iou_thr) {
+    __shared__ NmsBox col[64];
+    __shared__ int col_ok[64];
+    const int w = blockIdx.x, rb = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    if (info[b * 8 + 4] != 1) return;
+    const int n = min(info[b * 8 + 3], nms_pre);
+    if (rb * 64 >= n || w > rb) return;
+    const size_t o = (size_t)b * cap;
+    {
+        const int j = w * 64 + lane;
+        const float4 v = j < n ? boxes[o + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        col[lane] = make_nms_box(v.x, v.y, v.z, v.w);
+        col_ok[lane] = j < n && valid[o + j] != 0;
+    }
+    __syncthreads();
+    const int c = rb * 64 + lane;
+    if (c >= n) return;
+    const float4 v = boxes[o + c];
+    const NmsBox cb = make_nms_box(v.x, v.y, v.z, v.w);
+    const bool c_ok = valid[o + c] != 0;
+    unsigned long long before = 0ull;
+    if (c_ok) {
+#pragma unroll 4
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = w * 64 + jj;
+            if (j < c && col_ok[jj] && iou_gt(col[jj], cb, iou_thr)) before |= 1ull << jj;
+        }
+    }
+    mt[(o + c) * RPN_MT_WORDS + w] = before;
 }
 
 extern "C" size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nms_pre) {
@@ -525,8 +714,9 @@ extern "C" size_t fgn_rpn_proposals_scratch_bytes(int batch, int n_total, int nm
     int cap = POST_THREADS;
     while (cap < n_sel) cap <<= 1;
     const size_t base = ((size_t)batch * cap * (sizeof(float4) + sizeof(float)) + 255) / 256 * 256;
-    // pre-selection: candidate keys + sorted keys (the zeroed histograms / counters come in `pre_zeroed`)
-    return base + (size_t)batch * (2 * RPN_FAST_CAP * 8);
+    // pre-selection: candidate keys + sorted keys (the zeroed histograms / counters come in `pre_zeroed`), then the
+    // boxes, min-size flags and suppression bits of the ranked candidates
+    return base + (size_t)batch * RPN_FAST_CAP * (2 * 8 + sizeof(float4) + 4 + RPN_MT_WORDS * 8);
 }
 
 // zero-initialised workspace of the pre-selection per call: two 4096-bin histograms + info + counter per image
@@ -565,6 +755,8 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     const hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(rpn_proposals_kernel), &lds_ok);
     if (attr != hipSuccess) return (int)attr;
     p.pre_sorted = nullptr; p.pre_info = nullptr;
+    p.pre_boxes = nullptr; p.pre_valid = nullptr; p.pre_mt = nullptr;
+    static const int use_matrix = getenv("FGN_RPN_MATRIX") ? atoi(getenv("FGN_RPN_MATRIX")) : 1;   // 0: IoU tests inside the proposal kernel
     static const int multi = getenv("FGN_RPN_MULTI") ? atoi(getenv("FGN_RPN_MULTI")) : 1;   // 0: single-workgroup path only
     if (multi && pre_zeroed && n_sel > RPN_FAST_SEL && p.n_total > RPN_FAST_CAP) {
         unsigned char* z = reinterpret_cast<unsigned char*>(pre_zeroed);
@@ -583,10 +775,23 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
                            RPN_FAST_SEL);
         hipLaunchKernelGGL(rpn_compact_kernel, ga, dim3(POST_THREADS), 0, stream, scores, hist2, info, counter, candk,
                            p.n_total, RPN_FAST_SEL, RPN_FAST_CAP);
+        float4* boxes = reinterpret_cast<float4*>(sortedk + (size_t)batch * RPN_FAST_CAP);
+        unsigned long long* mt = reinterpret_cast<unsigned long long*>(boxes + (size_t)batch * RPN_FAST_CAP);
+        int32_t* valid = reinterpret_cast<int32_t*>(mt + (size_t)batch * RPN_FAST_CAP * RPN_MT_WORDS);
+        if (!use_matrix) boxes = nullptr;
         hipLaunchKernelGGL(rpn_ranksort_kernel, dim3(RPN_FAST_CAP * RANK_SPLIT / 256, batch), dim3(256), RPN_FAST_CAP * 8, stream,
-                           candk, info, sortedk, RPN_FAST_CAP);
+                           candk, info, sortedk, RPN_FAST_CAP, p, boxes, valid);
+        if (boxes) {
+            hipLaunchKernelGGL(rpn_iou_matrix_kernel, dim3(RPN_MT_WORDS, RPN_FAST_CAP / 64, batch), dim3(64), 0, stream, info,
+                               boxes, valid, mt, RPN_FAST_CAP, n_sel, iou_thr);
+            p.pre_boxes = boxes; p.pre_valid = valid; p.pre_mt = mt;
+        }
         FGN_LAUNCH_CHECK();
         p.pre_sorted = sortedk; p.pre_info = info;
+        if (boxes) {
+            hipLaunchKernelGGL(rpn_matrix_nms_kernel, dim3(batch), dim3(64), 0, stream, p);
+            FGN_LAUNCH_CHECK();
+        }
     }
     hipLaunchKernelGGL(rpn_proposals_kernel, dim3(batch), dim3(POST_THREADS), lds, stream, p);
     FGN_LAUNCH_CHECK();

@@ -1014,18 +1014,15 @@ class FGN(torch.nn.Module):
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'], cnt_all)
-        dets, labs, n_dets, mrois = [], [], [], []
-        for i in range(B):                                                         # one selection workgroup per image
-            det, lab, n_det, mr = ops.det_post(rois_all[i * R:(i + 1) * R], cls_raw[i * R * N:(i + 1) * R * N],
-                                               reg_raw[i * R * N:(i + 1) * R * N], N, ih, iw, bh['target_means'],
-                                               bh['target_stds'], tc['rcnn']['score_thr'],
-                                               tc['rcnn']['nms_iou_threshold'], D, n_props[i:i + 1], img_index=i)
-            dets.append(det); labs.append(lab); n_dets.append(n_det); mrois.append(mr)
+        # one selection workgroup per image, one launch for the batch
+        det_all, lab_all, n_det_all, mrois_all = ops.det_post(
+            rois_all, cls_raw, reg_raw, N, ih, iw, bh['target_means'], bh['target_stds'], tc['rcnn']['score_thr'],
+            tc['rcnn']['nms_iou_threshold'], D, n_props, img_index=0, batch=B)      # mrois_all [B*D,5] = bbox2roi
+        dets = [det_all[i * D:(i + 1) * D] for i in range(B)]
+        labs = [lab_all[i * D:(i + 1) * D] for i in range(B)]
+        n_dets = [n_det_all[i:i + 1] for i in range(B)]
         # ---- mask head on the detections of all images at once (fgn_roi_head.py:704-718, 360-382)
-        det_all = dets[0] if B == 1 else torch.cat(dets)
-        lab_all = labs[0] if B == 1 else torch.cat(labs)
         nd_all = n_dets[0] if B == 1 else None
-        mrois_all = mrois[0] if B == 1 else torch.cat(mrois)                       # [B*D,5] = bbox2roi of the detections
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
         _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
         mlog, mprob = self._mask_head(mf, vmask, nd_all)

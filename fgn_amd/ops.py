@@ -790,28 +790,39 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
 
 def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n_ways: int, img_h: int, img_w: int,
              means, stds, score_thr: float, iou_thr: float, max_per_img: int,
-             n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False, img_index: Optional[int] = None):
+             n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False, img_index: Optional[int] = None,
+             batch: int = 1):
     """-> det [max_per_img,5], labels, n_det (+ with ``img_index``: mask RoIs [max_per_img,5] = (img_index, box), the
-    mask branch's bbox2roi, fgn_roi_head.py:654)."""
+    mask branch's bbox2roi, fgn_roi_head.py:654).  ``batch`` > 1: the RoIs of ``batch`` images stacked ([batch*R,5],
+    ``n_rois_dev`` [batch] when given), one workgroup per image in one launch; outputs stacked the same way
+    ([batch*max_per_img,5], ..., n_det [batch]), image i carrying index ``img_index + i``."""
     for t, nm in ((rois, 'rois'), (cls_raw, 'cls_raw'), (reg_raw, 'reg_raw')):
         _chk(t, nm)
-    r = rois.shape[0]
-    if rois.shape[1] != 5 or tuple(cls_raw.shape) != (r * n_ways, 2) or tuple(reg_raw.shape) != (r * n_ways, 4):
+    if batch < 1 or rois.shape[0] % batch:
+        raise _lib.FgnHipError('det_post: the RoI rows are not a multiple of batch')
+    r = rois.shape[0] // batch
+    if rois.shape[1] != 5 or tuple(cls_raw.shape) != (batch * r * n_ways, 2) or \
+            tuple(reg_raw.shape) != (batch * r * n_ways, 4):
         raise _lib.FgnHipError('det_post: operand shapes inconsistent')
+    if n_rois_dev is not None and n_rois_dev.numel() < batch:
+        raise _lib.FgnHipError('det_post: n_rois_dev holds fewer counts than batch')
     L = _lib.load()
-    scratch = torch.empty(L.fgn_det_post_scratch_bytes(r, n_ways), device=rois.device, dtype=torch.uint8)
-    det = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32)
-    lab = torch.empty((max_per_img,), device=rois.device, dtype=torch.int64)
-    n_det = zeros((1,), rois.device, torch.int32)
-    mrois = torch.empty((max_per_img, 5), device=rois.device, dtype=torch.float32) if img_index is not None else None
-    dbg = torch.zeros((r, n_ways + 1), device=rois.device, dtype=torch.float32) if debug_scores else None
+    scratch = torch.empty(batch * L.fgn_det_post_scratch_bytes(r, n_ways), device=rois.device, dtype=torch.uint8)
+    det = torch.empty((batch * max_per_img, 5), device=rois.device, dtype=torch.float32)
+    lab = torch.empty((batch * max_per_img,), device=rois.device, dtype=torch.int64)
+    n_det = zeros((batch,), rois.device, torch.int32)
+    mrois = torch.empty((batch * max_per_img, 5), device=rois.device, dtype=torch.float32) \
+        if img_index is not None else None
+    # softmax scores [r, n_ways + 1] of the first image followed by 16 words of phase stamps (tools/post_time.py)
+    dbg = torch.zeros((r * (n_ways + 1) + 16,), device=rois.device, dtype=torch.float32) if debug_scores else None
     rc = L.fgn_det_post_f32(_ptr(rois), _ptr(cls_raw), _ptr(reg_raw), _ptr(n_rois_dev), _ptr(scratch), _ptr(det),
-                            _ptr(mrois), int(img_index or 0), _ptr(lab), _ptr(n_det), _ptr(dbg), r, n_ways,
+                            _ptr(mrois), int(img_index or 0), _ptr(lab), _ptr(n_det), _ptr(dbg), batch, r, n_ways,
                             float(img_h), float(img_w), _f4(means),
                             _f4(stds), MAX_RATIO, float(score_thr), float(iou_thr), max_per_img, _stream())
     _lib.check(rc, 'fgn_det_post_f32')
     if debug_scores:
-        return det, lab, n_det, dbg
+        det_post.last_stamps = dbg[r * (n_ways + 1):].view(torch.int32)
+        return det, lab, n_det, dbg[:r * (n_ways + 1)].view(r, n_ways + 1)
     if img_index is not None:
         return det, lab, n_det, mrois
     return det, lab, n_det

@@ -193,14 +193,18 @@ int fgn_rpn_proposals_f32(const float* scores, const float* deltas, const float*
                           const float* host_means4, const float* host_stds4, float max_ratio, int nms_pre,
                           float min_bbox_size, float iou_thr, int max_per_img, void* stream);
 
-/* count_modified_cls_bbox + BBoxHead.get_bboxes + multiclass_nms for one image
- * (fgn_roi_head.py:302-326, 606-613). det_bboxes [max_per_img,5], det_labels int64 [max_per_img]. */
-size_t fgn_det_post_scratch_bytes(int max_rois, int n_ways);
+/* count_modified_cls_bbox + BBoxHead.get_bboxes + multiclass_nms, one workgroup per image
+ * (fgn_roi_head.py:302-326, 606-613).  `batch` images with n_rois RoIs each, stacked: rois [batch*n_rois,5],
+ * cls_raw [batch*n_rois*n_ways,2], reg_raw [batch*n_rois*n_ways,4], n_rois_dev (optional) [batch];
+ * det_bboxes [batch*max_per_img,5], det_labels int64 [batch*max_per_img], n_dets [batch]; image i carries
+ * image index img_index + i in mask_rois_out.  scratch: batch * fgn_det_post_scratch_bytes() bytes. */
+size_t fgn_det_post_scratch_bytes(int max_rois, int n_ways);   /* per image */
 int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_raw, const int32_t* n_rois_dev,
                      void* scratch, float* det_bboxes, float* mask_rois_out /* optional [max_per_img,5]: (img_index, box),
                      the mask branch's bbox2roi, fgn_roi_head.py:654 */, int img_index, int64_t* det_labels, int32_t* n_dets,
-                     float* dbg_scores,
-                     int n_rois, int n_ways, float img_h, float img_w, const float* host_means4,
+                     float* dbg_scores /* optional, tests / diagnostics: n_rois*(n_ways+1) softmax scores of the first image
+                     + 16 words of phase stamps */,
+                     int batch, int n_rois, int n_ways, float img_h, float img_w, const float* host_means4,
                      const float* host_stds4, float max_ratio, float score_thr, float iou_thr, int max_per_img,
                      void* stream);
 

@@ -184,11 +184,12 @@ def test_relation_head_matches_oracle(gw):
 
 
 # ---------------------------------------------------------------- proposals: bit-exact
-def _proposal_case(seed, fh, fw, nms_pre, max_out, ties, img=None):
+def _proposal_case(seed, fh, fw, nms_pre, max_out, ties, img=None, min_size=0):
     from fgn_amd import ops
     from fgn_amd.config import fgn_r50_c4_config, with_caps
     from oracle import fgn_ref_cpu as O
     cfg = with_caps(fgn_r50_c4_config(3, 3), nms_pre=nms_pre, rpn_max=max_out)
+    cfg['test_cfg']['rpn']['min_bbox_size'] = min_size
     g = torch.Generator().manual_seed(seed)
     cls = torch.randn(15, fh, fw, generator=g) * 3
     if ties:
@@ -204,7 +205,7 @@ def _proposal_case(seed, fh, fw, nms_pre, max_out, ties, img=None):
     anchors = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'], rp['anchor_stride']))
     assert np.array_equal(anchors.numpy(), O.base_anchors(rp['anchor_scales'], rp['anchor_ratios'], 16))
     props, n = ops.rpn_proposals(scores.cuda(), deltas.cuda(), anchors.cuda(), fh, fw, 16, ih, iw,
-                                 rp['target_means'], rp['target_stds'], nms_pre, 0, 0.7, max_out)
+                                 rp['target_means'], rp['target_stds'], nms_pre, min_size, 0.7, max_out)
     n = int(n.item())
     got = props[0, :n].cpu().numpy()
     assert n == len(ref), (n, len(ref))
@@ -220,6 +221,31 @@ def test_proposals_bit_exact_small(seed):
 @pytest.mark.parametrize('ties', [False, True])
 def test_proposals_bit_exact_cfg3_size(ties):
     _proposal_case(7, 50, 84, 6000, 300, ties, img=(800, 1333))    # 63 000 anchors -> 6000 -> 300
+
+
+def test_proposals_bit_exact_with_boxes_under_the_minimum_size():
+    """Candidates that fail the min-size test sit between the ranked ones: never kept, never suppressing (the
+    multi-workgroup IoU matrix carries them as invalid rows / columns)."""
+    _proposal_case(11, 50, 84, 6000, 300, ties=False, img=(800, 1333), min_size=40)
+    _proposal_case(12, 50, 84, 6000, 300, ties=True, img=(800, 1333), min_size=90)
+
+
+def test_proposals_batch_of_two_images_equals_single_images():
+    from fgn_amd import ops
+    from fgn_amd.config import fgn_r50_c4_config
+    rp = fgn_r50_c4_config(3, 3)['rpn_head']
+    g = torch.Generator().manual_seed(21)
+    fh, fw = 50, 84
+    scores = torch.sigmoid(torch.randn(2, fh * fw * 15, generator=g) * 3).cuda()
+    deltas = (torch.randn(2, fh * fw * 15, 4, generator=g) * 0.5).cuda()
+    anchors = torch.from_numpy(ops.base_anchors(rp['anchor_scales'], rp['anchor_ratios'], 16)).cuda()
+    run = lambda s, d: ops.rpn_proposals(s, d, anchors, fh, fw, 16, 800, 1333, rp['target_means'], rp['target_stds'],
+                                         6000, 0, 0.7, 300, with_rois=True)
+    props, n, rois = run(scores, deltas)
+    for i in range(2):
+        p1, n1, r1 = run(scores[i:i + 1].contiguous(), deltas[i:i + 1].contiguous())
+        assert int(n1[0]) == int(n[i]) and torch.equal(p1[0], props[i])
+        assert torch.equal(r1[:, 1:], rois[i * 300:(i + 1) * 300, 1:]) and float(rois[i * 300, 0]) == i
 
 
 def test_proposals_bit_exact_odd_caps():
@@ -276,6 +302,28 @@ def test_det_post_bit_exact(n_ways, r, seed):
     cs2, bp2 = O.count_modified_cls_bbox(h, cls_raw[:h * n_ways], reg_raw[:h * n_ways], n_ways)
     rb2, rl2 = O.bbox_get_bboxes(rois[:h].numpy(), cs2.numpy(), bp2.numpy(), np.array([ih, iw, 3]), cfg)
     assert np.array_equal(det2[:int(n2.item())].cpu().numpy(), rb2)
+
+
+def test_det_post_batch_of_images_in_one_launch_equals_one_launch_per_image():
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, r, n_ways, ih, iw = 3, 200, 3, 800, 1333
+    x1 = torch.rand(B * r, generator=g) * iw * 0.8
+    y1 = torch.rand(B * r, generator=g) * ih * 0.8
+    rois = torch.stack([torch.arange(B * r) // r, x1, y1, x1 + torch.rand(B * r, generator=g) * 300 + 1,
+                        y1 + torch.rand(B * r, generator=g) * 200 + 1], 1).float().cuda()
+    cls_raw = (torch.randn(B * r * n_ways, 2, generator=g) * 2).cuda()
+    reg_raw = torch.randn(B * r * n_ways, 4, generator=g).cuda()
+    cnt = torch.tensor([r, r // 2, 7], dtype=torch.int32, device='cuda')
+    args = (n_ways, ih, iw, (0, 0, 0, 0), (.1, .1, .2, .2), 0.05, 0.5, 100)
+    det, lab, n, mr = ops.det_post(rois, cls_raw, reg_raw, *args, n_rois_dev=cnt, img_index=0, batch=B)
+    for i in range(B):
+        d1, l1, n1, m1 = ops.det_post(rois[i * r:(i + 1) * r], cls_raw[i * r * n_ways:(i + 1) * r * n_ways],
+                                      reg_raw[i * r * n_ways:(i + 1) * r * n_ways], *args, n_rois_dev=cnt[i:i + 1],
+                                      img_index=i)
+        assert int(n1[0]) == int(n[i]) and int(n1[0]) > 0
+        assert torch.equal(d1, det[i * 100:(i + 1) * 100]) and torch.equal(l1, lab[i * 100:(i + 1) * 100])
+        assert torch.equal(m1, mr[i * 100:(i + 1) * 100])
 
 
 def test_det_post_matches_reference_golden_cls_mod(golden_dir):
