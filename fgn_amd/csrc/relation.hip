@@ -16,32 +16,71 @@
 #include "common.h"
 
 constexpr int REL_MAX_N = 8;
-constexpr int REL_WAVES = 8;     // 32-channel slabs per workgroup: one per wave
+constexpr int REL_WAVES = 4;     // 32-channel slabs per workgroup: one per wave
+
+// Lane exchanges through the DPP path of the VALU (no LDS crossbar): the lane whose index differs in bit 0 / bit 1
+// (quad permutes), the other quad of an aligned group of 8 (half-row mirror: exact once the 4 lanes of every quad
+// hold equal values), the lane 8 on in its row of 16.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_f32<0xB1>(v); }        // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_f32<0x4E>(v); }        // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float other_quad(float v) { return dpp_f32<0x141>(v); }      // row_half_mirror
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_f32<0x128>(v); }       // row_ror:8
+// sum over the four rows of 16 lanes, every lane of a row holding the row's value: scalar reads, the result is uniform
+__device__ __forceinline__ float sum_rows(float v) {
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+// v + the value of the lane 16 / 32 on or back (butterfly step across rows / halves): the gfx950 row and half swaps
+typedef unsigned rel_v2u __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float add_xor16(float v) {
+    const rel_v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float v) {
+    const rel_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // Mapping: a wave owns one 32-channel slab (one GroupNorm group of the reference's GN(32, 1024); 2 or 4 groups for
 // narrower heads) x 49 pixels of one RoI: lane = (pixel slot 0..7, channel quad 0..7), 7 float4 per lane stay in
 // registers across the N classes.  A workgroup holds REL_WAVES slabs of one RoI; grid = R x (C / 32 / REL_WAVES), i.e.
-// 1200 workgroups for 300 RoIs x 1024 channels - round 2 ran one workgroup per RoI with every wave looping over four
-// slabs x N classes, a serial chain of dependent load -> shuffle-reduce -> normalise steps that took 90 us for 60 MB.
-// Statistics are two-pass in registers (mean, then centred sum of squares) with wavefront xor-shuffle reductions.
+// 2400 workgroups of 4 waves for 300 RoIs x 1024 channels.  History: one workgroup per RoI with every wave looping
+// over four slabs x N classes took 90 us for 60 MB (round 2); one slab per wave in 8-wave workgroups 48 us (168
+// VGPRs: one workgroup per CU, every class a serial load -> LDS-crossbar reductions chain).  Now the classes are
+// unrolled (template NW) with the NEXT class's support slab in flight while the current one is normalised, the
+// reductions run on DPP + scalar lane reads (no ds_bpermute where the group is the whole wave), the fc products are
+// taken per lane BEFORE the reduction (six wave sums instead of a pooled vector + six dot reductions), and the register
+// budget is held at 168 (3 waves per SIMD; 150 used at three classes).
+// Statistics are two-pass in registers (mean, then centred sum of squares).
 // The fc products are reduced per workgroup in a fixed order and written as partials [R][chunks][N][6];
 // relation_fc_finalize_kernel adds the chunks in chunk order and the bias (bit-reproducible: no float atomics).
-__global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
+template <int NW, bool REL_OUT>
+__global__ __launch_bounds__(64 * REL_WAVES, NW <= 4 ? 3 : 2) void relation_head_kernel(
     const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ rois,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ fcw,
-    float* __restrict__ fc_part, const int32_t* __restrict__ n_rois_dev, int n_rois, int n_ways, int C, int gw, float eps,
+    float* __restrict__ fc_part, const int32_t* __restrict__ n_rois_dev, int n_rois, int C, int gw, float eps,
     int chunks, float* __restrict__ rel_out) {
     constexpr int P = 49;
     // a wave covers 32 consecutive channels = 32 / gw GroupNorm groups (gw = channels per group: 8, 16 or 32);
     // statistics are reduced over the lanes of one group: all 8 pixel slots (lane bits 3..5) and the channel
     // quads of the group (lane bits below log2(gw / 4))
     auto group_sum = [gw](float v) {
-#pragma unroll
-        for (int off = 32; off >= 8; off >>= 1) v += __shfl_xor(v, off, 64);
-        for (int off = (gw >> 3); off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;
+        v += lane_xor1(v);                       // gw >= 8: two quads
+        if (gw >= 16) v += lane_xor2(v);
+        if (gw == 32) v += other_quad(v);
+        v += lane_xor8(v);                       // pixel slots 0..7: lane bits 3..5
+        if (gw == 32) return sum_rows(v);        // the group is the whole wave
+        return add_xor32(add_xor16(v));
     };
-    __shared__ float fc_acc[REL_WAVES][REL_MAX_N][6];
+    __shared__ float fc_acc[REL_WAVES][NW][6];
     const int r = blockIdx.x / chunks, chunk = blockIdx.x - r * chunks;
     int nr = n_rois;
     if (n_rois_dev) nr = min(nr, *n_rois_dev);
@@ -55,92 +94,101 @@ __global__ __launch_bounds__(64 * REL_WAVES) void relation_head_kernel(
     const bool active = g * 32 < C;
     if (active) {
         const int c = g * 32 + quad * 4;
-        float4 q[7];
+        // pixel 48 = slot 0 of the seventh sweep; the other slots have 6 pixels and carry zeros (masked by m7) there
+        const bool last = slot == 0;
+        const float m7s = last ? 1.f : 0.f;
+        const v2f m7 = {m7s, m7s};
+        struct Slab { v2f lo[7], hi[7]; };      // 7 pixels x 4 channels as pairs: the arithmetic below is v_pk_*_f32
+        auto load_slab = [&](const float* base, Slab& o) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int p = slot + 8 * i;
-            q[i] = (p < P) ? *reinterpret_cast<const float4*>(Q + ((size_t)r * P + p) * C + c)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 be = *reinterpret_cast<const float4*>(beta + c);
-        float4 fw[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const float4*>(fcw + (size_t)j * C + c);
+            for (int i = 0; i < 7; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < 6 || last) v = *reinterpret_cast<const float4*>(base + (size_t)(slot + 8 * i) * C);
+                o.lo[i] = v2f{v.x, v.y};
+                o.hi[i] = v2f{v.z, v.w};
+            }
+        };
+        Slab q, sbuf[2];
+        load_slab(Q + (size_t)r * P * C + c, q);
+        load_slab(S + (size_t)(img * NW) * P * C + c, sbuf[0]);
+        const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be4 = *reinterpret_cast<const float4*>(beta + c);
+        const v2f ga_lo = {ga4.x, ga4.y}, ga_hi = {ga4.z, ga4.w}, be_lo = {be4.x, be4.y}, be_hi = {be4.z, be4.w};
+        const v2f zero2 = {0.f, 0.f};
 
-        for (int n = 0; n < n_ways; ++n) {
-            const float* Sn = S + ((size_t)(img * n_ways + n) * P) * C + c;
-            float4 x[7];
-            float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            Slab& x = sbuf[n & 1];              // x = q + s in place; the other buffer receives the next class
+            if (n + 1 < NW) load_slab(S + (size_t)(img * NW + n + 1) * P * C + c, sbuf[(n + 1) & 1]);
+            v2f sum2 = zero2;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                const int p = slot + 8 * i;
-                if (p < P) {
-                    const float4 s = *reinterpret_cast<const float4*>(Sn + (size_t)p * C);
-                    x[i] = make_float4(q[i].x + s.x, q[i].y + s.y, q[i].z + s.z, q[i].w + s.w);
-                    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-                } else {
-                    x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                x.lo[i] += q.lo[i];
+                x.hi[i] += q.hi[i];
+                sum2 += x.lo[i];
+                sum2 += x.hi[i];
             }
-            const float mean = group_sum(sum) * inv_cnt;
-            float sq = 0.f;
+            const float mean = group_sum(sum2.x + sum2.y) * inv_cnt;
+            const v2f mean2 = {mean, mean};
+            v2f sq2 = zero2;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                const int p = slot + 8 * i;
-                if (p < P) {
-                    const float a = x[i].x - mean, b = x[i].y - mean, d = x[i].z - mean, e = x[i].w - mean;
-                    sq += (a * a + b * b) + (d * d + e * e);
+                x.lo[i] -= mean2;
+                x.hi[i] -= mean2;
+                if (i == 6) {                   // no pixel there for slots 1..7
+                    x.lo[i] *= m7;
+                    x.hi[i] *= m7;
                 }
+                sq2 = __builtin_elementwise_fma(x.lo[i], x.lo[i], sq2);
+                sq2 = __builtin_elementwise_fma(x.hi[i], x.hi[i], sq2);
             }
-            const float var = group_sum(sq) * inv_cnt;
+            const float var = group_sum(sq2.x + sq2.y) * inv_cnt;
             const float rstd = 1.f / sqrtf(var + eps);
-            float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
+            const v2f rg_lo = ga_lo * rstd, rg_hi = ga_hi * rstd;
+            v2f pool_lo = zero2, pool_hi = zero2;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                const int p = slot + 8 * i;
-                if (p < P) {
-                    const float4 y = make_float4(fmaxf((x[i].x - mean) * rstd * ga.x + be.x, 0.f),
-                                                 fmaxf((x[i].y - mean) * rstd * ga.y + be.y, 0.f),
-                                                 fmaxf((x[i].z - mean) * rstd * ga.z + be.z, 0.f),
-                                                 fmaxf((x[i].w - mean) * rstd * ga.w + be.w, 0.f));
-                    pool.x += y.x; pool.y += y.y; pool.z += y.z; pool.w += y.w;
-                    // parity tests only: the relation feature map the reference materialises (fgn_roi_head.py:274)
-                    if (rel_out) *reinterpret_cast<float4*>(rel_out + (((size_t)r * n_ways + n) * P + p) * C + c) = y;
+                v2f y_lo = __builtin_elementwise_max(__builtin_elementwise_fma(x.lo[i], rg_lo, be_lo), zero2);
+                v2f y_hi = __builtin_elementwise_max(__builtin_elementwise_fma(x.hi[i], rg_hi, be_hi), zero2);
+                if (i == 6) {
+                    y_lo *= m7;
+                    y_hi *= m7;
                 }
+                pool_lo += y_lo;
+                pool_hi += y_hi;
+                // parity tests only: the relation feature map the reference materialises (fgn_roi_head.py:274)
+                if (REL_OUT && (i < 6 || last))
+                    *reinterpret_cast<float4*>(rel_out + (((size_t)r * NW + n) * P + slot + 8 * i) * C + c) =
+                        make_float4(y_lo.x, y_lo.y, y_hi.x, y_hi.y);
             }
-            // reduce over the 8 pixel slots (lanes differing in bits 3..5), then over quads
-            float dots[6];
+            // average pool: sum over the 8 pixel slots (lane bits 3..5) - every lane ends with the pooled values of its
+            // four channels -, then fc_cls / fc_reg: 4 products per lane and a sum over the 8 channel quads (lane bits 0..2)
+            float pl[4] = {pool_lo.x, pool_lo.y, pool_hi.x, pool_hi.y};
 #pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
-                pool.x += __shfl_xor(pool.x, off, 64);
-                pool.y += __shfl_xor(pool.y, off, 64);
-                pool.z += __shfl_xor(pool.z, off, 64);
-                pool.w += __shfl_xor(pool.w, off, 64);
+            for (int k = 0; k < 4; ++k) {
+                pl[k] += lane_xor8(pl[k]);
+                pl[k] = add_xor16(pl[k]);
+                pl[k] = add_xor32(pl[k]);
             }
             const float ip = 1.f / (float)P;
-            pool.x *= ip; pool.y *= ip; pool.z *= ip; pool.w *= ip;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                float d = (pool.x * fw[j].x + pool.y * fw[j].y) + (pool.z * fw[j].z + pool.w * fw[j].w);
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
-                dots[j] = d;
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) fc_acc[wv][n][j] = dots[j];
+                const float4 fw = *reinterpret_cast<const float4*>(fcw + (size_t)j * C + c);
+                float d = (pl[0] * fw.x + pl[1] * fw.y) + (pl[2] * fw.z + pl[3] * fw.w);
+                d += lane_xor1(d);
+                d += lane_xor2(d);
+                d += other_quad(d);
+                if (lane == 0) fc_acc[wv][n][j] = d * ip;
             }
         }
     }
     __syncthreads();
-    if (t < n_ways * 6) {
+    if (t < NW * 6) {
         const int n = t / 6, j = t - n * 6;
         const int waves = min(REL_WAVES, C / 32 - chunk * REL_WAVES);
         float v = 0.f;
         for (int w = 0; w < waves; ++w) v += fc_acc[w][n][j];     // fixed order
-        fc_part[(((size_t)r * chunks + chunk) * n_ways + n) * 6 + j] = v;
+        fc_part[(((size_t)r * chunks + chunk) * NW + n) * 6 + j] = v;
     }
 }
 
@@ -179,8 +227,21 @@ extern "C" int fgn_relation_gn_head_f32(const float* Q, const float* S, const fl
     if (gw != 8 && gw != 16 && gw != 32) return FGN_ERR_SHAPE;
     if (n_rois == 0) return FGN_OK;
     const int chunks = cdiv(C / 32, REL_WAVES);
-    hipLaunchKernelGGL(relation_head_kernel, dim3(n_rois * chunks), dim3(64 * REL_WAVES), 0, stream, Q, S, rois, gn_weight,
-                       gn_bias, fc_weight, scratch, n_rois_dev, n_rois, n_ways, C, gw, eps, chunks, rel_out_debug);
+#define REL_LAUNCH(NW)                                                                                                  \
+    case NW:                                                                                                            \
+        if (rel_out_debug)                                                                                              \
+            hipLaunchKernelGGL((relation_head_kernel<NW, true>), dim3(n_rois * chunks), dim3(64 * REL_WAVES), 0, stream, Q, S, \
+                               rois, gn_weight, gn_bias, fc_weight, scratch, n_rois_dev, n_rois, C, gw, eps, chunks,    \
+                               rel_out_debug);                                                                          \
+        else                                                                                                            \
+            hipLaunchKernelGGL((relation_head_kernel<NW, false>), dim3(n_rois * chunks), dim3(64 * REL_WAVES), 0, stream, Q, S, \
+                               rois, gn_weight, gn_bias, fc_weight, scratch, n_rois_dev, n_rois, C, gw, eps, chunks,    \
+                               rel_out_debug);                                                                          \
+        break;
+    switch (n_ways) {
+        REL_LAUNCH(1) REL_LAUNCH(2) REL_LAUNCH(3) REL_LAUNCH(4) REL_LAUNCH(5) REL_LAUNCH(6) REL_LAUNCH(7) REL_LAUNCH(8)
+    }
+#undef REL_LAUNCH
     FGN_LAUNCH_CHECK();
     const int total = n_rois * n_ways * 6;
     hipLaunchKernelGGL(relation_fc_finalize_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, scratch, fc_bias, cls_out,
