@@ -55,8 +55,7 @@ st = dbg[0, 8192 - 16: 8192 - 16 + 10].cpu().numpy().astype(np.int64)
 print(f'rpn_proposals ({which}): n_props {int(n_p.item())}; whole pipeline (hist x2, compact, ranksort + decode, IoU matrix, '
       f'matrix NMS, proposals) {wall(rpn):.1f} us per call')
 if st[9] > 0:     # rpn_matrix_nms_kernel finished the image: its own stamps
-    print(f'  matrix NMS kernel: resolution + outputs {(st[6] - st[5]) / 100.0:.1f} us, of which serial walks '
-          f'{st[8] / 100.0:.1f} us over {st[9]} rounds')
+    print(f'  rpn_matrix_nms_kernel (one wavefront): resolution + outputs {(st[6] - st[5]) / 100.0:.1f} us')
 else:
     for i, nm in enumerate(['load', 'select', 'compact', 'sort', 'decode', 'nms+out']):
         print(f'  {nm:10s} {(st[i + 1] - st[i]) / 100.0:8.1f} us')
