@@ -20,6 +20,7 @@ without host synchronisation until the final device-to-host copy of the results.
 from __future__ import annotations
 
 import copy
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
@@ -300,7 +301,10 @@ class _GraphedEpisode:
         model._detect_eager(*args())
         torch.cuda.current_stream().synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: only this thread's calls are checked against the capture, so nothing another
+        # thread does (the watchdog of an RCCL process group polling the all-gather of the previous step) can
+        # invalidate it.  (The global mode passed the same test on this torch build; FGN_GRAPH_CAPTURE_MODE selects.)
+        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get('FGN_GRAPH_CAPTURE_MODE', 'thread_local')):
             self.outs = model._detect_eager(*args())
 
     def run(self, model, ins: dict, support_code, main) -> list:

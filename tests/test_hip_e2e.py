@@ -195,6 +195,48 @@ def test_rccl_gather_single_rank():
         dist.destroy_process_group()
 
 
+def test_graph_capture_with_an_rccl_collective_in_flight():
+    """bench.py at N > 1: every caller stream captures its hipGraph during set-up while the all-gather of the previous
+    step may still be polled by the process group's watchdog thread.  One rank is all this box hosts: the collective
+    is issued on its own stream right before the second capture; results must equal the eager ones."""
+    import os
+    import torch.distributed as dist
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29300 + os.getpid() % 300))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        cfg = tiny_config(3, 2, width_div=2)
+        model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                    test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+        batch = make_batch(4, 1, 3, 2, 160, 224, 64)
+        ref = model.simple_test(**batch, rescale=True)
+        model.use_graphs = True
+        msg = torch.rand(1 << 20, device='cuda')
+        out = torch.empty_like(msg)
+        comm = torch.cuda.Stream()
+        got = []
+        for st in (torch.cuda.Stream(), torch.cuda.Stream()):          # one capture per caller stream
+            with torch.cuda.stream(comm):
+                for _ in range(8):
+                    dist.all_gather_into_tensor(out, msg)               # in flight / polled while the capture runs
+            with torch.cuda.stream(st):
+                got.append(model.simple_test(**batch, rescale=True))
+        torch.cuda.synchronize()
+        assert torch.equal(out, msg) and len(model._graphs) == 2
+        for g in got:
+            for x, y in zip(g, ref):
+                assert len(y['dt_scores']) > 0
+                for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+                    assert np.array_equal(x[key], y[key]), key
+                assert x['dt_isegmaps_rle'] == y['dt_isegmaps_rle']
+    finally:
+        dist.destroy_process_group()
+
+
 def test_cfg3_full_size_parity_and_invariants():
     """The headline configuration itself (3-way 3-shot, 800x1333, full ResNet-50-C4, R<=300, D<=100):
     parity against the oracle, plus size-independent properties of the output."""
