@@ -230,6 +230,60 @@ def test_proposals_bit_exact_with_boxes_under_the_minimum_size():
     _proposal_case(12, 50, 84, 6000, 300, ties=True, img=(800, 1333), min_size=90)
 
 
+@pytest.mark.parametrize('shift', [10.0, 3.0])
+def test_proposals_bit_exact_on_suppression_chains(shift):
+    """Worst case of the wavefront NMS: the ranked boxes form staircases (box k overlaps only its neighbours, or with
+    the smaller shift its next few), so inside a 64-candidate chunk every decision hangs on the one before - as many
+    passes as lanes -, and the chains run across chunk boundaries.  Expected: the oracle's sequential greedy NMS."""
+    from fgn_amd import ops
+    from fgn_amd.config import fgn_r50_c4_config
+    from oracle import fgn_ref_cpu as O
+    from oracle import fgn_train_cpu as OT
+    cfg = fgn_r50_c4_config(3, 3)
+    rp = cfg['rpn_head']
+    fh, fw, ih, iw, A = 50, 84, 800, 1333, 15
+    base = O.base_anchors(rp['anchor_scales'], rp['anchor_ratios'], rp['anchor_stride'])
+    anchors = O.grid_anchors(base, fh, fw, rp['anchor_stride'])                 # [fh*fw*A, 4], index = (y*fw + x)*A + a
+    n_chain, per_row = 1200, 120
+    k = np.arange(n_chain)
+    bx = 20.0 + shift * (k % per_row)
+    by = 20.0 + 72.0 * (k // per_row)
+    target = np.stack([bx, by, bx + 64.0, by + 64.0], 1).astype(np.float32)
+    # one anchor per chain box: the anchor whose centre is nearest, a different one for every box
+    cx, cy = (target[:, 0] + target[:, 2]) / 2, (target[:, 1] + target[:, 3]) / 2
+    px = np.clip(np.round(cx / 16).astype(int), 0, fw - 1)
+    py = np.clip(np.round(cy / 16).astype(int), 0, fh - 1)
+    used, idx = set(), []
+    for i in range(n_chain):
+        for a in range(A):
+            j = (py[i] * fw + px[i]) * A + a
+            if j not in used:
+                used.add(j); idx.append(j)
+                break
+        else:
+            raise AssertionError('ran out of anchors at a pixel')
+    idx = np.array(idx)
+    deltas = np.zeros((fh * fw * A, 4), np.float32)
+    deltas[idx] = OT.bbox2delta(torch.from_numpy(anchors[idx]), torch.from_numpy(target), rp['target_means'],
+                                rp['target_stds']).numpy()
+    # (background anchors: distinct low scores - a block of equal keys would send the stage to its fallback path)
+    logits = (np.random.RandomState(3).randn(fh * fw * A) - 12.0).astype(np.float32)
+    logits[idx] = np.linspace(9.0, 3.0, n_chain).astype(np.float32)            # rank = chain order
+    cls = torch.from_numpy(logits.reshape(fh, fw, A)).permute(2, 0, 1).contiguous()
+    reg = torch.from_numpy(deltas.reshape(fh, fw, A * 4)).permute(2, 0, 1).contiguous()
+    ref = O.rpn_get_bboxes(cls.numpy(), reg.numpy(), np.array([ih, iw, 3]), cfg)
+    scores = torch.from_numpy(O.sigmoid32(logits[None]))
+    props, n = ops.rpn_proposals(scores.cuda(), torch.from_numpy(deltas[None]).cuda(), torch.from_numpy(base).cuda(), fh, fw,
+                                 16, ih, iw, rp['target_means'], rp['target_stds'], 6000, 0, 0.7, 300)
+    n = int(n.item())
+    assert n == len(ref) == 300
+    assert np.array_equal(props[0, :n].cpu().numpy(), ref)
+    # the chain really alternates: with the 10 px shift every second box of a row survives
+    if shift == 10.0:
+        kept_x = np.sort(ref[np.abs(ref[:, 1] - 20.0) < 1.0][:, 0])
+        assert len(kept_x) == per_row // 2 and np.allclose(np.diff(kept_x), 20.0, atol=0.05)
+
+
 def test_proposals_batch_of_two_images_equals_single_images():
     from fgn_amd import ops
     from fgn_amd.config import fgn_r50_c4_config
