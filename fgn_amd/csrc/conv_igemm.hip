@@ -410,8 +410,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
 // ix0..ix0+7 of input row iy0+ky are 128 contiguous bytes, i.e. exactly one LDS-DMA tile row; weights are packed
 // [Cout][KH][8][4] with zeros beyond KW (K = 32*KH).  Lane chunk = pixel: validity is per lane (x) and per
 // K-tile (y).
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, int MODE>
-__global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
+// (the body: workgroup (bx, by) of a launch of nwg_in x splits workgroups - the kernels below pass their own block
+// index and grid size, or the position of the workgroup inside ITS half of a two-convolution launch)
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const int bx, const int nwg_in, const int by) {
     constexpr bool PW = MODE == 1, STEM = MODE == 2;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     const int wv = t >> 6;
     const int wm = wv / WAVES_N, wn = wv % WAVES_N;
 
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    const int nwg = nwg_in;
+    int bid = bx;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
     const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
 
     const int KT_all = p.K / BK;
-    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt0 = by * p.kt_per_split;
     const int KT = min(KT_all, kt0 + p.kt_per_split);
     const int cin_tiles = p.Cin / BK;
 
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             // ---- split-K with the reduce inside the launch (see ConvParams::tickets)
             const size_t slab = (size_t)p.n_img * HoWo * p.Cout;
             if (n < p.Cout) {
-                float* dst = p.ws + (size_t)blockIdx.y * slab;
+                float* dst = p.ws + (size_t)by * slab;
 #pragma unroll
                 for (int k = 0; k < BM / RPP; ++k) {
                     const int row = rr + RPP * k;
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!raw && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
             if (!raw && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
-            float* dst = raw ? p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout : p.y;
+            float* dst = raw ? p.ws + (size_t)by * ((size_t)p.n_img * HoWo) * p.Cout : p.y;
 #pragma unroll
             for (int k0 = 0; k0 < BM / RPP; k0 += 4) {
                 float4 res[4];
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
         return;
     }
     if (p.splits > 1) {
-        float* slab = p.ws + (size_t)blockIdx.y * ((size_t)p.n_img * HoWo) * p.Cout;
+        float* slab = p.ws + (size_t)by * ((size_t)p.n_img * HoWo) * p.Cout;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + frag_row;
@@ -798,6 +800,25 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const Co
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, int MODE>
+__global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
+    conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, MODE>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Two convolutions with the SAME weights on two tensors of different geometry (the query map and the support maps of
+// one backbone layer whose stride keeps them from sharing rows: the strided 3x3 / 1x1 convolutions and the stem) as
+// ONE launch: workgroups [0, n0) run p0, the rest p1.  The support half alone is a small grid that needed split-K
+// slabs and a reduce launch to fill the chip; behind the query half it needs neither.  n0 is a multiple of 8, so the
+// XCD-contiguous tile walk of each half keeps its meaning.  No split-K in this form.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, int MODE>
+__global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_pair_kernel(const ConvParams p0, const ConvParams p1,
+                                                                             const int n0) {
+    if ((int)blockIdx.x < n0)
+        conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, MODE>(p0, blockIdx.x, n0, 0);
+    else
+        conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, MODE>(p1, (int)blockIdx.x - n0, (int)gridDim.x - n0, 0);
 }
 
 
@@ -1100,24 +1121,26 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
     return s < 2 ? 1 : s;
 }
 
+// banded raster when the launch's weights exceed the L2 budget (see ConvParams::band_nt)
+static void set_band(ConvParams& p, int BM, int BN, int m_tiles) {
+    static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
+    const long long per_nt = (long long)BN * (p.K / p.splits) * 4;
+    p.band_nt = 0; p.band_mt = 0;
+    if (budget > 0 && per_nt * p.n_tiles_n > budget) {
+        int nb = (int)std::max<long long>(1, budget / per_nt);
+        while (nb > 1 && p.n_tiles_n % nb) --nb;
+        const int mt = p.grp_rows ? p.grp_rows / BM : m_tiles;
+        if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, BN);
     const int m_tiles = cdiv(M_max, BM);
     const dim3 grid(m_tiles * p.n_tiles_n, p.splits);
-    {
-        // banded raster when the launch's weights exceed the L2 budget (see ConvParams::band_nt)
-        static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
-        const long long per_nt = (long long)BN * (p.K / p.splits) * 4;
-        p.band_nt = 0; p.band_mt = 0;
-        if (budget > 0 && per_nt * p.n_tiles_n > budget) {
-            int nb = (int)std::max<long long>(1, budget / per_nt);
-            while (nb > 1 && p.n_tiles_n % nb) --nb;
-            const int mt = p.grp_rows ? p.grp_rows / BM : m_tiles;
-            if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
-        }
-    }
+    set_band(p, BM, BN, m_tiles);
     // the in-launch reduce lives in the LDS-DMA kernel's 16-byte epilogue
     if (p.in_scale || p.x_bytes == 0 || cin4 || (p.Cout & 3) != 0 || p.splits <= 1) p.tickets = nullptr;
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
@@ -1302,6 +1325,65 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         case 4: return launch_cfg<64, 64, 32, 32, 4>(p, (int)M, cin4, stream);
         default: return FGN_ERR_ARG;
     }
+}
+
+// One launch for the same convolution (weights, BN epilogue) on two tensors of different geometry - the query map and
+// the support maps of a backbone layer that looks at the spatial structure with a stride (3x3 / stride 2, the 1x1 /
+// stride 2 shortcut, the stem): conv_igemm_dma_pair_kernel, 64x64 tiles, no split-K, no residual / input scale.
+// Per tensor the arithmetic is that of fgn_conv2d_nhwc_f32 without split-K.
+extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, int H0, int W0, const float* x1, float* y1,
+                                        int n_img1, int H1, int W1, const float* w_packed, const float* scale,
+                                        const float* shift, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
+                                        int pad, int relu, hipStream_t stream) {
+    if (!x0 || !y0 || !x1 || !y1 || !w_packed) return FGN_ERR_ARG;
+    if (n_img0 <= 0 || n_img1 <= 0) return FGN_ERR_SHAPE;
+    const bool cin4 = (Cin == 4);
+    if (!cin4 && (Cin % BK) != 0) return FGN_ERR_SHAPE;
+    if (stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout || (Cout & 3) != 0 || KH * KW > 64 || (cin4 && KW > 8))
+        return FGN_ERR_SHAPE;
+    ConvParams ps[2];
+    int tiles[2];
+    const float* xs[2] = {x0, x1};
+    float* ys[2] = {y0, y1};
+    const int ns[2] = {n_img0, n_img1}, Hs[2] = {H0, H1}, Ws[2] = {W0, W1};
+    for (int i = 0; i < 2; ++i) {
+        ConvParams& p = ps[i];
+        p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
+        p.in_scale = nullptr; p.n_img_dev = nullptr; p.tickets = nullptr;
+        p.n_img = ns[i]; p.H = Hs[i]; p.W = Ws[i]; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
+        p.stride = stride; p.pad = pad; p.a_img_div = 1; p.relu = relu;
+        p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
+        p.grp_count_dev = nullptr;
+        p.Ho = (p.H + 2 * pad - KH) / stride + 1;
+        p.Wo = (p.W + 2 * pad - KW) / stride + 1;
+        if (p.Ho <= 0 || p.Wo <= 0) return FGN_ERR_SHAPE;
+        p.K = cin4 ? KH * BK : cdiv(KH * KW * Cin, BK) * BK;
+        if ((long long)(p.n_img + 1) * p.H * p.W * Cin >= (1ll << 31)) return FGN_ERR_SHAPE;
+        const long long M = (long long)p.n_img * p.Ho * p.Wo;
+        if (M * (long long)Cout >= (1ll << 31) * 4) return FGN_ERR_SHAPE;
+        const long long xb = (long long)p.n_img * p.H * p.W * Cin * 4, wb = (long long)cout_pad * p.K * 4;
+        if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll) return FGN_ERR_SHAPE;
+        p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+        p.ws = nullptr; p.splits = 1; p.kt_per_split = p.K / BK;
+        p.n_tiles_n = cdiv(Cout, 64);
+        const int m_tiles = cdiv((int)M, 64);
+        set_band(p, 64, 64, m_tiles);
+        tiles[i] = (m_tiles * p.n_tiles_n + 7) / 8 * 8;       // workgroups past the last tile leave at once
+    }
+    constexpr int NST = CONV_DMA_STAGES;
+    const size_t dlds = std::max((size_t)NST * (64 + 64) * BK, (size_t)64 * (64 + 4)) * sizeof(float);
+    static unsigned long long lds_ok[2] = {0ull, 0ull};
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_dma_pair_kernel<64, 64, 32, 32, NST, 4, 0>), &lds_ok[0]);
+    if (attr == hipSuccess)
+        attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_dma_pair_kernel<64, 64, 32, 32, NST, 4, 2>), &lds_ok[1]);
+    if (attr != hipSuccess) return (int)attr;
+    const dim3 grid(tiles[0] + tiles[1]);
+    if (cin4)
+        FGN_LAUNCH_TIMED((conv_igemm_dma_pair_kernel<64, 64, 32, 32, NST, 4, 2>), grid, dim3(256), dlds, stream, ps[0], ps[1], tiles[0]);
+    else
+        FGN_LAUNCH_TIMED((conv_igemm_dma_pair_kernel<64, 64, 32, 32, NST, 4, 0>), grid, dim3(256), dlds, stream, ps[0], ps[1], tiles[0]);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -175,9 +175,22 @@ class _Pair:
         return _Pair(tuple(qs), tuple(ss), c, self.buf.device)
 
 
+USE_CONV_PAIR = os.environ.get('FGN_CONV_PAIR', '1') != '0'      # A/B knob: 0 = one launch per tensor
+
+
+def _conv_pair(xq, xs, layer, out_q, out_s):
+    """A convolution that strides over the spatial structure on the query map and the support maps: one two-tensor
+    launch (ops.conv2d_pair), or one launch each."""
+    if USE_CONV_PAIR and layer.cout % 4 == 0 and (layer.cin == 4 or layer.cin % 32 == 0):
+        ops.conv2d_pair(xq, xs, layer, out_q, out_s)
+    else:
+        ops.conv2d(xq, layer, out=out_q)
+        ops.conv2d(xs, layer, out=out_s)
+
+
 def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
     """``_Bottleneck.__call__`` on a query / support pair: merged launches for conv1, conv3 (+ residual), the
-    stride-1 downsample and the Winograd GEMM; per-branch launches for the strided convolutions and the transforms."""
+    stride-1 downsample and the Winograd GEMM; two-tensor launches for the strided convolutions and the transforms."""
     stride = blk.conv2.stride
     out_hw = lambda t: ((t.shape[1] - 1) // stride + 1, (t.shape[2] - 1) // stride + 1)
     if blk.down is None:
@@ -187,8 +200,7 @@ def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
         if blk.down.stride == 1:
             ops.conv2d(x.flat, blk.down, out=idt.flat)
         else:
-            ops.conv2d(x.q, blk.down, out=idt.q)
-            ops.conv2d(x.s, blk.down, out=idt.s)
+            _conv_pair(x.q, x.s, blk.down, idt.q, idt.s)
     y1 = x.like(blk.conv1.cout)
     ops.conv2d(x.flat, blk.conv1, out=y1.flat)
     y2 = x.like(blk.conv2.cout, out_hw(x.q), out_hw(x.s))
@@ -196,8 +208,7 @@ def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
     if wg is not None and ops.winograd_pays(1, (y1.mq + y1.ms) // 64 + 1, 64, wg.cin, wg.cout, wg.m):
         ops.conv3x3_winograd_multi([y1.q, y1.s], wg, [y2.q, y2.s])
     else:
-        ops.conv2d(y1.q, blk.conv2, out=y2.q)
-        ops.conv2d(y1.s, blk.conv2, out=y2.s)
+        _conv_pair(y1.q, y1.s, blk.conv2, y2.q, y2.s)
     out = y2.like(blk.conv3.cout)
     ops.conv2d(y2.flat, blk.conv3, residual=idt.flat, out=out.flat)
     return out
@@ -612,12 +623,13 @@ class FGN(torch.nn.Module):
         """Both backbone passes of an episode (fgn.py:212-215) through SHARED launches wherever a layer does not look at
         the spatial structure (``use_merged_backbone``; frozen-BN bottleneck backbones only)."""
         P = self._P
-        outs = []
-        for img in (qry_nchw, spp_nchw):
-            x = ops.nchw3_to_nhwc4(img.contiguous())
-            for conv, _ in P['stem']:
-                x = ops.conv2d(x, conv)
-            outs.append(x)
+        outs = [ops.nchw3_to_nhwc4(img.contiguous()) for img in (qry_nchw, spp_nchw)]
+        for conv, _ in P['stem']:
+            y = [torch.empty((o.shape[0], (o.shape[1] + 2 * conv.pad - conv.kh) // conv.stride + 1,
+                              (o.shape[2] + 2 * conv.pad - conv.kw) // conv.stride + 1, conv.cout), device=o.device,
+                             dtype=torch.float32) for o in outs]
+            _conv_pair(outs[0], outs[1], conv, y[0], y[1])
+            outs = y
         hw = lambda t: ((t.shape[1] - 1) // 2 + 1, (t.shape[2] - 1) // 2 + 1)
         x = _Pair((outs[0].shape[0],) + hw(outs[0]), (outs[1].shape[0],) + hw(outs[1]), outs[0].shape[3], outs[0].device)
         ops.maxpool3x3s2(outs[0], out=x.q)

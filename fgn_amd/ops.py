@@ -277,6 +277,46 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     return out
 
 
+def conv2d_pair(x0: torch.Tensor, x1: torch.Tensor, layer: ConvLayer, out0: Optional[torch.Tensor] = None,
+                out1: Optional[torch.Tensor] = None):
+    """The same convolution (weights, folded BN, ReLU) on two NHWC tensors of different geometry in ONE launch - the
+    query map and the support maps of a backbone layer that strides over the spatial structure (3x3 / stride 2, the
+    1x1 / stride 2 shortcut, the stem).  Per tensor the arithmetic of ``conv2d`` without split-K.  -> (y0, y1)."""
+    _chk(x0, 'x0')
+    _chk(x1, 'x1')
+    if x0.shape[3] != layer.cin or x1.shape[3] != layer.cin:
+        raise _lib.FgnHipError(f'conv2d_pair: Cin {x0.shape[3]} / {x1.shape[3]} != layer Cin {layer.cin}')
+    outs = []
+    for x, out in ((x0, out0), (x1, out1)):
+        n, H, W, _ = x.shape
+        ho = (H + 2 * layer.pad - layer.kh) // layer.stride + 1
+        wo = (W + 2 * layer.pad - layer.kw) // layer.stride + 1
+        if out is None:
+            out = torch.empty((n, ho, wo, layer.cout), device=x.device, dtype=torch.float32)
+        else:
+            _chk(out, 'out')
+            if tuple(out.shape) != (n, ho, wo, layer.cout):
+                raise _lib.FgnHipError('conv2d_pair: bad out shape')
+        outs.append(out)
+    prof = PROFILE
+    L = _lib.load()
+    if prof is not None:
+        e0, e1 = prof.arm()
+    rc = L.fgn_conv2d_pair_nhwc_f32(_ptr(x0), _ptr(outs[0]), x0.shape[0], x0.shape[1], x0.shape[2],
+                                    _ptr(x1), _ptr(outs[1]), x1.shape[0], x1.shape[1], x1.shape[2],
+                                    _ptr(layer.w), _ptr(layer.scale), _ptr(layer.shift), layer.cin, layer.cout,
+                                    layer.cout_pad, layer.kh, layer.kw, layer.stride, layer.pad, int(layer.relu), _stream())
+    _lib.check(rc, 'fgn_conv2d_pair_nhwc_f32')
+    if prof is not None:
+        per_px = 2.0 * layer.cout * layer.kh * layer.kw * (3 if layer.cin == 4 else layer.cin)
+        flop = per_px * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)
+        prof.append(dict(kind='conv', kernel='conv_igemm_dma_pair_kernel<64, 64, 32, 32, 2, 4, %d>' % (2 if layer.cin == 4 else 0),
+                         e0=e0, e1=e1, flop_direct=flop, flop_issued=flop, n_img=1, n_img_dev=None,
+                         shape=(x0.shape[0] + x1.shape[0], x0.shape[1], x0.shape[2], layer.cin, layer.cout, layer.kh,
+                                layer.stride)))
+    return outs[0], outs[1]
+
+
 # --------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) form of 3x3 / stride 1 / pad 1 convolutions
 # --------------------------------------------------------------------------------------

@@ -72,6 +72,17 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
 int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                               int tile_hint);
 
+/* The same convolution (w_packed, scale, shift, relu as in fgn_conv2d_nhwc_f32) on TWO NHWC tensors of different
+ * geometry in one launch: x0 [n_img0,H0,W0,Cin] -> y0, x1 [n_img1,H1,W1,Cin] -> y1.  For the backbone layers that
+ * stride over the spatial structure when the query image and the support crops go through the backbone together
+ * (fgn.py:212,215: the 3x3 / stride 2 conv2 and the 1x1 / stride 2 shortcut of a stage's first block, the stem) -
+ * the other layers of the two passes already share launches by sharing rows.  Per tensor the arithmetic of
+ * fgn_conv2d_nhwc_f32 without split-K; no residual / in_scale / device-side count; Cout % 4 == 0. */
+int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, int H0, int W0, const float* x1, float* y1,
+                             int n_img1, int H1, int W1, const float* w_packed, const float* scale, const float* shift,
+                             int Cin, int Cout, int cout_pad, int KH, int KW, int stride, int pad, int relu,
+                             void* stream);
+
 /* Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 convolution (same call sites as
  * fgn_conv2d_nhwc_f32: fgn_ag_rpn_head.py:48 rpn_conv, fgn_roi_head.py:236 shared_head conv2):
  *   fgn_winograd_input_f32   V[16][t_pad][C]   = B^T (x * in_scale?) B per 4x4 input tile

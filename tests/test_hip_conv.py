@@ -191,3 +191,37 @@ def test_repeated_runs_are_bit_identical_at_full_occupancy():
     assert (first.reshape(-1, 512).cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
     for i in range(200):
         assert torch.equal(ops.conv2d(xc, layer), first), f'launch {i} differs'
+
+
+@pytest.mark.parametrize('cin,cout,k,stride', [(128, 128, 3, 2), (256, 512, 1, 2), (64, 64, 3, 1), (4, 64, 7, 2)])
+def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
+    """``ops.conv2d_pair``: the query map and the support maps of a strided backbone layer in ONE launch.  Per tensor it
+    is the arithmetic of ``conv2d`` without split-K: identical bytes where the single launch is not split, within
+    rounding of the K order where it is (the small support half alone is split to fill the chip)."""
+    from fgn_amd import lib, ops
+    g = torch.Generator().manual_seed(17)
+    real_cin = 3 if cin == 4 else cin
+    wt = torch.randn(cout, real_cin, k, k, generator=g) / (real_cin * k * k) ** 0.5
+    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    layer = ops.pack_conv(wt, bn=bn, stride=stride, pad=k // 2, relu=True, **({'pad_cin_to': 4} if cin == 4 else {})).to('cuda')
+    xq = torch.randn(1, 101, 167, cin, generator=g).cuda()
+    xs = torch.randn(9, 32, 32, cin, generator=g).cuda()
+    if cin == 4:
+        xq[..., 3] = 0
+        xs[..., 3] = 0
+    yq, ys = ops.conv2d_pair(xq, xs, layer)
+    L = lib.load()
+    for x, y in ((xq, yq), (xs, ys)):
+        ref = ops.conv2d(x, layer)
+        assert y.shape == ref.shape
+        split = L.fgn_conv2d_workspace_bytes(x.shape[0], x.shape[1], x.shape[2], cin, cout, k, k, stride, k // 2, 0) > 0
+        if split:
+            assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        else:
+            assert torch.equal(y, ref)
+    # outputs into caller-provided buffers (views of one allocation, as the backbone uses them)
+    buf = torch.empty(yq.numel() + ys.numel(), device='cuda')
+    oq, os_ = buf[:yq.numel()].view(yq.shape), buf[yq.numel():].view(ys.shape)
+    ops.conv2d_pair(xq, xs, layer, oq, os_)
+    assert torch.equal(oq, yq) and torch.equal(os_, ys)
