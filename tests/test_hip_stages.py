@@ -147,14 +147,15 @@ def test_ag_rpn_merge_matches_reference_golden(golden_dir):
 
 
 # ---------------------------------------------------------------- relation head
-@pytest.mark.parametrize('gw', [32, 16, 8])
-def test_relation_head_matches_oracle(gw):
+@pytest.mark.parametrize('gw,n', [(32, 3), (16, 3), (8, 3), (32, 1), (32, 2), (32, 5), (16, 8)])
+def test_relation_head_matches_oracle(gw, n):
     """gw = channels per GroupNorm group: 32 is the reference's GN(32, 1024); 16 / 8 are narrower heads (the
-    ResNet-18 variant of cfg2: GN(32, 256))."""
+    ResNet-18 variant of cfg2: GN(32, 256)).  n = ways: the kernel is unrolled per class count (1..8; the next
+    class's support slab is loaded while the current one is normalised)."""
     from fgn_amd import ops
     from oracle import fgn_ref_cpu as O
     g = torch.Generator().manual_seed(5)
-    c, r, n, b = 128, 9, 3, 2
+    c, r, b = 128, 9, 2
     feats = torch.randn(r, c, 7, 7, generator=g).abs()
     cat_mean = torch.randn(b, n, c, 7, 7, generator=g).abs()
     rois = torch.zeros(r, 5)
@@ -356,6 +357,17 @@ def test_det_post_bit_exact(n_ways, r, seed):
     cs2, bp2 = O.count_modified_cls_bbox(h, cls_raw[:h * n_ways], reg_raw[:h * n_ways], n_ways)
     rb2, rl2 = O.bbox_get_bboxes(rois[:h].numpy(), cs2.numpy(), bp2.numpy(), np.array([ih, iw, 3]), cfg)
     assert np.array_equal(det2[:int(n2.item())].cpu().numpy(), rb2)
+
+
+def test_det_post_without_a_candidate_over_the_score_threshold():
+    from fgn_amd import ops
+    r, n_ways = 50, 3
+    rois = torch.tensor([[0, 10.0 + i, 20.0, 200.0 + i, 180.0] for i in range(r)]).cuda()
+    cls_raw = torch.zeros(r * n_ways, 2)
+    cls_raw[:, 0] = 12.0                               # background logit: every class score ~ 6e-6 < 0.05
+    det, lab, n = ops.det_post(rois, cls_raw.cuda(), torch.zeros(r * n_ways, 4).cuda(), n_ways, 400, 400, (0, 0, 0, 0),
+                               (.1, .1, .2, .2), 0.05, 0.5, 100)
+    assert int(n[0]) == 0 and float(det.abs().sum()) == 0.0 and int(lab.abs().sum()) == 0
 
 
 def test_det_post_batch_of_images_in_one_launch_equals_one_launch_per_image():
