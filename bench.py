@@ -328,10 +328,15 @@ def main():
                         d[k].record_stream(comm_stream)
         return e, dets
 
+    latencies = []        # seconds from the start of an episode's launch to its packed result dicts (host clock)
+
     def finish(pending):
-        e, dets = pending
-        return model.pack_results(dets, args.batch, qry_bboxes=e['qry_bboxes'], qry_cat_ids=e['qry_cat_ids'],
-                                  qry_isegmaps=e['qry_isegmaps'], img_shape=e['img_shape'], idx=e['idx'])
+        e, dets = pending[0], pending[1]
+        out = model.pack_results(dets, args.batch, qry_bboxes=e['qry_bboxes'], qry_cat_ids=e['qry_cat_ids'],
+                                 qry_isegmaps=e['qry_isegmaps'], img_shape=e['img_shape'], idx=e['idx'])
+        if len(pending) > 2:
+            latencies.append(time.perf_counter() - pending[2])
+        return out
 
     def run(n_steps, prof=None, prof_steps=(), alone=None, alone_steps=()):
         """Software-pipelined: episode i+1 is queued before the results of episode i are packed,
@@ -350,13 +355,13 @@ def main():
                     last = finish(pending.pop(0))
                     n_det += sum(len(r['dt_scores']) for r in last)
                     n_gt += sum(len(r['qry_isegmaps_rle']) for r in last)
-                pending.append(launch(i, alone))
+                pending.append(launch(i, alone) + (t_a,))
                 # the following steps are queued at once (no host wait), but their compute waits on the GPU for this
                 # episode: its kernels share the chip with nothing but their own side stream
                 for st in ep_streams:
                     (st if st is not None else torch.cuda.current_stream()).wait_event(pending[-1][1][0]['host_ready'])
             else:
-                pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None))
+                pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None) + (t_a,))
             t_b = time.perf_counter()
             if len(pending) > args.inflight:
                 last = finish(pending.pop(0))
@@ -404,7 +409,9 @@ def main():
     t0 = time.perf_counter()
     # in the instrumented steps every convolution kernel launch stamps a start/stop HIP event pair
     # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on)
+    latencies.clear()
     n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps, alone=prof_alone, alone_steps=alone_steps)
+    timed_latencies = sorted(latencies)
     barrier()
     dt = time.perf_counter() - t0
     per_rank_dt = [dt]
@@ -490,6 +497,12 @@ def main():
                        'rccl_world_size': (dist.get_world_size() if (world > 1 and dist.get_backend() == 'nccl') else None),
                        'process_group': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
                                          if world > 1 else None),
+                       # host clock, launch of an episode -> its packed result dicts, with `inflight` episodes queued
+                       # ahead of packing (the pipelined mode of this bench: ~inflight x ms_per_step; not the metric)
+                       'episode_latency_ms': ({'p50': round(timed_latencies[len(timed_latencies) // 2] * 1e3, 2),
+                                               'p95': round(timed_latencies[min(len(timed_latencies) - 1, int(len(timed_latencies) * 0.95))] * 1e3, 2),
+                                               'max': round(timed_latencies[-1] * 1e3, 2), 'episodes_in_flight': args.inflight}
+                                              if timed_latencies else None),
                        'per_rank_ms_per_step': {'min': round(min(per_rank_dt) / args.steps * 1e3, 3),
                                                 'max': round(max(per_rank_dt) / args.steps * 1e3, 3),
                                                 'all': [round(v / args.steps * 1e3, 3) for v in per_rank_dt]},
