@@ -82,7 +82,10 @@ def parse_args():
                          '0 vs 0, then score HIP and the CPU oracle with those weights; 0 = skip')
     ap.add_argument('--trained-eval-episodes', type=int, default=3, help='episodes scored by both paths with the trained heads')
     ap.add_argument('--inflight', type=int, default=None, help='episodes queued ahead of result packing per GPU '
-                    '(default: 2 with hipGraph replay, 1 without)')
+                    '(default: 3 with hipGraph replay, 1 without).  Measured on one box (r03, cfg3, two caller streams; '
+                    'tools/micro/ab_inflight.sh): with 2 in flight the GPU holds a single episode while the host packs one '
+                    'and replays the next - 177.7 img/s over 20 steps, 3 in flight 184.3, 4: 178.5, 6: 176.8 (filling '
+                    'and draining a deeper queue weighs on a 20-step run); over 300 steps 186.5 / 191.6 / 193.7 / 193.1')
     ap.add_argument('--streams', type=int, default=None,
                     help='caller streams the steps alternate between: with 2, the low-occupancy phases of one episode '
                          '(selection kernels, small-grid launches, transforms) run beside the GEMMs of the next.  Measured '
@@ -111,7 +114,7 @@ def parse_args():
     if args.streams is None:
         args.streams = 2 if args.graphs else 1
     if args.inflight is None:
-        args.inflight = 2 if args.graphs else 1
+        args.inflight = 3 if args.graphs else 1
     return args
 
 

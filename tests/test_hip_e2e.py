@@ -388,11 +388,14 @@ def test_hip_graph_replay_is_identical():
     assert len(model._graphs) == 3
 
 
-def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager():
-    """bench.py's execution mode (round 3): hipGraph replay, steps alternating between two caller streams, two episodes
-    queued before the first is packed - one captured graph, one set of static buffers, one side / upload / copy stream
-    and one ring of pinned result slots per caller stream.  Twelve steps over five distinct episodes must give, step by
-    step, the bytes of a serial eager run (boxes, scores, labels, detection RLE, ground-truth RLE)."""
+@pytest.mark.parametrize('in_flight', [2, 3, 5])
+def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager(in_flight):
+    """bench.py's execution mode (round 3): hipGraph replay, steps alternating between two caller streams, two to five
+    episodes queued before the first is packed (three is bench.py's default: a caller stream then holds two replays of
+    its graph, the second waiting on the GPU for the download of the first) - one captured graph, one set of static
+    buffers, one side / upload / copy stream and one ring of pinned result slots per caller stream.  Twelve steps over
+    five distinct episodes must give, step by step, the bytes of a serial eager run (boxes, scores, labels, detection
+    RLE, ground-truth RLE)."""
     from fgn_amd.config import tiny_config
     from fgn_amd.detector import FGN
     from fgn_amd.episodes import make_batch
@@ -417,7 +420,7 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'],
                                        qry_isegmaps=e['qry_isegmaps'])
         pending.append((e, dets))
-        if len(pending) > 2:
+        if len(pending) > in_flight:
             got.append(finish(pending.pop(0)))
     while pending:
         got.append(finish(pending.pop(0)))
