@@ -401,6 +401,13 @@ def main():
     prof_alone = ops.ConvProfile().reserve(2 * len(prime) + 16)      # isolated step -> roofline
     for ev in prof.pool + prof_alone.pool:
         ev.record()
+    # (Measured, r03: a Python garbage collection never fell into the 20-step window - collector on / off 185.5 / 184.4
+    # img/s -, but an IDLE GPU right before it does cost: a gc.collect() of ~50 ms placed between the warm-up and the timed
+    # region took 2.5 % off the 20 steps, the first of which then ran at a lower clock.  Nothing sits between the warm-up
+    # steps and the timed region but the barrier.)
+    preheat = int(os.environ.get('FGN_BENCH_PREHEAT', '0'))        # tuning aid: extra untimed steps in front of the warm-up
+    if preheat:
+        run(preheat)
     run(args.warmup)
 
     def barrier():
