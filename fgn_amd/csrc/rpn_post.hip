@@ -7,6 +7,16 @@
 // The reference runs this stage on CPU tensors (img_metas_cpu, fgn.py:209,233); here it
 // never leaves the GPU and never synchronises with the host: counts stay in device memory.
 // Compiled with -ffp-contract=off: fp32 op order is the oracle's.
+//
+// Launch sequence of fgn_rpn_proposals_f32 (inference sizes), all behind one C call:
+//   rpn_hist<1>, rpn_hist<2>, rpn_compact   the best >= 1536, <= 2048 keys of the 63 000 (two histogram levels)
+//   rpn_ranksort                            their order (rank = number of smaller keys) + the decoded box of each rank
+//   rpn_iou_matrix                          suppression bits between the ranked boxes, on the whole chip
+//   rpn_matrix_nms                          greedy resolution + outputs by ONE wavefront; marks the image finished
+//   rpn_proposals                           returns at once for finished images; otherwise (ties / saturation made the
+//                                           pre-selection invalid, or the ranked prefix ran dry) the whole stage in one
+//                                           workgroup: radix select, bitonic sort, decode, round-of-128 NMS
+// Identical outputs on every route (tests/test_hip_stages.py: bit-exact against the oracle, incl. the fallbacks).
 #include "post_common.h"
 #include <cstdlib>
 
@@ -53,7 +63,7 @@ extern "C" int fgn_rpn_merge_f32(const float* head, float* logits, float* scores
 }
 
 // ----------------------------------------------------------------------------------------------
-// proposals: one workgroup (1024 threads) per image.
+// proposals, single-workgroup form (the fallback of the launch sequence above): one workgroup (1024 threads) per image.
 // ----------------------------------------------------------------------------------------------
 constexpr int RPN_EPT = 64;
 constexpr int RPN_FAST_SEL = 1536;   // candidates ranked by the fast first attempt
@@ -70,7 +80,7 @@ struct ProposalParams {
     float* rois;             // optional out [B*max_out][5] = (image index, x1, y1, x2, y2): bbox2roi (fgn_roi_head.py:556)
     int32_t* n_props;        // out [B]
     int32_t* dbg_topk_idx;   // optional out [B][cap] (selected anchor indices, sorted) or null
-    // multi-workgroup pre-selection (rpn_hist16 / rpn_thresh / rpn_compact / rpn_ranksort kernels): the best
+    // multi-workgroup pre-selection (rpn_hist<1>, rpn_hist<2>, rpn_compact, rpn_ranksort kernels): the best
     // pre_info[b][3] <= RPN_FAST_CAP keys of image b, sorted, in pre_sorted[b]; pre_info[b][4] = 1 when valid
     const uint64_t* pre_sorted;   // [B][RPN_FAST_CAP] or null
     int32_t* pre_info;            // [B][8]: b1, count before b1, b2, candidate count, ok flag, [5] = finished by rpn_matrix_nms_kernel
