@@ -521,8 +521,12 @@ def main():
                        'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,
                        'avg_detections': n_d / args.steps / args.batch,
-                       'algorithmic_gflop_per_episode': round(gflop, 1),
-                       'algorithmic_tflops': round(gflop * world * args.steps * args.batch / dt / 1e3, 2)},
+                       # the REFERENCE's formulation of an episode (direct 3x3 convs, relation conv on the
+                       # concatenated tensor) - a unit of work for comparing builds, NOT a utilisation figure: the
+                       # build issues fewer FLOPs (roofline.flop_per_step), so this rate may exceed the 157.3 TF/s peak
+                       'reference_formulation_gflop_per_episode': round(gflop, 1),
+                       'reference_formulation_tflops_not_a_utilisation_figure':
+                           round(gflop * world * args.steps * args.batch / dt / 1e3, 2)},
             # frac = MFMA FLOPs the dominant kernel actually ISSUED / its summed HIP-event launch durations / peak.
             # Reproducible from profiles/rNN_kernel_stats.csv: flop_per_step * steps / TotalDurationNs of `kernel`.
             'roofline': {'bound': 'mfma', 'kernel': dom_name,
