@@ -10,10 +10,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4      # BASELINE.json north_star: "masks/scores within 1e-4 fp32"; boxes/labels of matched pairs within 1e-2 px
 
 
-def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=2):
+BOX_TOL = 1e-2  # px: the matching radius of fgn_amd.agreement AND the asserted bound on matched pairs
+
+
+def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0):
     """Per image: match HIP detections to the oracle's (same label, box within 1e-2 px), assert
-    |d score| <= 1e-4 and max |d mask probability| <= 1e-4 on EVERY matched pair, and report the
-    detections without a partner (an upstream selection flipped) as a count, not a percentage."""
+    |d score| <= 1e-4, max |d mask probability| <= 1e-4 and |d box| <= 1e-2 px on EVERY matched pair, and count the
+    detections without a partner (an upstream selection flipped).  Every seeded episode of this file produces ZERO
+    flips (rounds 1-3, 6400 detections in profiles/r03_accuracy_64.json), so zero is what is asserted: one flipped
+    detection is a regression until someone shows the key that sat on a threshold.  A test that can genuinely flip
+    passes its own `max_flips` with a comment saying why."""
     start = 0
     out = []
     for i in range(len(ref)):
@@ -36,6 +42,7 @@ def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=2):
         assert m['matched'] > 0
         assert m['max_dscore'] <= TOL, (name, i, m)
         assert m['max_dprob'] <= TOL, (name, i, m)
+        assert m['max_dbox'] <= BOX_TOL, (name, i, m)
         assert m['flips_ref'] <= max_flips and m['flips_got'] <= max_flips, (name, i, m)
         out.append(m)
     return out
@@ -521,11 +528,13 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
         ds = np.abs(a['dt_scores'][ia] - b['dt_scores'][ib]).max()
         print(f'[cfg4 batch {EPB} vs alone, episode {i}] matched {len(pairs)}/{len(b["dt_scores"])}, '
               f'flips {len(ma)}/{len(mb)}, max|d score| {ds:.2e}')
-        assert ds <= TOL and len(ma) <= 2 and len(mb) <= 2      # tile partition differs with the batch: fp32 order
+        assert ds <= TOL and len(ma) == 0 and len(mb) == 0      # tile partition differs with the batch: fp32 order; 0 flips observed in every round
     del model
-    # ---- cfg4 against the oracle: a batch of two 800x1328 episodes, every matched pair within north_star's tolerance
-    ref, tr_ref, got, tr = _run(cfg, make_batch(40, 2, **CONFIGS['cfg4']))
-    _check_tolerance(ref, got, tr_ref, tr, 'cfg4 batch 2')
+    # ---- cfg4 against the ORACLE at the reference's own evaluation call shape: batch = 4 (fgn_test.py:49,108;
+    # fgn_train.py:56) at 800x1328 - every matched pair of all four episodes within north_star's tolerance, zero flips
+    ref, tr_ref, got, tr = _run(cfg, make_batch(40, 4, **CONFIGS['cfg4']))
+    assert len(ref) == len(got) == 4
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg4 batch 4')
     # ---- cfg5
     shape = CONFIGS['cfg5']
     cfg5 = with_caps(fgn_r50_c4_config(5, 5), rpn_max=RPN_MAX_PER_IMG['cfg5'])
