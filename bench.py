@@ -179,14 +179,20 @@ def pin_rank(local_rank: int, local_world: int, sysfs: str = '/sys', apply: bool
         return info
     gpus = gpu_local_cpus(sysfs)
     mine = None
-    if local_rank < len(gpus) and gpus[local_rank]['cpus']:
-        local = [c for c in gpus[local_rank]['cpus'] if c in set(allowed)]
-        sharers = [r for r in range(min(local_world, len(gpus))) if gpus[r]['cpus'] == gpus[local_rank]['cpus']]
-        if local and local_rank in sharers:
-            k, n = sharers.index(local_rank), len(sharers)
-            per = max(1, len(local) // n)
-            mine = local[k * per:(k + 1) * per] or local
-            info = dict(policy='gpu-local', numa=gpus[local_rank]['numa'], sharers=n)
+    if gpus:
+        # rank -> GPU: one GPU per rank when there are enough, otherwise (a rehearsal of several ranks on one card, or
+        # HIP_VISIBLE_DEVICES per rank) ranks wrap around; the cores of a cpulist are split among ALL ranks whose GPU
+        # reports that list, so no two ranks ever get overlapping sets
+        gpu_of = [r % len(gpus) for r in range(local_world)]
+        g = gpus[gpu_of[local_rank]]
+        if g['cpus']:
+            local = [c for c in g['cpus'] if c in set(allowed)]
+            sharers = [r for r in range(local_world) if gpus[gpu_of[r]]['cpus'] == g['cpus']]
+            if local and len(local) >= len(sharers):
+                k, n = sharers.index(local_rank), len(sharers)
+                per = len(local) // n
+                mine = local[k * per:(k + 1) * per]
+                info = dict(policy='gpu-local', numa=g['numa'], sharers=n, gpu=gpu_of[local_rank])
     if mine is None:
         per = max(1, len(allowed) // local_world)
         mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed

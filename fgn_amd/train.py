@@ -23,6 +23,7 @@ trainable heads, the Adagrad update and the re-pack of the kernel layouts itself
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional
 
 import numpy as np
@@ -152,19 +153,27 @@ def _choose(cand: np.ndarray, num: int, perm_fn) -> np.ndarray:
     return cand
 
 
+_PERM_LOCK = threading.Lock()
+
+
 def _perm(perm_fn, n: int) -> torch.Tensor:
     """``perm_fn(n)``; ``torch.randperm`` of more than 32768 elements on ONE intra-op thread.  torch fills the
     identity permutation with ``at::parallel_for`` (grain 32768) before its sequential Fisher-Yates shuffle; on a
     128-thread host waking the sleeping OpenMP pool for that fill costs 4.5-5 ms per call (0.19 ms on one thread,
     tools/micro/randperm_probe.py) - six draws of ~60 000 anchors were 34 of the 43 ms of a ``forward_train`` call.
     The permutation does not depend on the thread count (tests/test_host_cpu.py), so seed parity with mmdet holds."""
-    if perm_fn is torch.randperm and n > 32768 and torch.get_num_threads() > 1:
-        k = torch.get_num_threads()
-        torch.set_num_threads(1)
-        try:
-            return perm_fn(n)
-        finally:
-            torch.set_num_threads(k)
+    if perm_fn is torch.randperm and n > 32768:
+        # the thread count is process-global: one caller at a time flips it, and the value to restore is read INSIDE
+        # the lock, so a racing call can never read the other's temporary 1 and leave the pool there
+        with _PERM_LOCK:
+            k = torch.get_num_threads()
+            if k == 1:
+                return perm_fn(n)
+            torch.set_num_threads(1)
+            try:
+                return perm_fn(n)
+            finally:
+                torch.set_num_threads(k)
     return perm_fn(n)
 
 
@@ -693,6 +702,68 @@ def trainable_names(sd: dict) -> list:
             and 'running_' not in k and 'num_batches' not in k]
 
 
+_REF_RANK = {'backbone': 0, 'rpn_head': 1, 'roi_head': 2,
+             'stem': 0, 'conv1': 0, 'bn1': 1, 'gn1': 1, 'conv2': 2, 'bn2': 3, 'gn2': 3, 'conv3': 4, 'bn3': 5, 'gn3': 5,
+             'downsample': 6, 'layer1': 10, 'layer2': 11, 'layer3': 12, 'layer4': 13,
+             'rpn_conv': 0, 'rpn_cls': 1, 'rpn_reg': 2,
+             'bbox_head': 0, 'mask_head': 1, 'shared_head': 2, 'cls_reg_shared_conv': 3, 'cls_reg_shared_conv_norm': 4,
+             'fc_cls': 0, 'fc_reg': 1, 'convs': 0, 'upsample': 1, 'conv_logits': 2, 'conv': 0, 'weight': 0, 'bias': 1}
+_BUFFER_TAILS = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def _layer4_params(bb: dict) -> list:
+    """(name, shape) of the parameters of ``backbone.layer4``.  The reference builds all four stages
+    (fgn_r50_c4_densecl.py:21 ``num_stages=4``) and main.py:402-405 only shortens ``res_layers``, the list of stage
+    NAMES the forward pass walks: the module stays registered, so its (frozen, never used) parameters are part of
+    ``model.named_parameters()``, of every checkpoint and of the optimizer's index space.  This build holds no
+    layer4; its shapes follow from the architecture (mmdet ResNet ``arch_settings``: Bottleneck x3 at depth 50,
+    BasicBlock x2 at depth 18; planes = 2 x the third stage's)."""
+    if len(bb['stage_blocks']) != 3:
+        return []
+    planes = 2 * bb['stage_planes'][-1]
+    bottleneck = bb.get('block', 'bottleneck') == 'bottleneck'
+    exp = 4 if bottleneck else 1
+    inpl, out = bb['stage_planes'][-1] * exp, planes * exp
+    n_blocks = 3 if bottleneck else 2
+    res = []
+    for b in range(n_blocks):
+        pre = f'backbone.layer4.{b}.'
+        cin = inpl if b == 0 else out
+        convs = [('conv1', (planes, cin, 1, 1)), ('conv2', (planes, planes, 3, 3)), ('conv3', (out, planes, 1, 1))] \
+            if bottleneck else [('conv1', (planes, cin, 3, 3)), ('conv2', (planes, planes, 3, 3))]
+        for i, (cname, shape) in enumerate(convs):
+            res.append((pre + cname + '.weight', shape))
+            res += [(pre + f'bn{i + 1}.weight', (shape[0],)), (pre + f'bn{i + 1}.bias', (shape[0],))]
+        if b == 0:
+            res.append((pre + 'downsample.0.weight', (out, cin, 1, 1)))
+            res += [(pre + 'downsample.1.weight', (out,)), (pre + 'downsample.1.bias', (out,))]
+    return res
+
+
+def reference_param_order(sd: dict, backbone_cfg: dict) -> list:
+    """[(name, shape)] of EVERY parameter of the reference's detector in the order mmcv's
+    ``DefaultOptimizerConstructor.add_params`` visits them (= ``model.named_parameters()``: a module's own parameters,
+    then its children in registration order), which is the index space of ``torch.optim.Adagrad.state_dict()`` in a
+    reference checkpoint.  Under ``paramwise_cfg`` (fgn_train_schedule.py:10-15) the constructor appends one param
+    group per parameter, FROZEN ONES INCLUDED (``if not param.requires_grad: params.append(param_group); continue``),
+    and ``Adagrad.__init__`` creates ``step`` / ``sum`` state for every parameter of every group.
+    Registration order: ``backbone`` (conv1, bn1, layer1..layer4; a Bottleneck registers conv1, bn1, conv2, bn2, conv3,
+    bn3 and sets ``downsample`` last), ``rpn_head`` (rpn_conv, rpn_cls, rpn_reg), ``roi_head``: ``StandardRoIHead.__init__``
+    builds bbox_head (fc_cls, fc_reg) and mask_head (convs, upsample, conv_logits) FIRST, then ``FGNRoIHead.__init__``
+    adds shared_head, cls_reg_shared_conv, cls_reg_shared_conv_norm (fgn_roi_head.py:197-200, 240-243; the config passes
+    ``shared_head=None``, fgn_r50_c4_densecl.py:68)."""
+    items = [(k, tuple(v.shape)) for k, v in sd.items() if not k.endswith(_BUFFER_TAILS)]
+    have = {k for k, _ in items}
+    items += [(k, shp) for k, shp in _layer4_params(backbone_cfg) if k not in have]
+
+    def key(name):
+        try:
+            return tuple(int(t) if t.isdigit() else _REF_RANK[t] for t in name.split('.'))
+        except KeyError as e:
+            raise ValueError(f'{name}: no place in the reference parameter order ({e})') from None
+    return sorted(items, key=lambda it: key(it[0]))
+
+
 def step_lr(base_lr: float, it: int, epoch: int, steps=(3,), gamma: float = 0.1, min_lr: float = 1e-6,
             warmup_iters: int = 100, warmup_ratio: float = 0.01) -> float:
     """mmcv ``StepLrUpdaterHook`` as configured in fgn_train_schedule.py:17-23: lr = base * gamma^(#steps <= epoch),
@@ -732,8 +803,11 @@ class Trainer:
                         if k.startswith('roi_head.shared_head') and 'running_' in k}
         self.grads: dict = {}
         self.n_steps = 0
+        # num_batches_tracked of the shared head's BatchNorms = the loaded counter + the train-mode passes made since
+        # (one over the support RoIs per step, one over the sampled RoIs when the step sampled any)
         self._bn_tracked0 = {k: int(v) for k, v in sd.items()
                              if k.startswith('roi_head.shared_head') and k.endswith('num_batches_tracked')}
+        self._bn_calls = 0
         import weakref
         model._trainer = weakref.ref(self)      # the model sources its weights from W / buffers while a trainer lives
         self.refresh()
@@ -765,6 +839,7 @@ class Trainer:
         m._tape = {}
         try:
             losses = forward_train(m, perm_fn=perm_fn, bn_momentum=self.bn_momentum, **batch)
+            self._bn_calls += 1 + (m._tape.get('roi') is not None)
             g = backward(m, self.W, m._tape)
         finally:
             m._tape = None
@@ -791,20 +866,27 @@ class Trainer:
         return losses
 
     def optimizer_state_dict(self) -> dict:
-        """``torch.optim.Adagrad.state_dict()`` layout, as mmcv saves it (checkpoint_config save_optimizer=True,
-        fgn_train_schedule.py:33-38): 'state' {index: {'step', 'sum'}} and one param group per parameter - mmcv's
-        DefaultOptimizerConstructor builds one group per parameter under ``paramwise_cfg`` (the 0.1 lr_mult of
-        ``roi_head``, fgn_train_schedule.py:3-13).  Parameter order = ``trainable_names`` = the order of the heads'
-        parameters in the state dict; the frozen backbone's parameters (no state in torch either) are not listed, so
-        indices are relative to the first trainable parameter - ``param_names`` (an extra key) spells them out."""
-        names = list(self.W)
-        step = torch.tensor(float(self.n_steps))
-        return {'state': {i: {'step': step.clone(), 'sum': self.state[k].detach().cpu()} for i, k in enumerate(names)},
-                'param_groups': [{'lr': self.lr * (self.mult if k.startswith('roi_head') else 1.0), 'lr_decay': 0,
-                                  'eps': self.eps, 'weight_decay': self.wd, 'initial_accumulator_value': 0,
-                                  'foreach': None, 'maximize': False, 'differentiable': False, 'fused': None,
-                                  'params': [i]} for i, k in enumerate(names)],
-                'param_names': names}
+        """``torch.optim.Adagrad.state_dict()`` of the REFERENCE's optimizer, as mmcv saves it (checkpoint_config
+        save_optimizer=True, fgn_train_schedule.py:33-38): 'state' {index: {'step', 'sum'}} and one param group per
+        parameter over ``reference_param_order`` - every parameter of the detector, the frozen backbone (and the unused
+        layer4) included, because mmcv's constructor lists frozen parameters too and Adagrad creates state for all of
+        them.  Frozen parameters never see a gradient: their state is torch's initial one (step 0, zero sum) at the
+        optimizer's default lr.  The reference's ``optimizer.load_state_dict`` accepts this dict as it is (same group
+        count, one parameter per group); ``param_names`` (extra key, ignored by torch) spells the index space out."""
+        order = reference_param_order(self.model._sd, self.model.cfg['backbone'])
+        state, groups = {}, []
+        for i, (k, shape) in enumerate(order):
+            if k in self.W:
+                st = {'step': torch.tensor(float(self.n_steps)), 'sum': self.state[k].detach().cpu()}
+                lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
+            else:
+                st = {'step': torch.tensor(0.0), 'sum': torch.zeros(shape)}
+                lr = self.lr
+            state[i] = st
+            groups.append({'lr': lr, 'lr_decay': 0, 'eps': self.eps, 'weight_decay': self.wd,
+                           'initial_accumulator_value': 0, 'foreach': None, 'maximize': False, 'differentiable': False,
+                           'fused': None, 'params': [i]})
+        return {'state': state, 'param_groups': groups, 'param_names': [k for k, _ in order]}
 
     def checkpoint(self, meta: Optional[dict] = None) -> dict:
         """mmcv checkpoint layout: {'state_dict', 'optimizer' (torch Adagrad layout, see ``optimizer_state_dict``),
@@ -823,23 +905,41 @@ class Trainer:
                 self.buffers[k].copy_(sd[k].to(self.device, torch.float32))
         for k in self._bn_tracked0:
             if k in sd:
-                self._bn_tracked0[k] = int(sd[k]) - 2 * int(ckpt.get('meta', {}).get('iter', 0))
+                self._bn_tracked0[k] = int(sd[k])                     # the loaded counter is the base from here on
+        self._bn_calls = 0
+        if 'iter' in ckpt.get('meta', {}):
+            self.n_steps = int(ckpt['meta']['iter'])                  # mmcv's runner resumes its iteration from here
         opt = ckpt.get('optimizer')
         if opt is not None:
             if 'state_sum' in opt:                                    # this package's round-2 layout
                 sums = opt['state_sum']
                 self.lr, self.wd = opt.get('lr', self.lr), opt.get('weight_decay', self.wd)
             elif 'state' in opt and 'param_groups' in opt:
-                names = list(opt.get('param_names', self.W))
+                # index -> name: the dict's own `param_names`, else the reference's full parameter order (a checkpoint
+                # written by mmcv / torch itself), else - a torch optimizer built over the trainable heads alone -
+                # the heads in state-dict order.  Entries of frozen parameters are ignored.
                 n_idx = sum(len(g['params']) for g in opt['param_groups'])
-                if n_idx != len(names) or set(names) != set(self.W):
-                    raise ValueError(f'optimizer state covers {n_idx} parameters, the trainable heads have '
-                                     f'{len(self.W)}: cannot map indices to parameters (pass param_names)')
-                sums = {names[int(i)]: st['sum'] for i, st in opt['state'].items()}
-                steps = [float(st['step']) for st in opt['state'].values()]
-                self.n_steps = int(max(steps)) if steps else 0
-                by_name = {names[i]: g for g in opt['param_groups'] for i in g['params']}
-                rp = next((g for k, g in by_name.items() if not k.startswith('roi_head')), None)
+                full = [k for k, _ in reference_param_order(self.model._sd, self.model.cfg['backbone'])]
+                if 'param_names' in opt:
+                    names = list(opt['param_names'])
+                elif n_idx == len(full):
+                    names = full
+                elif n_idx == len(self.W):
+                    names = list(self.W)
+                else:
+                    names = []
+                if n_idx != len(names) or not set(self.W) <= set(names):
+                    raise ValueError(f'optimizer state covers {n_idx} parameters; the reference model has {len(full)} '
+                                     f'({len(self.W)} of them trainable): cannot map indices to parameters '
+                                     f'(pass param_names)')
+                flat = [i for g in opt['param_groups'] for i in g['params']]
+                name_of = {int(i): names[pos] for pos, i in enumerate(flat)}
+                sums = {name_of[int(i)]: st['sum'] for i, st in opt['state'].items() if name_of[int(i)] in self.W}
+                steps = [float(st['step']) for i, st in opt['state'].items() if name_of[int(i)] in self.W]
+                if steps:
+                    self.n_steps = int(max(steps))                    # Adagrad's own step count wins over meta
+                by_name = {name_of[int(i)]: g for g in opt['param_groups'] for i in g['params']}
+                rp = next((g for k, g in by_name.items() if k in self.W and not k.startswith('roi_head')), None)
                 if rp is not None:
                     self.lr, self.wd = float(rp['lr']), float(rp['weight_decay'])
             else:
@@ -855,6 +955,6 @@ class Trainer:
             sd[k] = v.detach().cpu()
         for k, v in self.buffers.items():
             sd[k] = v.detach().cpu()
-        for k, v0 in self._bn_tracked0.items():       # every BatchNorm of the shared head runs twice per step
-            sd[k] = torch.tensor(v0 + 2 * self.n_steps, dtype=torch.long)       # (RoI batch + support batch)
+        for k, v0 in self._bn_tracked0.items():       # train-mode passes actually made (support batch + RoI batch)
+            sd[k] = torch.tensor(v0 + self._bn_calls, dtype=torch.long)
         return sd

@@ -641,18 +641,28 @@ def test_step_without_positives_keeps_every_gradient_and_torch_optimizer_layout(
     opt.step()
     assert torch.allclose(t.W[name], p.detach(), rtol=1e-6, atol=1e-9) and not torch.equal(t.W[name], w0)
     assert torch.allclose(t.state[name], opt.state[p]['sum'], rtol=1e-6, atol=0)
-    # ---- torch layout of the optimizer entry
+    # ---- torch layout of the optimizer entry: the index space is the REFERENCE model's named_parameters() - frozen
+    # backbone and the unused layer4 included (mmcv lists frozen parameters under paramwise_cfg, Adagrad creates state
+    # for every one) - so a real torch.optim.Adagrad built over ALL parameters loads it, as the reference's resume does
+    from fgn_amd.train import reference_param_order
     ck = t.checkpoint()
+    order = reference_param_order(m._sd, cfg['backbone'])
     names = ck['optimizer']['param_names']
-    assert names == list(t.W) and ck['meta']['iter'] == 2
-    params = [torch.nn.Parameter(ck['state_dict'][k].clone()) for k in names]
-    topt = torch.optim.Adagrad([{'params': [q], 'lr': g['lr']} for q, g in zip(params, ck['optimizer']['param_groups'])],
-                               lr=t.lr, weight_decay=t.wd, eps=t.eps)
+    assert names == [k for k, _ in order] and len(names) > len(t.W) and ck['meta']['iter'] == 2
+    assert names[0] == 'backbone.conv1.weight' and any(k.startswith('backbone.layer4.') for k in names)
+    params = [torch.nn.Parameter(ck['state_dict'][k].clone() if k in ck['state_dict'] else torch.zeros(shape),
+                                 requires_grad=k in t.W) for k, shape in order]
+    topt = torch.optim.Adagrad([{'params': [q]} for q in params], lr=t.lr, weight_decay=t.wd, eps=t.eps)
     topt.load_state_dict({k: v for k, v in ck['optimizer'].items() if k != 'param_names'})
     for q, k in zip(params, names):
-        assert torch.equal(topt.state[q]['sum'], t.state[k].cpu()) and float(topt.state[q]['step']) == 2.0
+        if k in t.W:
+            assert torch.equal(topt.state[q]['sum'], t.state[k].cpu()) and float(topt.state[q]['step']) == 2.0
+        else:                                              # torch's own initial state of a parameter without gradient
+            assert float(topt.state[q]['sum'].abs().max()) == 0.0 and float(topt.state[q]['step']) == 0.0
+            assert topt.state[q]['sum'].shape == q.shape
     assert topt.param_groups[names.index(name)]['lr'] == pytest.approx(t.lr * t.mult)
     assert topt.param_groups[names.index('rpn_head.rpn_conv.weight')]['lr'] == pytest.approx(t.lr)
+    assert topt.param_groups[0]['lr'] == pytest.approx(t.lr)
     bn_key = 'roi_head.shared_head.0.bn1.num_batches_tracked'
     assert int(ck['state_dict'][bn_key]) == int(m._sd[bn_key]) + 4          # 2 steps x (RoI batch + support batch)
     m2, _ = _models(cfg)
@@ -661,6 +671,23 @@ def test_step_without_positives_keeps_every_gradient_and_torch_optimizer_layout(
     assert t2.n_steps == 2
     for k in t.W:
         assert torch.equal(t2.state[k], t.state[k]) and torch.equal(t2.W[k], t.W[k])
+    assert int(t2.state_dict()[bn_key]) == int(ck['state_dict'][bn_key])   # the loaded counter is the base, no offset
+    # a torch optimizer over the trainable heads alone (no frozen entries) maps by state-dict order, as before
+    hp = [torch.nn.Parameter(ck['state_dict'][k].clone()) for k in t.W]
+    hopt = torch.optim.Adagrad([{'params': [q]} for q in hp], lr=t.lr, weight_decay=t.wd, eps=t.eps)
+    for q, k in zip(hp, t.W):
+        hopt.state[q]['sum'].copy_(t.state[k].cpu())
+        hopt.state[q]['step'] = torch.tensor(2.0)
+    m3, _ = _models(cfg)
+    t3 = Trainer(m3)
+    t3.resume({'state_dict': ck['state_dict'], 'optimizer': hopt.state_dict()})
+    assert t3.n_steps == 2 and all(torch.equal(t3.state[k], t.state[k]) for k in t.W)
+    # an index space that is neither is refused, not guessed
+    bad = hopt.state_dict()
+    bad['param_groups'] = bad['param_groups'][:-1]
+    with pytest.raises(ValueError):
+        t3.resume({'state_dict': ck['state_dict'], 'optimizer': bad})
+    del m3, t3
     # ---- re-pack after training
     want = m.simple_test(**b, rescale=True)
     m._packed_device = None                          # what a device change / use_winograd switch does

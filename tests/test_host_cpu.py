@@ -555,6 +555,14 @@ def test_rank_placement_from_a_kfd_topology(tmp_path):
     sets = [set(g['cpu_list']) for g in got]
     assert sets[0] | sets[1] <= set(lists[0]) and sets[2] | sets[3] <= set(lists[1])
     assert not (sets[0] & sets[1]) and not (sets[2] & sets[3]) and all(len(s_) == half // 2 for s_ in sets)
+    # more ranks than GPUs (the 5-rank rehearsal on one card, HIP_VISIBLE_DEVICES per rank): ranks wrap around the GPUs
+    # and the cores of a cpulist are split among ALL the ranks that land on it - no two ranks overlap
+    if half >= 4:
+        got = [bench.pin_rank(r, 6, sysfs=str(tmp_path), apply=False) for r in range(6)]
+        sets = [set(g['cpu_list']) for g in got]
+        assert all(g['policy'] == 'gpu-local' for g in got) and [g['sharers'] for g in got] == [4, 4, 2, 2, 4, 4]
+        assert all(not (sets[a] & sets[b]) for a in range(6) for b in range(a + 1, 6))
+        assert [g['gpu'] for g in got] == [0, 1, 2, 3, 0, 1]
     # no topology at all -> even contiguous split of the allowed cores; one rank -> untouched
     got = [bench.pin_rank(r, 4, sysfs=str(tmp_path / 'nothing'), apply=False) for r in range(4)]
     assert all(g['policy'] == 'even-split' for g in got) and not (set(got[0]['cpu_list']) & set(got[1]['cpu_list']))
@@ -639,3 +647,103 @@ def test_evaluator_records_and_summary_match_the_reference_fsisegeval(tmp_path):
     ev.eval = {'precision': -np.ones((11, 3)), 'recall': -np.ones(3)}
     out = ev.summarize_short()
     np.testing.assert_array_equal([out['mAP'], out['mAR']], z['summary_empty'])
+
+
+def _reference_shaped_detector(cfg):
+    """An nn.Module tree with the REGISTRATION ORDER of the reference's detector (mmdet 2.18 ``ResNet`` with all four
+    stages - main.py:402-405 only shortens the list of stage names -, ``RPNHead``, then ``FGNRoIHead``: bbox_head and
+    mask_head from ``StandardRoIHead.__init__``, shared_head / cls_reg_shared_conv / cls_reg_shared_conv_norm added by
+    fgn_roi_head.py:197-200), built independently of ``fgn_amd.train.reference_param_order``: torch's own
+    ``named_parameters()`` then gives the index space of the reference's optimizer."""
+    import torch.nn as nn
+    bb = cfg['backbone']
+
+    class Bottleneck(nn.Module):
+        def __init__(self, cin, planes, out, down):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, planes, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, out, 1, bias=False); self.bn3 = nn.BatchNorm2d(out)
+            self.relu = nn.ReLU()
+            self.downsample = nn.Sequential(nn.Conv2d(cin, out, 1, bias=False), nn.BatchNorm2d(out)) if down else None
+
+    def res_layer(cin, planes, out, n, force_down=True):
+        return nn.Sequential(*[Bottleneck(cin if i == 0 else out, planes, out, i == 0 and (force_down or cin != out))
+                               for i in range(n)])
+
+    class Backbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            c = bb['stem_channels']
+            self.conv1 = nn.Conv2d(3, c, 7, bias=False); self.bn1 = nn.BatchNorm2d(c)
+            planes = list(bb['stage_planes']) + [2 * bb['stage_planes'][-1]]
+            blocks = list(bb['stage_blocks']) + [3]
+            for i, (p, n) in enumerate(zip(planes, blocks)):
+                setattr(self, f'layer{i + 1}', res_layer(c, p, 4 * p, n))
+                c = 4 * p
+
+    C = 4 * bb['stage_planes'][-1]
+    A = 15
+
+    class RPN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.rpn_conv = nn.Conv2d(C, C, 3); self.rpn_cls = nn.Conv2d(C, A, 1); self.rpn_reg = nn.Conv2d(C, 4 * A, 1)
+
+    class BBoxHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_cls = nn.Linear(C, 2); self.fc_reg = nn.Linear(C, 4)
+
+    mc = cfg['roi_head']['mask_head']['conv_out_channels']
+
+    class ConvModule(nn.Module):
+        def __init__(self, cin):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, mc, 3)
+
+    class MaskHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = nn.ModuleList([ConvModule(C if i == 0 else mc) for i in range(4)])
+            self.upsample = nn.ConvTranspose2d(mc, mc, 2, 2); self.conv_logits = nn.Conv2d(mc, 1, 1)
+
+    class RoIHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bbox_head = BBoxHead(); self.mask_head = MaskHead()
+            self.shared_head = res_layer(C, C // 2, C, 3, force_down=False)
+            self.cls_reg_shared_conv = nn.Conv2d(2 * C, C, 1); self.cls_reg_shared_conv_norm = nn.GroupNorm(32, C)
+
+    class Det(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = Backbone(); self.rpn_head = RPN(); self.roi_head = RoIHead()
+    return Det()
+
+
+def test_optimizer_index_space_is_the_reference_models_named_parameters():
+    """a reference checkpoint's Adagrad state indexes EVERY parameter (mmcv's constructor lists frozen ones
+    under paramwise_cfg; Adagrad creates state for all).  ``reference_param_order`` must be ``named_parameters()`` of a
+    detector with the reference's registration order - names AND shapes, layer4 included."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.train import reference_param_order, trainable_names
+    from fgn_amd.weights import init_state_dict
+    cfg = tiny_config(3, 2, width_div=2)
+    sd = init_state_dict(cfg, 0)
+    det = _reference_shaped_detector(cfg)
+    want = [(k, tuple(p.shape)) for k, p in det.named_parameters()]
+    got = reference_param_order(sd, cfg['backbone'])
+    assert [k for k, _ in got] == [k for k, _ in want]
+    assert got == want
+    # every state-dict tensor of this build that is a parameter sits in that order; only layer4 is extra
+    names = [k for k, _ in got]
+    mine = [k for k in sd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    assert set(mine) < set(names) and all(k.startswith('backbone.layer4.') for k in set(names) - set(mine))
+    assert set(trainable_names(sd)) == {k for k in names if not k.startswith('backbone.')}
+    # a real torch Adagrad over ALL parameters, one group each (frozen backbone included), has that many entries
+    for k, p in det.named_parameters():
+        p.requires_grad_(not k.startswith('backbone.'))
+    opt = torch.optim.Adagrad([{'params': [p]} for p in det.parameters()], lr=0.005, weight_decay=1e-5)
+    osd = opt.state_dict()
+    assert len(osd['state']) == len(osd['param_groups']) == len(names)
