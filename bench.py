@@ -304,10 +304,36 @@ def main():
     comm_stream = torch.cuda.Stream()
     ep_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else [None]
     gathered_last = {}
+    gather_on_compute = bool(os.environ.get('FGN_BENCH_GATHER_ON_COMPUTE'))
+    gather_pool = None
+    if world > 1 and backend == 'gloo':
+        # rehearsal backend: gloo has no device collective, so the records go through the host.  Done inline that is
+        # a host-blocking D2H + all-gather in the launch loop (every rank's HOST then runs in lockstep, which RCCL
+        # does not do: its all-gather is enqueued and the host moves on).  A single worker thread per rank keeps the
+        # rehearsal's host side shaped like the real thing: collectives are issued in step order, the launch loop
+        # does not wait for them.
+        from concurrent.futures import ThreadPoolExecutor
+        gather_pool = ThreadPoolExecutor(max_workers=1)
+
+    def gather(recs, cnts):
+        if gather_pool is None or gather_on_compute:
+            return fdist.gather_detections(recs, cnts)
+        ready = torch.cuda.current_stream().record_event()
+
+        def work():
+            torch.cuda.set_device(dev)
+            ready.synchronize()
+            with torch.cuda.stream(comm_stream):
+                return fdist.gather_detections(recs, cnts)
+        return gather_pool.submit(work)
+
+    jitter_ms = float(os.environ.get('FGN_BENCH_JITTER_MS', '0'))     # rehearsal: rank r is late once every `world` steps
 
     def launch(i, profile=None):
         """Queue one step's device work (asynchronous): H2D of the episode, the whole path, D2H of the results."""
         e = episodes[i % n_distinct]
+        if jitter_ms and world > 1 and i % world == rank:
+            time.sleep(jitter_ms * 1e-3)
         ops.PROFILE = profile
         st = ep_streams[i % len(ep_streams)]
         ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
@@ -319,22 +345,25 @@ def main():
         finally:
             ops.PROFILE = None
         if world > 1:
-            # one RCCL all-gather of fixed-size padded records (boxes, scores, labels, mask probabilities) per step,
-            # on a communication stream behind an event of the episode (no host synchronisation): the next
-            # episode's kernels do not queue behind the collective, so a rank that runs a step late does not stall
-            # the others' compute
-            if model.use_graphs:      # replayed graphs reuse their output buffers: keep the gather in stream order
+            # one RCCL all-gather of fixed-size padded records (boxes, scores, labels, mask probabilities) per step.
+            # The records are packed on the CALLER stream - five small copies out of the episode's output buffers,
+            # which a replayed hipGraph overwrites with its next replay, into fresh memory - and the collective itself
+            # runs on the communication stream behind an event: the next episode's kernels never queue behind it, so a
+            # rank that runs a step late delays the others' gathered results, not their compute (eager and graph
+            # mode alike; FGN_BENCH_GATHER_ON_COMPUTE=1 puts it back on the caller stream for the A/B of
+            # tools/rehearse_jitter.sh)
+            with ctx:
+                recs, cnts = fdist.pack_detections(dets, max_det)
+                packed = torch.cuda.current_stream().record_event()
+            if gather_on_compute:
                 with ctx:
-                    recs, cnts = fdist.pack_detections(dets, max_det)
-                    gathered_last['g'] = fdist.gather_detections(recs, cnts)
+                    gathered_last['g'] = gather(recs, cnts)
             else:
-                comm_stream.wait_event(done)
+                comm_stream.wait_event(packed)
                 with torch.cuda.stream(comm_stream):
-                    recs, cnts = fdist.pack_detections(dets, max_det)
-                    gathered_last['g'] = fdist.gather_detections(recs, cnts)
-                for d in dets:
-                    for k in ('det_bboxes', 'det_labels', 'n_dets', 'mask_prob'):
-                        d[k].record_stream(comm_stream)
+                    gathered_last['g'] = gather(recs, cnts)
+                recs.record_stream(comm_stream)
+                cnts.record_stream(comm_stream)
         return e, dets
 
     latencies = []        # seconds from the start of an episode's launch to its packed result dicts (host clock)
@@ -417,6 +446,9 @@ def main():
     run(args.warmup)
 
     def barrier():
+        g = gathered_last.get('g')
+        if hasattr(g, 'result'):      # gloo rehearsal: the worker thread's collectives are done before the main thread's
+            g.result()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -523,6 +555,8 @@ def main():
                                                 'max': round(max(per_rank_dt) / args.steps * 1e3, 3),
                                                 'all': [round(v / args.steps * 1e3, 3) for v in per_rank_dt]},
                        'rank_placement': rank_info,
+                       'gather_stream': (None if world == 1 else 'caller' if gather_on_compute else 'communication'),
+                       'jitter_ms_rehearsal': jitter_ms or None,
                        'caller_streams': args.streams, 'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
                        'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,
@@ -582,7 +616,8 @@ def main():
             # rank 0 holds every rank's detections of the last step incl. the mask probabilities: materialise the
             # complete result dicts of all `world` episodes from the gathered records (off the timed path) and
             # check rank 0's own episode against the dict its normal path produced
-            g_recs, g_cnts = gathered_last['g']
+            g = gathered_last['g']
+            g_recs, g_cnts = g.result() if hasattr(g, 'result') else g
             torch.cuda.synchronize()
             ih, iw = int(episodes[0]['img_shape'][0][0]), int(episodes[0]['img_shape'][0][1])
             full = fdist.results_from_gathered(g_recs.reshape(-1, *g_recs.shape[2:]), g_cnts.reshape(-1), (ih, iw),
