@@ -74,6 +74,32 @@ struct ConvParams {
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats
 
+// Diagnostic build only (-DCONV_CLOCK_STAMPS, tools/micro/gemm_clock.hip; the product library never defines it): one
+// workgroup-level pair of (s_memtime = shader cycles, s_memrealtime = 100 MHz) stamps around a kernel's work, written
+// to a buffer of their own that nothing else reads - the in-kernel clock of MI355X_MICROARCH.md "DVFS give-back" (6).
+#ifdef CONV_CLOCK_STAMPS
+__device__ unsigned long long g_clock_stamps[16384 * 4];
+#define CLOCK_STAMP_BEGIN()                                                \
+    const unsigned long long cs_t0 = __builtin_amdgcn_s_memtime();         \
+    const unsigned long long cs_r0 = __builtin_amdgcn_s_memrealtime();     \
+    __builtin_amdgcn_s_waitcnt(0xC07F)
+#define CLOCK_STAMP_END(slot)                                              \
+    do {                                                                   \
+        const unsigned long long cs_t1 = __builtin_amdgcn_s_memtime();     \
+        const unsigned long long cs_r1 = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                \
+        if (threadIdx.x == 0 && (slot) < 16384) {                          \
+            g_clock_stamps[(slot) * 4 + 0] = cs_t0;                        \
+            g_clock_stamps[(slot) * 4 + 1] = cs_t1;                        \
+            g_clock_stamps[(slot) * 4 + 2] = cs_r0;                        \
+            g_clock_stamps[(slot) * 4 + 3] = cs_r1;                        \
+        }                                                                  \
+    } while (0)
+#else
+#define CLOCK_STAMP_BEGIN() do { } while (0)
+#define CLOCK_STAMP_END(slot) do { } while (0)
+#endif
+
 // Per-thread staging state, fixed for the whole K loop: for each A row this thread loads, the
 // element offset of the (ky=0,kx=0) tap and a bit mask of the filter taps that fall inside the
 // image.  Per K-tile the address is then `off + uniform tap offset` (one VALU add) and the
@@ -804,7 +830,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MIN_WAVES, int MODE>
 __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_kernel(const ConvParams p) {
+    CLOCK_STAMP_BEGIN();
     conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, MODE>(p, blockIdx.x, gridDim.x, blockIdx.y);
+#ifdef CONV_CLOCK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CLOCK_STAMP_END(blockIdx.x);
 }
 
 // Two convolutions with the SAME weights on two tensors of different geometry (the query map and the support maps of
@@ -934,6 +965,7 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
     int m0, n0;
     int tile = next_active(blockIdx.x, m0, n0);
     if (tile < 0) return;
+    CLOCK_STAMP_BEGIN();
     set_offsets(m0, n0);
     issue_tile(0, 0);
 
@@ -1061,6 +1093,206 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         tile = next; m0 = nm0; n0 = nn0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLOCK_STAMP_END(blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent point-wise kernel, second form (round 4): any workgroup tile BM x BN out of wave tiles WM x WN
+// (NW = (BM/WM)*(BN/WN) waves), v_mfma_f32_16x16x4_f32 only, and NO LDS round trip in the epilogue.
+//   * The MFMA is issued with its operands SWAPPED (B fragment as "A", A fragment as "B"): the 16x16 result tile is then
+//     C^T, i.e. lane (c = lane & 15, g = lane >> 4) holds C[m = c][n = 4g .. 4g+3] in its four accumulator registers -
+//     four CONSECUTIVE output channels of one row.  The epilogue is one 16-byte global store (and one 16-byte residual
+//     load, one 16-byte scale / shift load) per 16x16 tile straight from the accumulators: no C tile in LDS, no
+//     epilogue barriers, and the LDS the C tile took is free for a larger operand tile.  (Same products in the same k
+//     order as the unswapped form: bit-identical sums.)
+//   * Larger tiles: a 64x64 wave tile reads half the LDS bytes per MFMA of the 32x32 one and a 128x128 workgroup tile
+//     takes half the L2 -> LDS bytes per MFMA of the 64x64 one - the two largest levers on the clock the chip holds in
+//     an MFMA-dense loop (cdna_hip_programming.md 5.4 rule 28) - and runs one barrier per 4096 MFMA cycles of a wave
+//     instead of one per 1024.
+//   * Fragments of the next 16-deep step are read while the current step's MFMAs issue (two register sets).
+//   * Grouped GEMM with any BM: a row tile never straddles two groups (tiles are numbered per group, the last one of a
+//     group is cut at the group's valid rows), so t_pad stays a multiple of 64.
+// Tile order: XCD-contiguous runs of logical tiles; inside a group band-major ([band][row tile][channel tile of the
+// band]) so that a band's weights stay in the XCD's L2 while the group's rows stream past.
+// ------------------------------------------------------------------------------------------------
+struct Persist2Geom {
+    int mt;          // row tiles per group (grouped GEMM) or of the whole launch
+    int band_nt;     // channel tiles per band (divides n_tiles_n; n_tiles_n = no banding)
+    int n_groups;    // 1 for a plain convolution
+};
+
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_persist2_kernel(const ConvParams p,
+                                                                                          const Persist2Geom gm,
+                                                                                          const int total_tiles) {
+    constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
+    constexpr int RPP = NW * 8;                        // tile rows one DMA pass of the workgroup covers
+    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+    constexpr int TI = WM / 16, TJ = WN / 16;
+    constexpr int STAGE = (BM + BN) * BK;              // floats
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv / NWN, wn = wv - wm * NWN;
+    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
+    int grp_valid = p.grp_valid;
+    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+    grp_valid = min(grp_valid, p.grp_rows);
+
+    const int col4 = t & 7, row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const int KT = p.K / BK;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    const int nq = total_tiles >> 3, nr = total_tiles & 7;
+    const int per_grp = gm.mt * p.n_tiles_n, per_band = gm.mt * gm.band_nt;
+    // tile -> (first row, row limit, first channel, weight offset of the group); false: nothing to compute
+    auto coords = [&](int tile, int& m0, int& mend, int& n0, int& wofs) -> bool {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
+        const int grp = bid / per_grp;
+        int r = bid - grp * per_grp;
+        const int band = r / per_band;
+        r -= band * per_band;
+        const int mi = r / gm.band_nt;
+        n0 = (band * gm.band_nt + (r - mi * gm.band_nt)) * BN;
+        if (p.grp_rows) {
+            m0 = grp * p.grp_rows + mi * BM;
+            mend = min(M, grp * p.grp_rows + grp_valid);
+            wofs = grp * p.grp_w_stride;
+        } else {
+            m0 = mi * BM;
+            mend = M;
+            wofs = 0;
+        }
+        return m0 < mend;
+    };
+    auto next_active = [&](int tile, int& m0, int& mend, int& n0, int& wofs) -> int {
+        for (; tile < total_tiles; tile += gridDim.x)
+            if (coords(tile, m0, mend, n0, wofs)) return tile;
+        return -1;
+    };
+
+    unsigned a_voff[A_LD], b_voff[B_LD];
+    auto set_offsets = [&](int m0, int mend, int n0, int wofs) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + RPP * i;
+            a_voff[i] = m < mend ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+        }
+        const int b0 = (wofs + (n0 + row0) * p.K + src_c4 * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * RPP * p.K * 4);
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+        const unsigned ko = (unsigned)(kt * BK * 4);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * RPP * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        const unsigned sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * RPP * 128, b_voff[i] + ko);
+    };
+
+    const int r16 = lane & 15, g16 = lane >> 4;
+    // fragment read: row (base + 16 i + r16), 16-byte chunk (4 kk + g16) ^ swizzle(row); the swizzle of row r is
+    // (r >> 1) & 7 and the bases are multiples of 16, so it depends on r16 alone
+    const int fswz = (r16 >> 1) & 7;
+    const float* const rd_a = smem + (wm * WM + r16) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
+
+    int m0, mend, n0, wofs;
+    int tile = next_active(blockIdx.x, m0, mend, n0, wofs);
+    if (tile < 0) return;
+    CLOCK_STAMP_BEGIN();
+    set_offsets(m0, mend, n0, wofs);
+    issue_tile(0, 0);
+
+    while (true) {
+        f32x4 acc[TI][TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves')
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
+            f32x4 af[2][TI], bf[2][TJ];
+            const int pc0 = ((0 * 4 + g16) ^ fswz) * 4, pc1 = ((1 * 4 + g16) ^ fswz) * 4;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(As + 16 * i * BK + pc0);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bs + 16 * j * BK + pc0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[1][i] = *reinterpret_cast<const f32x4*>(As + 16 * i * BK + pc1);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[1][j] = *reinterpret_cast<const f32x4*>(Bs + 16 * j * BK + pc1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // k-slot e of the 16-deep step over ALL accumulators before slot e + 1: an accumulator sees its next
+                // MFMA TI*TJ issues later (dependent latency 40 cycles, issue 32); operands swapped: the accumulator
+                // holds C^T (see the header of this kernel)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
+            }
+            // reads of stage `cur` must have returned before the barrier is signalled (the next DMA overwrites it)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        // both stages are free: the first K-tile of the next output tile flies while this tile's accumulators are stored
+        const int em0 = m0, emend = mend, en0 = n0;
+        int nm0 = 0, nmend = 0, nn0 = 0, nwofs = 0;
+        const int next = next_active(tile + gridDim.x, nm0, nmend, nn0, nwofs);
+        if (next >= 0) {
+            set_offsets(nm0, nmend, nn0, nwofs);
+            issue_tile(0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = en0 + wn * WN + 16 * j + 4 * g16;
+            if (n >= p.Cout) continue;                                   // Cout % 4 == 0 (checked by the launcher)
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int m = em0 + wm * WM + 16 * i + r16;
+                if (m >= emend) continue;
+                const size_t o = (size_t)m * p.Cout + n;
+                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (p.residual) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+        }
+        if (next < 0) break;
+        tile = next; m0 = nm0; mend = nmend; n0 = nn0; wofs = nwofs;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLOCK_STAMP_END(blockIdx.x);
 }
 
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
@@ -1210,6 +1442,74 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     return FGN_OK;
 }
 
+// tuning knobs (fgn_conv2d_tune): forced tile code (-1 = heuristic) and workgroups per CU (0 = the tile's default)
+static int g_pw2_force = getenv("FGN_PW2") ? atoi(getenv("FGN_PW2")) : -1;      // -1: the heuristic below
+static int g_pw2_wgs = getenv("FGN_PW2_WGS") ? atoi(getenv("FGN_PW2_WGS")) : 0;   // 0: the tile's own workgroups per CU
+// ---- conv_pw_persist2_kernel: launch -------------------------------------------------------------------------
+// tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 64x128 (32x64), 3 = 128x64 (64x32), 4 = 64x64 (32x32),
+// 5 = 128x128 with 8 waves of 32x64
+template <int BM, int BN, int WM, int WN, int MINW, int WG_PER_CU>
+static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream) {
+    ConvParams p = p0;
+    p.n_tiles_n = cdiv(p.Cout, BN);
+    Persist2Geom gm;
+    gm.n_groups = p.grp_rows ? M_max / p.grp_rows : 1;
+    gm.mt = p.grp_rows ? cdiv(p.grp_rows, BM) : cdiv(M_max, BM);
+    static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
+    const long long per_nt = (long long)BN * p.K * 4;
+    gm.band_nt = p.n_tiles_n;
+    if (budget > 0 && per_nt * p.n_tiles_n > budget) {
+        int nb = (int)std::max<long long>(1, budget / per_nt);
+        while (nb > 1 && p.n_tiles_n % nb) --nb;
+        gm.band_nt = nb;
+    }
+    const long long total = (long long)gm.n_groups * gm.mt * p.n_tiles_n;
+    if (total <= 0 || total >= (1ll << 30)) return FGN_ERR_SHAPE;
+    const int per_cu = g_pw2_wgs > 0 ? g_pw2_wgs : WG_PER_CU;
+    const int cap = 256 * per_cu;
+    const int grid = (int)std::min<long long>((total + 7) / 8 * 8, cap);
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    static unsigned long long ok = 0ull;
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist2_kernel<BM, BN, WM, WN, MINW>), &ok);
+    if (attr != hipSuccess) return (int)attr;
+    FGN_LAUNCH_TIMED((conv_pw_persist2_kernel<BM, BN, WM, WN, MINW>), dim3(grid), dim3(NT), lds, stream, p, gm, (int)total);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+static int launch_persist2(int code, const ConvParams& p, int M_max, hipStream_t stream) {
+    switch (code) {
+        case 1: return launch_persist2_t<128, 128, 64, 64, 2, 2>(p, M_max, stream);
+        case 2: return launch_persist2_t<64, 128, 32, 64, 3, 3>(p, M_max, stream);
+        case 3: return launch_persist2_t<128, 64, 64, 32, 3, 3>(p, M_max, stream);
+        case 4: return launch_persist2_t<64, 64, 32, 32, 4, 4>(p, M_max, stream);
+        case 5: return launch_persist2_t<128, 128, 32, 64, 4, 2>(p, M_max, stream);
+        default: return FGN_ERR_ARG;
+    }
+}
+
+// Which point-wise launches take conv_pw_persist2_kernel, and with which tile (0: none).  FGN_PW2 forces a code for
+// every eligible launch (tools/gemm_time.py A/B); eligible = 1x1 / stride 1 on the LDS-DMA path, no split-K, no fused
+// input scale, Cout % 4 == 0.
+
+static int pick_persist2(long long M, int Cout, int K, bool grouped) {
+    if (g_pw2_force >= 0) return g_pw2_force;
+    (void)M; (void)Cout; (void)K; (void)grouped;
+    return 0;
+}
+
+// Tuning knobs at run time (tools/: interleaved A/B of kernel variants inside ONE process, cdna_hip_programming.md 5.4
+// rule 24).  knob 0: tile code of conv_pw_persist2_kernel for every eligible point-wise launch (-1 = heuristic,
+// 0 = never); knob 1: its workgroups per CU (0 = the tile's default).  Returns the previous value.
+extern "C" int fgn_conv2d_tune(int knob, int value) {
+    int* k = knob == 0 ? &g_pw2_force : knob == 1 ? &g_pw2_wgs : nullptr;
+    if (!k) return FGN_ERR_ARG;
+    const int prev = *k;
+    *k = value;
+    return prev;
+}
+
 // tile choice (measured on MI355X, tools/conv_bench.py): 64x64 everywhere, except when the 128x128 grid is one nearly
 // full round of 2 workgroups per CU (the 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per
 // MAC is worth ~8 %.  1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (tile_hint forces one; tests).
@@ -1324,6 +1624,11 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
             p.splits = cdiv(KT, p.kt_per_split);
         }
     }
+    if (p.splits == 1 && !in_scale && p.x_bytes != 0 && !cin4 && KH == 1 && KW == 1 && stride == 1 && pad == 0 &&
+        a_img_div == 1 && (Cout & 3) == 0 && tile_hint == 0) {
+        const int code = pick_persist2(M, Cout, p.K, false);
+        if (code) return launch_persist2(code, p, (int)M, stream);
+    }
     switch (tile) {
         case 1: return launch_cfg<128, 128, 64, 64, 2>(p, (int)M, cin4, stream);
         case 2: return launch_cfg<64, 128, 32, 64, 3>(p, (int)M, cin4, stream);
@@ -1423,5 +1728,9 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
     p.n_tiles_n = 0;
+    {
+        const int code = pick_persist2(rows, Cout, p.K, true);
+        if (code) return launch_persist2(code, p, (int)rows, stream);
+    }
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

@@ -21,6 +21,7 @@ SIGNATURES = {
     'fgn_profile_next_launch': (_i, [_p, _p]),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
     'fgn_conv2d_kernel_id': (_i, [_i] * 14),
+    'fgn_conv2d_tune': (_i, [_i, _i]),
     'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p, _p]),
     'fgn_conv2d_splitk_tickets': (_i, [_i] * 10),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -225,3 +225,88 @@ def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
     oq, os_ = buf[:yq.numel()].view(yq.shape), buf[yq.numel():].view(ys.shape)
     ops.conv2d_pair(xq, xs, layer, oq, os_)
     assert torch.equal(oq, yq) and torch.equal(os_, ys)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv_pw_persist2_kernel (round 4): every tile code through the tuning knob, against fp64 and against
+# the round-3 kernels on the same operands
+# ------------------------------------------------------------------------------------------------
+class _pw2:
+    """``with _pw2(code):`` forces tile code `code` of conv_pw_persist2_kernel for every eligible launch."""
+
+    def __init__(self, code):
+        self.code = code
+
+    def __enter__(self):
+        from fgn_amd import lib
+        self.prev = lib.load().fgn_conv2d_tune(0, self.code)
+
+    def __exit__(self, *a):
+        from fgn_amd import lib
+        lib.load().fgn_conv2d_tune(0, self.prev)
+
+
+@pytest.mark.parametrize('code', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('rows,cin,cout,res,relu', [(1000, 64, 72, True, True), (49 * 37, 96, 256, False, True),
+                                                     (130, 1024, 512, True, False), (64 * 9 + 1, 32, 4, False, False)])
+def test_persist2_pointwise_matches_fp64_and_round3_kernel(code, rows, cin, cout, res, relu):
+    """1x1 / stride 1 convolutions with BN epilogue (+ residual, ReLU): row counts that end inside a tile, Cout that
+    ends inside a 16-channel MFMA tile and inside a workgroup tile, K of 1..32 K-tiles; a device-side image count."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(rows + cin + cout)
+    x = torch.randn(rows, cin, 1, 1, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    r = torch.randn(rows, cout, 1, 1, generator=g) if res else None
+    ref = _ref(x, wt, None, bn, 1, 0, r, relu)
+    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
+    xc, rc = _nhwc(x).cuda(), None if r is None else _nhwc(r).cuda()
+    with _pw2(0):
+        old = ops.conv2d(xc, layer, residual=rc).clone()
+    with _pw2(code):
+        got = ops.conv2d(xc, layer, residual=rc).clone()
+        cnt = torch.tensor([rows - 77], dtype=torch.int32, device='cuda')
+        part = torch.full((rows, 1, 1, cout), -7.0, device='cuda')
+        ops.conv2d(xc, layer, residual=rc, n_img_dev=cnt, out=part)
+    scale = ref.abs().max().item() + 1e-6
+    assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * scale + 1e-6
+    # same products in the same k order as the round-3 kernels; the epilogue may contract differently (one ulp)
+    assert (got - old).abs().max().item() <= 2e-6 * scale
+    assert torch.equal(part[:rows - 77], got[:rows - 77]) and float((part[rows - 77:] + 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('code', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 64, 128), (5, 4, 512, 64), (100, 4, 32, 256)])
+def test_persist2_grouped_gemm_is_bit_identical_to_the_round3_kernel(code, n, tiles, cin, cout):
+    """The grouped Winograd GEMM (36 groups, per-group weights): t_pad is a multiple of 64, so with 128-row tiles the
+    last row tile of every group is cut at the group's end; rows past n * tiles of a group and items past the device
+    count are never written.  No epilogue arithmetic -> the sums are the round-3 kernel's bit for bit."""
+    from fgn_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(n * tiles + cin)
+    t_pad = L.fgn_winograd_t_pad(n * tiles)
+    V = torch.randn(36, t_pad, cin, generator=g).cuda()
+    U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) / cin ** 0.5).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(force, cnt=None):
+        Mo = torch.full((36, t_pad, cout), -7.0, device='cuda')
+        with _pw2(force):
+            rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
+                                         n, tiles, t_pad, cin, cout, U.shape[1], 36, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return Mo
+    old, got = run(0), run(code)
+    valid = n * tiles
+    ref = torch.einsum('gtc,gnc->gtn', V[:, :valid].double(), U[:, :cout].double()).float()
+    assert (got[:, :valid] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(got[:, :valid], old[:, :valid])
+    # rows of a group past its valid rows: the round-3 kernel writes the padding rows of a started 64-row tile,
+    # this one writes none of them
+    assert float((got[:, valid:] + 7.0).abs().max()) == 0.0 if valid < t_pad else True
+    cnt = torch.tensor([n - 1], dtype=torch.int32, device='cuda')
+    part = run(code, cnt)
+    v2 = (n - 1) * tiles
+    assert torch.equal(part[:, :v2], got[:, :v2]) and float((part[:, v2:] + 7.0).abs().max()) == 0.0

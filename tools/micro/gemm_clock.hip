@@ -1,0 +1,120 @@
+// In-kernel clock of the GEMM kernels under sustained load (MI355X_MICROARCH.md "DVFS give-back" item 6): a diagnostic
+// build of csrc/conv_igemm.hip (-DCONV_CLOCK_STAMPS: one s_memtime / s_memrealtime pair around each workgroup's work,
+// written to a buffer nothing else reads), >= 2.5 s of back-to-back launches of ONE GEMM shape on random data, then
+//   clock  = median over workgroups of  d(s_memtime) / d(s_memrealtime) * 100 MHz
+//   pipe   = MFMA issue cycles per SIMD (32 per v_mfma_f32_16x16x4_f32, 64 per 32x32x2) / median workgroup span in
+//            shader cycles of the LAST launch - the share of the span in which a SIMD's matrix pipe was issuing
+// build (here or on the box):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCONV_CLOCK_STAMPS tools/micro/gemm_clock.hip -o tools/micro/gemm_clock
+// usage: gemm_clock [seconds]      prints one JSON object per (shape, kernel variant)
+#include "../../fgn_amd/csrc/conv_igemm.hip"
+#include "../../fgn_amd/csrc/abi.hip"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static float* dev_random(size_t n, float scale, unsigned seed) {
+    std::vector<float> h(n);
+    std::mt19937 g(seed);
+    std::uniform_real_distribution<float> d(-1.f, 1.f);
+    for (auto& v : h) v = d(g) * scale;
+    float* p = nullptr;
+    if (hipMalloc(&p, n * 4) != hipSuccess) return nullptr;
+    (void)hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice);
+    return p;
+}
+
+struct Shape { const char* name; bool grouped; int n, tiles, rows, cin, cout; };
+
+static int run(const Shape& sh, int variant, double seconds) {
+    hipStream_t st; CK(hipStreamCreate(&st));
+    float *A = nullptr, *W = nullptr, *Y = nullptr;
+    int rc = 0;
+    double flop = 0;
+    const int cout_pad = (sh.cout + 127) / 128 * 128;
+    int t_pad = 0;
+    if (sh.grouped) {
+        t_pad = fgn_winograd_t_pad(sh.n * sh.tiles);
+        A = dev_random((size_t)36 * t_pad * sh.cin, 1.f, 1);
+        W = dev_random((size_t)36 * cout_pad * sh.cin, 0.03f, 2);
+        CK(hipMalloc(&Y, (size_t)36 * t_pad * sh.cout * 4));
+        flop = 2.0 * 36 * sh.n * sh.tiles * sh.cin * sh.cout;
+    } else {
+        A = dev_random((size_t)sh.rows * sh.cin, 1.f, 1);
+        W = dev_random((size_t)cout_pad * sh.cin, 0.03f, 2);
+        CK(hipMalloc(&Y, (size_t)sh.rows * sh.cout * 4));
+        flop = 2.0 * sh.rows * sh.cin * sh.cout;
+    }
+    if (!A || !W) return 1;
+    fgn_conv2d_tune(0, variant);
+    auto launch = [&]() -> int {
+        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, st)
+                          : fgn_conv2d_nhwc_f32(A, W, Y, nullptr, nullptr, nullptr, nullptr, nullptr, sh.rows, 1, 1, sh.cin, sh.cout,
+                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, nullptr, 0, nullptr, st);
+    };
+    for (int i = 0; i < 3; ++i) rc |= launch();
+    CK(hipStreamSynchronize(st));
+    if (rc) { fprintf(stderr, "launch rc %d\n", rc); return 1; }
+    // >= `seconds` of back-to-back launches; the stamps of the last launch are read
+    const auto t0 = std::chrono::steady_clock::now();
+    long launches = 0;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double last_batch_ms = 0; int batch = 50;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < batch; ++i) launch();
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        last_batch_ms = ms; launches += batch;
+    }
+    std::vector<unsigned long long> h(16384 * 4);
+    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_clock_stamps), h.size() * 8));
+    std::vector<double> clk, span;
+    for (int b = 0; b < 16384; ++b) {
+        const unsigned long long t0s = h[b * 4], t1s = h[b * 4 + 1], r0 = h[b * 4 + 2], r1 = h[b * 4 + 3];
+        if (t1s > t0s && r1 > r0 && r1 - r0 > 200) {       // >= 2 us of work
+            clk.push_back((double)(t1s - t0s) / (double)(r1 - r0) * 0.1);   // GHz
+            span.push_back((double)(t1s - t0s));
+        }
+    }
+    // reset the stamp buffer for the next run
+    std::fill(h.begin(), h.end(), 0ull);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clock_stamps), h.data(), h.size() * 8));
+    if (clk.empty()) { fprintf(stderr, "%s v%d: no stamps\n", sh.name, variant); return 1; }
+    std::sort(clk.begin(), clk.end()); std::sort(span.begin(), span.end());
+    auto q = [](const std::vector<double>& v, double f) { return v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+    const double us = last_batch_ms * 1e3 / batch;
+    // MFMA issue cycles per SIMD for the whole launch: flop / (64 FLOP per cycle per SIMD) / 1024 SIMDs
+    const double mfma_cycles_per_simd = flop / 64.0 / 1024.0;
+    const double wall_cycles = us * 1e-6 * q(clk, 0.5) * 1e9;
+    printf("{\"shape\": \"%s\", \"variant\": %d, \"launches\": %ld, \"us_per_launch_back_to_back\": %.1f, \"tflops\": %.1f, "
+           "\"frac_of_157.3\": %.3f, \"clock_ghz_median\": %.3f, \"clock_ghz_p10\": %.3f, \"clock_ghz_p90\": %.3f, "
+           "\"workgroups_stamped\": %zu, \"wg_span_cycles_median\": %.0f, \"launch_wall_cycles_at_median_clock\": %.0f, "
+           "\"mfma_issue_cycles_per_simd\": %.0f, \"mfma_pipe_share_of_wall\": %.3f, \"mfma_pipe_share_of_wg_span\": %.3f}\n",
+           sh.name, variant, launches, us, flop / us / 1e6, flop / us / 1e6 / 157.3, q(clk, 0.5), q(clk, 0.1), q(clk, 0.9), clk.size(),
+           q(span, 0.5), wall_cycles, mfma_cycles_per_simd, mfma_cycles_per_simd / wall_cycles, mfma_cycles_per_simd / q(span, 0.5));
+    fflush(stdout);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); (void)hipStreamDestroy(st);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
+    const char* vlist = argc > 2 ? argv[2] : "0,1";
+    std::vector<int> variants;
+    for (const char* c = vlist; *c;) { variants.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; }
+    const Shape shapes[] = {
+        {"wino agrpn 36x(3x273) 1024>1024", true, 3, 273, 0, 1024, 1024},
+        {"wino sh300 36x(300x4) 512>512", true, 300, 4, 0, 512, 512},
+        {"relq 14700x1024>1024", false, 0, 0, 14700, 1024, 1024},
+        {"sh conv1 14700x1024>512 (r3: 128x128 DMA kernel)", false, 0, 0, 14700, 1024, 512},
+    };
+    int rc = 0;
+    for (const auto& sh : shapes)
+        for (int v : variants) rc |= run(sh, v, seconds);
+    return rc;
+}
