@@ -59,6 +59,11 @@ struct ConvParams {
     // ticket sums the slabs in slab order (the order splitk_epilogue_kernel uses: bit-identical results), applies the
     // epilogue and returns the ticket to zero.  nullptr: the reduce runs as splitk_epilogue_kernel.
     int32_t* tickets;
+    // tile scheduler of conv_pw_persist2_kernel: FGN_SCHED_WORDS zero-initialised int32 (one counter per XCD share of the
+    // tiles, 64 bytes apart), zero again when the launch has run.  Workgroups take their first tile by index and pull
+    // every further one from the counter of their share, so the last tiles of a launch go to whichever workgroups are
+    // free first instead of to a fixed 1/3 of them.  nullptr: fixed tile order (tile, tile + grid, ...).
+    int32_t* sched;
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
     // grouped GEMM (Winograd; 64x64 kernel, point-wise mode): rows [g*grp_rows, (g+1)*grp_rows) use the weight
     // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
@@ -72,6 +77,7 @@ struct ConvParams {
 #define CONV_DMA_STAGES 2
 #endif
 constexpr int BK = 32;
+constexpr int FGN_SCHED_WORDS = 8 * 16;
 constexpr int LDS_STRIDE = 36;  // floats
 
 // Diagnostic build only (-DCONV_CLOCK_STAMPS, tools/micro/gemm_clock.hip; the product library never defines it): one
@@ -1149,12 +1155,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
     const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
     constexpr unsigned OOB = 0x7ffffff0u;
 
+    // Tiles are cut into 8 contiguous shares (one per value of blockIdx & 7: workgroups b and b + 8 sit on one XCD, so a
+    // share's operands stay in that XCD's L2); `idx` counts inside this workgroup's share.
     const int nq = total_tiles >> 3, nr = total_tiles & 7;
+    const int xk = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
+    const int size_x = nq + (xk < nr ? 1 : 0);
+    const int start_x = xk < nr ? xk * (nq + 1) : nr * (nq + 1) + (xk - nr) * nq;
     const int per_grp = gm.mt * p.n_tiles_n, per_band = gm.mt * gm.band_nt;
-    // tile -> (first row, row limit, first channel, weight offset of the group); false: nothing to compute
-    auto coords = [&](int tile, int& m0, int& mend, int& n0, int& wofs) -> bool {
-        const int xcd = tile & 7, idx = tile >> 3;
-        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
+    // tile of the share -> (first row, row limit, first channel, weight offset of the group); false: nothing to compute
+    auto coords = [&](int idx, int& m0, int& mend, int& n0, int& wofs) -> bool {
+        const int bid = start_x + idx;
         const int grp = bid / per_grp;
         int r = bid - grp * per_grp;
         const int band = r / per_band;
@@ -1172,10 +1182,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         }
         return m0 < mend;
     };
-    auto next_active = [&](int tile, int& m0, int& mend, int& n0, int& wofs) -> int {
-        for (; tile < total_tiles; tile += gridDim.x)
-            if (coords(tile, m0, mend, n0, wofs)) return tile;
-        return -1;
+    // ---- tile scheduler.  The first tile of a workgroup is idx = blockIdx >> 3 (no atomic in front of the first DMA);
+    // every further one is nwg_x + (old value of the share's counter).  Every workgroup ends on exactly one pull past
+    // the end of its share, so a share sees max(size_x - nwg_x, 0) + nwg_x pulls in all and the workgroup that draws
+    // the last of them returns the counter to zero for the next launch (kernel boundaries order it).  One lane pulls;
+    // the value reaches the other waves through one LDS word behind a workgroup barrier.
+    int* const s_next = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int32_t* const counter = p.sched ? p.sched + xk * 16 : nullptr;
+    const int pulls_x = max(size_x - nwg_x, 0) + nwg_x;
+    int pulled = 0;                                    // lane 0 of the workgroup: the value its pending pull returned
+    auto pull_issue = [&]() {
+        if (t == 0) pulled = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto pull_publish = [&]() {                        // lane 0: hand the pulled index to the workgroup (LDS word)
+        if (t == 0) {
+            if (pulled == pulls_x - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_next[0] = nwg_x + pulled;
+        }
+    };
+    // blocking form (start of a workgroup whose own first tile is empty, or a pulled tile without valid rows - a launch
+    // cut short by a device-side count): pull until a tile with work or the end of the share
+    auto pull_blocking = [&](int& m0, int& mend, int& n0, int& wofs) -> int {
+        int idx;
+        do {
+            pull_issue();
+            pull_publish();
+            __syncthreads();
+            idx = __builtin_amdgcn_readfirstlane(s_next[0]);
+            __syncthreads();
+        } while (idx < size_x && !coords(idx, m0, mend, n0, wofs));
+        return idx;
     };
 
     unsigned a_voff[A_LD], b_voff[B_LD];
@@ -1206,9 +1242,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
     const float* const rd_a = smem + (wm * WM + r16) * BK;
     const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
 
-    int m0, mend, n0, wofs;
-    int tile = next_active(blockIdx.x, m0, mend, n0, wofs);
-    if (tile < 0) return;
+    int m0 = 0, mend = 0, n0 = 0, wofs = 0;
+    int idx = blockIdx.x >> 3;
+    if (counter) {
+        if (!(idx < size_x && coords(idx, m0, mend, n0, wofs))) idx = pull_blocking(m0, mend, n0, wofs);
+    } else {
+        while (idx < size_x && !coords(idx, m0, mend, n0, wofs)) idx += nwg_x;
+    }
+    if (idx >= size_x) return;
     CLOCK_STAMP_BEGIN();
     set_offsets(m0, mend, n0, wofs);
     issue_tile(0, 0);
@@ -1222,9 +1263,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves')
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (counter) pull_issue();                       // the next tile's index arrives under this tile's K loop
         int cur = 0;
         for (int kt = 0; kt < KT; ++kt) {
             if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            else if (counter) pull_publish();            // ... and is handed to the workgroup behind the loop's last barrier
             asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
@@ -1259,8 +1302,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         // both stages are free: the first K-tile of the next output tile flies while this tile's accumulators are stored
         const int em0 = m0, emend = mend, en0 = n0;
         int nm0 = 0, nmend = 0, nn0 = 0, nwofs = 0;
-        const int next = next_active(tile + gridDim.x, nm0, nmend, nn0, nwofs);
-        if (next >= 0) {
+        int next;
+        if (counter) {
+            next = __builtin_amdgcn_readfirstlane(s_next[0]);
+            if (next < size_x && !coords(next, nm0, nmend, nn0, nwofs)) next = pull_blocking(nm0, nmend, nn0, nwofs);
+        } else {
+            next = idx + nwg_x;
+            while (next < size_x && !coords(next, nm0, nmend, nn0, nwofs)) next += nwg_x;
+        }
+        if (next < size_x) {
             set_offsets(nm0, nmend, nn0, nwofs);
             issue_tile(0, 0);
         }
@@ -1271,25 +1321,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
             if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+            // all residual rows of this channel block first (TI independent 16-byte loads in flight), then the arithmetic
+            float4 res[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int m = em0 + wm * WM + 16 * i + r16;
+                res[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.residual && m < emend) res[i] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int m = em0 + wm * WM + 16 * i + r16;
                 if (m >= emend) continue;
-                const size_t o = (size_t)m * p.Cout + n;
                 float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (p.residual) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
+                v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w;
                 if (p.relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<float4*>(p.y + o) = v;
+                *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
             }
         }
-        if (next < 0) break;
-        tile = next; m0 = nm0; mend = nmend; n0 = nn0; wofs = nwofs;
+        if (next >= size_x) break;
+        idx = next; m0 = nm0; mend = nmend; n0 = nn0; wofs = nwofs;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CLOCK_STAMP_END(blockIdx.x);
@@ -1469,7 +1523,7 @@ static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream
     const int cap = 256 * per_cu;
     const int grid = (int)std::min<long long>((total + 7) / 8 * 8, cap);
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + 16;      // + the scheduler's hand-off word
     static unsigned long long ok = 0ull;
     hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist2_kernel<BM, BN, WM, WN, MINW>), &ok);
     if (attr != hipSuccess) return (int)attr;
@@ -1541,6 +1595,12 @@ extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, 
     int mode = 3;
     if (use_dma && !has_in_scale)
         mode = cin4 ? 2 : (KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1) ? 1 : 0;
+    // conv_pw_persist2_kernel: tile code * 10 + 5 (the grouped Winograd GEMM asks with tile_hint 4)
+    if (mode == 1 && (Cout & 3) == 0 && (tile_hint == 0 || tile_hint == 4) &&
+        (tile_hint == 4 || plan_splits(M, Cout, K / BK, tile_hint) == 1)) {
+        const int code = pick_persist2(M, Cout, K, tile_hint == 4);
+        if (code) return code * 10 + 5;
+    }
     // point-wise launches with more 64x64 output tiles than resident workgroups run on conv_pw_persist_kernel
     if (mode == 1 && tile == 4 && (Cout & 3) == 0 && persist_blocks() > 0 &&
         ((M + 63) / 64) * cdiv(Cout, 64) > persist_blocks() && plan_splits(M, Cout, K / BK, tile_hint) == 1)
@@ -1574,7 +1634,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
                                    const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                                    int cout_pad, int KH, int KW, int stride, int pad, int a_img_div,
                                    int relu, int tile_hint, float* splitk_ws, size_t splitk_ws_bytes,
-                                   int32_t* splitk_tickets, hipStream_t stream) {
+                                   int32_t* splitk_tickets, int32_t* sched, hipStream_t stream) {
     if (!x || !w_packed || !y) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const bool cin4 = (Cin == 4);
@@ -1583,7 +1643,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (a_img_div < 1 || stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.tickets = splitk_tickets;
+    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.tickets = splitk_tickets; p.sched = sched;
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -1660,7 +1720,7 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
     for (int i = 0; i < 2; ++i) {
         ConvParams& p = ps[i];
         p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
-        p.in_scale = nullptr; p.n_img_dev = nullptr; p.tickets = nullptr;
+        p.in_scale = nullptr; p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = nullptr;
         p.n_img = ns[i]; p.H = Hs[i]; p.W = Ws[i]; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
         p.stride = stride; p.pad = pad; p.a_img_div = 1; p.relu = relu;
         p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -1707,9 +1767,12 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
 
+// int32 words of the tile scheduler workspace (`sched` of fgn_conv2d_nhwc_f32 / fgn_winograd_gemm_f32)
+extern "C" int fgn_gemm_sched_words(void) { return FGN_SCHED_WORDS; }
+
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                                      int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
-                                     hipStream_t stream) {
+                                     int32_t* sched, hipStream_t stream) {
     if (!V || !U || !Mo) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
@@ -1720,7 +1783,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
-    p.n_img_dev = nullptr; p.tickets = nullptr;
+    p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = sched;
     p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = Cin / BK;

@@ -39,8 +39,12 @@ _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32
 
 def kernel_name(kid: int) -> str:
     """fgn_conv2d_kernel_id -> the kernel name in a rocprofv3 kernel trace."""
-    bm, bn, wm, wn, mw = _TILES[kid // 10]
     mode = kid % 10
+    if mode == 5:      # conv_pw_persist2_kernel: tile code -> template arguments (csrc/conv_igemm.hip launch_persist2)
+        return 'conv_pw_persist2_kernel<%d, %d, %d, %d, %d>' % {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3),
+                                                               3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4),
+                                                               5: (128, 128, 32, 64, 4)}[kid // 10]
+    bm, bn, wm, wn, mw = _TILES[kid // 10]
     if mode == 4:      # template argument = MFMA shape (16x16x4 unless the tuning knob FGN_PW_M16=0 selects 32x32x2)
         return 'conv_pw_persist_kernel<%s>' % ('false' if os.environ.get('FGN_PW_M16') == '0' else 'true')
     if mode == 3:
@@ -132,6 +136,18 @@ class ConvProfile(list):
                 pair.append(e)
         _lib.check(_lib.load().fgn_profile_next_launch(pair[0].cuda_event, pair[1].cuda_event), 'fgn_profile_next_launch')
         return pair
+
+
+# Tile scheduler workspace of the persistent point-wise GEMM (include/fgn_hip.h, `sched`): 128 zero int32 per launch,
+# returned to zero by the launch.  Taken from the episode's zero arena (one private range per launch, so launches in
+# flight never share one); without an open arena a fresh torch.zeros (tests, tools).  FGN_GEMM_SCHED=0: fixed tile order.
+GEMM_SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'
+
+
+def _sched(device):
+    if not GEMM_SCHED:
+        return None
+    return zeros((_lib.load().fgn_gemm_sched_words(),), device, torch.int32)
 
 
 def _stream() -> int:
@@ -264,7 +280,8 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     rc = L.fgn_conv2d_nhwc_f32(
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
-        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _ptr(tickets), _stream())
+        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _ptr(tickets),
+        _ptr(_sched(x.device) if layer.kh == 1 and layer.stride == 1 and not ws_bytes else None), _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         kid = L.fgn_conv2d_kernel_id(n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw, layer.stride,
@@ -273,6 +290,7 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
         flop = 2.0 * ho * wo * layer.cout * layer.kh * layer.kw * (3 if cin == 4 else cin)
         prof.append(dict(kind='conv', kernel=kernel_name(kid), e0=e0, e1=e1, flop_direct=flop,
                          flop_issued=flop, n_img=n_img, n_img_dev=n_img_dev,
+                         gemm=(1, ho * wo, layer.cout, layer.kh * layer.kw * cin),       # groups, rows per image, N, K
                          shape=(n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
     return out
 
@@ -312,6 +330,8 @@ def conv2d_pair(x0: torch.Tensor, x1: torch.Tensor, layer: ConvLayer, out0: Opti
         flop = per_px * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)
         prof.append(dict(kind='conv', kernel='conv_igemm_dma_pair_kernel<64, 64, 32, 32, 2, 4, %d>' % (2 if layer.cin == 4 else 0),
                          e0=e0, e1=e1, flop_direct=flop, flop_issued=flop, n_img=1, n_img_dev=None,
+                         gemm=(1, sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs), layer.cout,
+                               layer.kh * layer.kw * (3 if layer.cin == 4 else layer.cin)),
                          shape=(x0.shape[0] + x1.shape[0], x0.shape[1], x0.shape[2], layer.cin, layer.cout, layer.kh,
                                 layer.stride)))
     return outs[0], outs[1]
@@ -431,7 +451,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     if ev is not None:
         ev.append(prof.arm())
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_f32')
+                                       layer.cout, layer.cout_pad, G, _ptr(_sched(x.device)), st), 'fgn_winograd_gemm_f32')
     if ev is not None:
         ev.append(prof.arm())
     _lib.check(f_out(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W, layer.cout, t_pad,
@@ -452,7 +472,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
         prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
-                         flop_issued=2.0 * G * tiles * layer.cout * cin, **common))
+                         flop_issued=2.0 * G * tiles * layer.cout * cin, gemm=(G, tiles, layer.cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
                          flop_issued=0.0, **common))
     return y
@@ -501,7 +521,7 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
     if prof is not None:
         ev.append(prof.arm())
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
-                                       G, st), 'fgn_winograd_gemm_f32')
+                                       G, _ptr(_sched(dev)), st), 'fgn_winograd_gemm_f32')
     if prof is not None:
         ev.append(prof.arm())
     if pair:
@@ -522,7 +542,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
                          e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
         prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
-                         flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin, **common))
+                         flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin,
+                         gemm=(G, total, cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel='wg4_output_kernel<%d>' % (vo // 10), e0=ev[2][0], e1=ev[2][1],
                          flop_direct=0.0, flop_issued=0.0, **common))
 

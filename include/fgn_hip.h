@@ -56,7 +56,14 @@ int fgn_profile_next_launch(void* start_event, void* stop_event);
  *   summed in slab order (bit-reproducible) before the epilogue.  NULL = never split.
  *   splitk_tickets: optional, fgn_conv2d_splitk_tickets() int32 values, ALL ZERO on entry (and
  *   zero again when the launch has run): the workgroup that publishes the last slab of an
- *   output tile reduces it inside the same launch.  NULL = the reduce runs as a second kernel. */
+ *   output tile reduces it inside the same launch.  NULL = the reduce runs as a second kernel.
+ *   sched: optional, fgn_gemm_sched_words() int32 values, ALL ZERO on entry (and zero again when the launch has
+ *   run): tile scheduler of the persistent point-wise kernel - its workgroups pull their next output tile from a
+ *   counter instead of walking a fixed order, so the last tiles of a launch go to whichever workgroups are free.
+ *   Used by 1x1 / stride 1 launches (and fgn_winograd_gemm_f32) that run on that kernel, ignored otherwise; one
+ *   workspace per launch IN FLIGHT (launches that may overlap on the GPU must not share one).  NULL = fixed order.
+ *   Results do not depend on it (each output tile is computed by one workgroup either way). */
+int fgn_gemm_sched_words(void);
 size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                   int pad, int tile_hint);
 /* Which kernel the dispatcher launches for a layer (tile*10 + mode; 41 = conv_igemm_dma_kernel<64,64,32,32,2,4,1>):
@@ -72,7 +79,7 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
                         const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                         int cout_pad, int KH, int KW, int stride, int pad, int a_img_div, int relu,
                         int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, int32_t* splitk_tickets,
-                        void* stream);
+                        int32_t* sched, void* stream);
 int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                               int tile_hint);
 
@@ -100,7 +107,8 @@ int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, cons
                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
 int fgn_winograd_t_pad(int tiles_total);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
+                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, int32_t* sched,
+                          void* stream);
 int fgn_winograd_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                             int H, int W, int C, int t_pad, int relu, void* stream);
 /* F(4x4,3x3) form of the same convolutions (the default): 36 tile positions (n_groups = 36 in

@@ -278,7 +278,7 @@ def test_persist2_pointwise_matches_fp64_and_round3_kernel(code, rows, cin, cout
 
 @pytest.mark.parametrize('code', [1, 2, 3, 4, 5])
 @pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 64, 128), (5, 4, 512, 64), (100, 4, 32, 256)])
-def test_persist2_grouped_gemm_is_bit_identical_to_the_round3_kernel(code, n, tiles, cin, cout):
+def test_persist2_grouped_gemm_all_tiles_and_the_tile_scheduler(code, n, tiles, cin, cout):
     """The grouped Winograd GEMM (36 groups, per-group weights): t_pad is a multiple of 64, so with 128-row tiles the
     last row tile of every group is cut at the group's end; rows past n * tiles of a group and items past the device
     count are never written.  No epilogue arithmetic -> the sums are the round-3 kernel's bit for bit."""
@@ -294,19 +294,32 @@ def test_persist2_grouped_gemm_is_bit_identical_to_the_round3_kernel(code, n, ti
         Mo = torch.full((36, t_pad, cout), -7.0, device='cuda')
         with _pw2(force):
             rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
-                                         n, tiles, t_pad, cin, cout, U.shape[1], 36, st)
+                                         n, tiles, t_pad, cin, cout, U.shape[1], 36,
+                                         None if sched is None else sched.data_ptr(), st)
         assert rc == 0
         torch.cuda.synchronize()
+        if sched is not None:
+            assert int(sched.abs().max()) == 0            # the scheduler's counters are back at zero after the launch
         return Mo
-    old, got = run(0), run(code)
+    sched = None
+    old, got, p4 = run(0), run(code), run(4)
     valid = n * tiles
     ref = torch.einsum('gtc,gnc->gtn', V[:, :valid].double(), U[:, :cout].double()).float()
     assert (got[:, :valid] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    assert torch.equal(got[:, :valid], old[:, :valid])
+    # every tile shape accumulates a sum in the same k order: the tile codes agree bit for bit (and with the round-3
+    # persistent kernel; its non-persistent 32x32x2 form pairs the k's differently: last-bit differences)
+    assert torch.equal(got[:, :valid], p4[:, :valid])
+    assert (got[:, :valid] - old[:, :valid]).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # the tile scheduler (workgroups pull their next tile from a counter) changes who computes a tile, not the tile
+    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
+    for _ in range(3):                                       # back to back on the same counters: they reset themselves
+        assert torch.equal(run(code), got)
+    sched = None
     # rows of a group past its valid rows: the round-3 kernel writes the padding rows of a started 64-row tile,
     # this one writes none of them
     assert float((got[:, valid:] + 7.0).abs().max()) == 0.0 if valid < t_pad else True
     cnt = torch.tensor([n - 1], dtype=torch.int32, device='cuda')
+    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')     # pulled tiles without valid rows
     part = run(code, cnt)
     v2 = (n - 1) * tiles
     assert torch.equal(part[:, :v2], got[:, :v2]) and float((part[:, v2:] + 7.0).abs().max()) == 0.0

@@ -11,6 +11,7 @@ g = torch.Generator().manual_seed(0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 variants = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 1, 2, 3, 4, 5]
+SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'    # (ops.conv2d reads the same switch)
 NAMES = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8'}
 
 
@@ -62,8 +63,9 @@ for name, (n, tiles, cin, cout) in {'wino agrpn 3x273 1024>1024': (3, 273, 1024,
     U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) * 0.03).cuda()
     Mo = torch.zeros(36, t_pad, cout, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
+    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda') if SCHED else None
     fn = lambda: L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout,
-                                         U.shape[1], 36, st)
+                                         U.shape[1], 36, None if sched is None else sched.data_ptr(), st)
     table[name] = run_shape(name, fn, Mo, 2.0 * 36 * n * tiles * cin * cout)
     del V, U, Mo
 for name, (rows, cin, cout, res) in {'relq 14700x1024>1024': (14700, 1024, 1024, False), 'sh conv3 14700x512>1024 +res': (14700, 512, 1024, True),

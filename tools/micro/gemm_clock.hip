@@ -50,10 +50,15 @@ static int run(const Shape& sh, int variant, double seconds) {
     }
     if (!A || !W) return 1;
     fgn_conv2d_tune(0, variant);
+    int32_t* sched = nullptr;
+    if (getenv("GEMM_CLOCK_SCHED") ? atoi(getenv("GEMM_CLOCK_SCHED")) : 1) {
+        CK(hipMalloc(&sched, fgn_gemm_sched_words() * 4));
+        CK(hipMemset(sched, 0, fgn_gemm_sched_words() * 4));
+    }
     auto launch = [&]() -> int {
-        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, st)
+        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, sched, st)
                           : fgn_conv2d_nhwc_f32(A, W, Y, nullptr, nullptr, nullptr, nullptr, nullptr, sh.rows, 1, 1, sh.cin, sh.cout,
-                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, nullptr, 0, nullptr, st);
+                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, nullptr, 0, nullptr, sched, st);
     };
     for (int i = 0; i < 3; ++i) rc |= launch();
     CK(hipStreamSynchronize(st));
