@@ -84,7 +84,7 @@ constexpr int LDS_STRIDE = 36;  // floats
 // workgroup-level pair of (s_memtime = shader cycles, s_memrealtime = 100 MHz) stamps around a kernel's work, written
 // to a buffer of their own that nothing else reads - the in-kernel clock of MI355X_MICROARCH.md "DVFS give-back" (6).
 #ifdef CONV_CLOCK_STAMPS
-__device__ unsigned long long g_clock_stamps[16384 * 4];
+__device__ unsigned long long g_clock_stamps[16384 * 6];
 #define CLOCK_STAMP_BEGIN()                                                \
     const unsigned long long cs_t0 = __builtin_amdgcn_s_memtime();         \
     const unsigned long long cs_r0 = __builtin_amdgcn_s_memrealtime();     \
@@ -94,11 +94,16 @@ __device__ unsigned long long g_clock_stamps[16384 * 4];
         const unsigned long long cs_t1 = __builtin_amdgcn_s_memtime();     \
         const unsigned long long cs_r1 = __builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                \
+        unsigned cs_xcc, cs_hw;                                            \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(cs_xcc)); \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(cs_hw));   \
         if (threadIdx.x == 0 && (slot) < 16384) {                          \
-            g_clock_stamps[(slot) * 4 + 0] = cs_t0;                        \
-            g_clock_stamps[(slot) * 4 + 1] = cs_t1;                        \
-            g_clock_stamps[(slot) * 4 + 2] = cs_r0;                        \
-            g_clock_stamps[(slot) * 4 + 3] = cs_r1;                        \
+            g_clock_stamps[(slot) * 6 + 0] = cs_t0;                        \
+            g_clock_stamps[(slot) * 6 + 1] = cs_t1;                        \
+            g_clock_stamps[(slot) * 6 + 2] = cs_r0;                        \
+            g_clock_stamps[(slot) * 6 + 3] = cs_r1;                        \
+            g_clock_stamps[(slot) * 6 + 4] = cs_xcc;                       \
+            g_clock_stamps[(slot) * 6 + 5] = cs_hw;                        \
         }                                                                  \
     } while (0)
 #else
@@ -1501,7 +1506,7 @@ static int g_pw2_force = getenv("FGN_PW2") ? atoi(getenv("FGN_PW2")) : -1;      
 static int g_pw2_wgs = getenv("FGN_PW2_WGS") ? atoi(getenv("FGN_PW2_WGS")) : 0;   // 0: the tile's own workgroups per CU
 // ---- conv_pw_persist2_kernel: launch -------------------------------------------------------------------------
 // tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 64x128 (32x64), 3 = 128x64 (64x32), 4 = 64x64 (32x32),
-// 5 = 128x128 with 8 waves of 32x64
+// 5 = 128x128 with 8 waves of 32x64, 6 = 64x64 with 8 waves of 32x16, 7 = 64x128 with 8 waves of 32x32, 8 = 32x64 (16x32)
 template <int BM, int BN, int WM, int WN, int MINW, int WG_PER_CU>
 static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream) {
     ConvParams p = p0;
@@ -1539,6 +1544,9 @@ static int launch_persist2(int code, const ConvParams& p, int M_max, hipStream_t
         case 3: return launch_persist2_t<128, 64, 64, 32, 3, 3>(p, M_max, stream);
         case 4: return launch_persist2_t<64, 64, 32, 32, 4, 4>(p, M_max, stream);
         case 5: return launch_persist2_t<128, 128, 32, 64, 4, 2>(p, M_max, stream);
+        case 6: return launch_persist2_t<64, 64, 32, 16, 8, 4>(p, M_max, stream);      // 8 waves on a 64x64 tile
+        case 7: return launch_persist2_t<64, 128, 32, 32, 6, 3>(p, M_max, stream);     // 8 waves on a 64x128 tile
+        case 8: return launch_persist2_t<32, 64, 16, 32, 4, 5>(p, M_max, stream);      // 4 waves on a 32x64 tile
         default: return FGN_ERR_ARG;
     }
 }

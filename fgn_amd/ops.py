@@ -43,7 +43,8 @@ def kernel_name(kid: int) -> str:
     if mode == 5:      # conv_pw_persist2_kernel: tile code -> template arguments (csrc/conv_igemm.hip launch_persist2)
         return 'conv_pw_persist2_kernel<%d, %d, %d, %d, %d>' % {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3),
                                                                3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4),
-                                                               5: (128, 128, 32, 64, 4)}[kid // 10]
+                                                               5: (128, 128, 32, 64, 4), 6: (64, 64, 32, 16, 8),
+                                                               7: (64, 128, 32, 32, 6), 8: (32, 64, 16, 32, 4)}[kid // 10]
     bm, bn, wm, wn, mw = _TILES[kid // 10]
     if mode == 4:      # template argument = MFMA shape (16x16x4 unless the tuning knob FGN_PW_M16=0 selects 32x32x2)
         return 'conv_pw_persist_kernel<%s>' % ('false' if os.environ.get('FGN_PW_M16') == '0' else 'true')

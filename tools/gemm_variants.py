@@ -12,7 +12,9 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 variants = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 1, 2, 3, 4, 5]
 SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'    # (ops.conv2d reads the same switch)
-NAMES = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8'}
+_SCH = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda') if SCHED else None
+ops._sched = lambda dev: _SCH          # one workspace for all (serialised) launches of this tool: no fill kernel per call
+NAMES = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8', 6: '64x64w8', 7: '64x128w8', 8: '32x64'}
 
 
 def time_once(fn):

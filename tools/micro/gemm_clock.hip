@@ -76,32 +76,50 @@ static int run(const Shape& sh, int variant, double seconds) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         last_batch_ms = ms; launches += batch;
     }
-    std::vector<unsigned long long> h(16384 * 4);
+    std::vector<unsigned long long> h(16384 * 6);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_clock_stamps), h.size() * 8));
-    std::vector<double> clk, span;
+    struct WgStamp { double clk, span, r0, r1; unsigned xcc, cu; };
+    std::vector<WgStamp> ws;
+    unsigned long long rmin = ~0ull, rmax = 0;
     for (int b = 0; b < 16384; ++b) {
-        const unsigned long long t0s = h[b * 4], t1s = h[b * 4 + 1], r0 = h[b * 4 + 2], r1 = h[b * 4 + 3];
+        const unsigned long long t0s = h[b * 6], t1s = h[b * 6 + 1], r0 = h[b * 6 + 2], r1 = h[b * 6 + 3];
         if (t1s > t0s && r1 > r0 && r1 - r0 > 200) {       // >= 2 us of work
-            clk.push_back((double)(t1s - t0s) / (double)(r1 - r0) * 0.1);   // GHz
-            span.push_back((double)(t1s - t0s));
+            const unsigned xcc = (unsigned)h[b * 6 + 4] & 0xf, hw = (unsigned)h[b * 6 + 5];
+            // HW_ID (gfx9): cu_id [11:8], sh_id [12], se_id [15:13]
+            ws.push_back({(double)(t1s - t0s) / (double)(r1 - r0) * 0.1, (double)(t1s - t0s), (double)r0, (double)r1, xcc,
+                          (xcc << 8) | ((hw >> 8) & 0xff)});
+            rmin = std::min(rmin, r0); rmax = std::max(rmax, r1);
         }
     }
-    // reset the stamp buffer for the next run
     std::fill(h.begin(), h.end(), 0ull);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clock_stamps), h.data(), h.size() * 8));
-    if (clk.empty()) { fprintf(stderr, "%s v%d: no stamps\n", sh.name, variant); return 1; }
-    std::sort(clk.begin(), clk.end()); std::sort(span.begin(), span.end());
-    auto q = [](const std::vector<double>& v, double f) { return v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+    if (ws.empty()) { fprintf(stderr, "%s v%d: no stamps\n", sh.name, variant); return 1; }
+    auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+    std::vector<double> clk, span, start_us, end_us;
+    for (auto& w : ws) { clk.push_back(w.clk); span.push_back(w.span); start_us.push_back((w.r0 - (double)rmin) * 0.01); end_us.push_back(((double)rmax - w.r1) * 0.01); }
+    // workgroups per CU (as placed in the last launch), and the median span of a workgroup by how crowded its CU was
+    std::vector<unsigned> cus; for (auto& w : ws) cus.push_back(w.cu);
+    std::sort(cus.begin(), cus.end());
+    int hist[12] = {0}; size_t n_cu = 0;
+    for (size_t i = 0; i < cus.size();) { size_t j = i; while (j < cus.size() && cus[j] == cus[i]) ++j; hist[std::min<size_t>(j - i, 11)]++; ++n_cu; i = j; }
+    char hbuf[256]; int hp = 0; hbuf[0] = 0;
+    for (int k = 1; k < 12; ++k) if (hist[k]) hp += snprintf(hbuf + hp, sizeof(hbuf) - hp, "%s\"%d\": %d", hp ? ", " : "", k, hist[k]);
+    double xcd_span[8] = {0}; char xbuf[256]; int xp = 0; xbuf[0] = 0;
+    for (unsigned x = 0; x < 8; ++x) { std::vector<double> v; for (auto& w : ws) if (w.xcc == x) v.push_back(w.span); xcd_span[x] = v.empty() ? 0 : q(v, 0.5); xp += snprintf(xbuf + xp, sizeof(xbuf) - xp, "%s%.0f", x ? ", " : "", xcd_span[x]); }
     const double us = last_batch_ms * 1e3 / batch;
-    // MFMA issue cycles per SIMD for the whole launch: flop / (64 FLOP per cycle per SIMD) / 1024 SIMDs
-    const double mfma_cycles_per_simd = flop / 64.0 / 1024.0;
+    const double mfma_cycles_per_simd = flop / 64.0 / 1024.0;     // flop / (64 FLOP per cycle per SIMD) / 1024 SIMDs
     const double wall_cycles = us * 1e-6 * q(clk, 0.5) * 1e9;
     printf("{\"shape\": \"%s\", \"variant\": %d, \"launches\": %ld, \"us_per_launch_back_to_back\": %.1f, \"tflops\": %.1f, "
            "\"frac_of_157.3\": %.3f, \"clock_ghz_median\": %.3f, \"clock_ghz_p10\": %.3f, \"clock_ghz_p90\": %.3f, "
-           "\"workgroups_stamped\": %zu, \"wg_span_cycles_median\": %.0f, \"launch_wall_cycles_at_median_clock\": %.0f, "
-           "\"mfma_issue_cycles_per_simd\": %.0f, \"mfma_pipe_share_of_wall\": %.3f, \"mfma_pipe_share_of_wg_span\": %.3f}\n",
-           sh.name, variant, launches, us, flop / us / 1e6, flop / us / 1e6 / 157.3, q(clk, 0.5), q(clk, 0.1), q(clk, 0.9), clk.size(),
-           q(span, 0.5), wall_cycles, mfma_cycles_per_simd, mfma_cycles_per_simd / wall_cycles, mfma_cycles_per_simd / q(span, 0.5));
+           "\"workgroups_stamped\": %zu, \"cus_seen\": %zu, \"workgroups_per_cu_histogram\": {%s}, "
+           "\"wg_span_cycles\": {\"p10\": %.0f, \"p50\": %.0f, \"p90\": %.0f, \"max\": %.0f}, \"wg_span_p50_by_xcd\": [%s], "
+           "\"wg_start_after_first_us\": {\"p50\": %.1f, \"p90\": %.1f, \"max\": %.1f}, \"wg_end_before_last_us\": {\"p10\": %.1f, \"p50\": %.1f, \"p90\": %.1f}, "
+           "\"first_start_to_last_end_us\": %.1f, \"launch_wall_cycles_at_median_clock\": %.0f, "
+           "\"mfma_issue_cycles_per_simd\": %.0f, \"mfma_pipe_share_of_wall\": %.3f, \"mfma_pipe_share_of_wg_span_p50\": %.3f}\n",
+           sh.name, variant, launches, us, flop / us / 1e6, flop / us / 1e6 / 157.3, q(clk, 0.5), q(clk, 0.1), q(clk, 0.9), ws.size(), n_cu, hbuf,
+           q(span, 0.1), q(span, 0.5), q(span, 0.9), q(span, 0.9999), xbuf, q(start_us, 0.5), q(start_us, 0.9), q(start_us, 0.9999),
+           q(end_us, 0.1), q(end_us, 0.5), q(end_us, 0.9), ((double)rmax - (double)rmin) * 0.01, wall_cycles, mfma_cycles_per_simd,
+           mfma_cycles_per_simd / wall_cycles, mfma_cycles_per_simd / q(span, 0.5));
     fflush(stdout);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); (void)hipStreamDestroy(st);
     return 0;
