@@ -13,7 +13,9 @@ LIB = os.path.join(HERE, 'libfgn_hip.so')
 # conv_igemm: MFMA kernel, default fp contraction.  Everything else is on (or next to)
 # the bit-exact selection path: no mul+add fusion, so fp32 op order is the oracle's.
 SOURCES = [
-    ('conv_igemm.hip', []),
+    # (the atomic optimizer would turn the tile scheduler's one-lane atomic into a wave reduction that reads the returned
+    # value at once: the pull could no longer fly under the K loop)
+    ('conv_igemm.hip', ['-mllvm', '-amdgpu-atomic-optimizer-strategy=None']),
     ('abi.hip', []),
     ('spatial.hip', ['-ffp-contract=off']),
     ('norm.hip', []),

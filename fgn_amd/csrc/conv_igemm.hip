@@ -1132,7 +1132,7 @@ struct Persist2Geom {
     int n_groups;    // 1 for a plain convolution
 };
 
-template <int BM, int BN, int WM, int WN, int MINW>
+template <int BM, int BN, int WM, int WN, int NST, int MINW>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_persist2_kernel(const ConvParams p,
                                                                                           const Persist2Geom gm,
                                                                                           const int total_tiles) {
@@ -1141,7 +1141,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
     constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
     constexpr int TI = WM / 16, TJ = WN / 16;
     constexpr int STAGE = (BM + BN) * BK;              // floats
+    constexpr int LOADS = A_LD + B_LD;                 // LDS-DMA wave-instructions per K-tile and wave
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
+    static_assert(NST >= 2 && NST <= 4 && (NST - 2) * LOADS <= 63, "stages");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1192,7 +1194,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
     // the end of its share, so a share sees max(size_x - nwg_x, 0) + nwg_x pulls in all and the workgroup that draws
     // the last of them returns the counter to zero for the next launch (kernel boundaries order it).  One lane pulls;
     // the value reaches the other waves through one LDS word behind a workgroup barrier.
-    int* const s_next = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* const s_next = reinterpret_cast<int*>(smem + NST * STAGE);
     int32_t* const counter = p.sched ? p.sched + xk * 16 : nullptr;
     const int pulls_x = max(size_x - nwg_x, 0) + nwg_x;
     int pulled = 0;                                    // lane 0 of the workgroup: the value its pending pull returned
@@ -1257,7 +1259,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
     if (idx >= size_x) return;
     CLOCK_STAMP_BEGIN();
     set_offsets(m0, mend, n0, wofs);
-    issue_tile(0, 0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < KT) issue_tile(s, s);
 
     while (true) {
         f32x4 acc[TI][TJ];
@@ -1265,14 +1269,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves')
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (counter) pull_issue();                       // the next tile's index arrives under this tile's K loop
+        // NST LDS stages: K-tiles kt + 1 .. kt + NST - 2 are in flight while tile kt is multiplied and tile kt + NST - 1
+        // is issued.  One barrier per K-tile, at its top: behind it tile kt has landed for every wave (own DMAs by the
+        // counted vmcnt - completion is in issue order, so "at most (NST - 2) * LOADS outstanding" means tile kt is in;
+        // stores of the previous epilogue and the scheduler's atomic only make that wait longer, never shorter) and
+        // every wave has finished reading the stage of tile kt - 1, which tile kt + NST - 1 overwrites.  With one or
+        // two workgroups on a CU (launches of few tiles, and the last round of every launch) a K-tile is ~1100
+        // MFMA cycles against a DMA latency of 2000-3000: two stages leave the pipe idle two thirds of the time
+        // (measured r04: a lone workgroup needs ~3300 cycles per K-tile), the deeper ring covers it.
         int cur = 0;
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
-            else if (counter) pull_publish();            // ... and is handed to the workgroup behind the loop's last barrier
+            if (NST > 2 && kt + NST - 2 < KT) {
+                if (NST == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LOADS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt == 0 && counter) pull_issue();        // the next tile's index arrives under this tile's K loop
+            if (kt + NST - 1 < KT) {
+                int st = cur + NST - 1;
+                if (st >= NST) st -= NST;
+                issue_tile(kt + NST - 1, st);
+            }
+            if (kt == KT - 1 && counter) pull_publish(); // ... and is handed to the workgroup behind the barrier after the loop
             asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
@@ -1299,12 +1319,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
                         for (int j = 0; j < TJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
             }
-            // reads of stage `cur` must have returned before the barrier is signalled (the next DMA overwrites it)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
+            cur = cur + 1 == NST ? 0 : cur + 1;
         }
-        // both stages are free: the first K-tile of the next output tile flies while this tile's accumulators are stored
+        // every wave is done with the last stage (and lane 0's hand-off word is visible) before the next tile's first
+        // K-tiles are issued: they fly while this tile's accumulators are stored
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const int em0 = m0, emend = mend, en0 = n0;
         int nm0 = 0, nmend = 0, nn0 = 0, nwofs = 0;
         int next;
@@ -1317,7 +1337,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         }
         if (next < size_x) {
             set_offsets(nm0, nmend, nn0, nwofs);
-            issue_tile(0, 0);
+#pragma unroll
+            for (int s = 0; s < NST - 1; ++s)
+                if (s < KT) issue_tile(s, s);
         }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -1507,8 +1529,15 @@ static int g_pw2_wgs = getenv("FGN_PW2_WGS") ? atoi(getenv("FGN_PW2_WGS")) : 0; 
 // ---- conv_pw_persist2_kernel: launch -------------------------------------------------------------------------
 // tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 64x128 (32x64), 3 = 128x64 (64x32), 4 = 64x64 (32x32),
 // 5 = 128x128 with 8 waves of 32x64, 6 = 64x64 with 8 waves of 32x16, 7 = 64x128 with 8 waves of 32x32, 8 = 32x64 (16x32)
-template <int BM, int BN, int WM, int WN, int MINW, int WG_PER_CU>
+template <int BM, int BN, int WM, int WN, int NST, int WG_MAX>
 static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr size_t LDS = (size_t)NST * (BM + BN) * BK * sizeof(float) + 16;      // + the scheduler's hand-off word
+    // workgroups per CU: what LDS and the 2048-thread limit admit, at most the tile's own bound
+    constexpr int BY_LDS = (int)(160 * 1024 / LDS), BY_THREADS = 2048 / NT;
+    constexpr int WG_PER_CU = BY_LDS < BY_THREADS ? (BY_LDS < WG_MAX ? BY_LDS : WG_MAX) : (BY_THREADS < WG_MAX ? BY_THREADS : WG_MAX);
+    constexpr int MINW = WG_PER_CU * NT / 256;           // __launch_bounds__: waves per SIMD the grid needs
+    static_assert(WG_PER_CU >= 1, "tile does not fit");
     ConvParams p = p0;
     p.n_tiles_n = cdiv(p.Cout, BN);
     Persist2Geom gm;
@@ -1524,29 +1553,38 @@ static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream
     }
     const long long total = (long long)gm.n_groups * gm.mt * p.n_tiles_n;
     if (total <= 0 || total >= (1ll << 30)) return FGN_ERR_SHAPE;
-    const int per_cu = g_pw2_wgs > 0 ? g_pw2_wgs : WG_PER_CU;
+    const int per_cu = g_pw2_wgs > 0 ? std::min(g_pw2_wgs, WG_PER_CU) : WG_PER_CU;
     const int cap = 256 * per_cu;
     const int grid = (int)std::min<long long>((total + 7) / 8 * 8, cap);
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + 16;      // + the scheduler's hand-off word
     static unsigned long long ok = 0ull;
-    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist2_kernel<BM, BN, WM, WN, MINW>), &ok);
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist2_kernel<BM, BN, WM, WN, NST, MINW>), &ok);
     if (attr != hipSuccess) return (int)attr;
-    FGN_LAUNCH_TIMED((conv_pw_persist2_kernel<BM, BN, WM, WN, MINW>), dim3(grid), dim3(NT), lds, stream, p, gm, (int)total);
+    FGN_LAUNCH_TIMED((conv_pw_persist2_kernel<BM, BN, WM, WN, NST, MINW>), dim3(grid), dim3(NT), LDS, stream, p, gm, (int)total);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int WG_MAX>
+static int launch_persist2_st(int nst, const ConvParams& p, int M_max, hipStream_t stream) {
+    switch (nst) {
+        case 3: return launch_persist2_t<BM, BN, WM, WN, 3, WG_MAX>(p, M_max, stream);
+        case 4: return launch_persist2_t<BM, BN, WM, WN, 4, WG_MAX>(p, M_max, stream);
+        default: return launch_persist2_t<BM, BN, WM, WN, 2, WG_MAX>(p, M_max, stream);
+    }
+}
+
+// code = tile + 10 * (LDS stages, 0 = 2)
 static int launch_persist2(int code, const ConvParams& p, int M_max, hipStream_t stream) {
-    switch (code) {
+    const int nst = code / 10 ? code / 10 : 2;
+    switch (code % 10) {
         case 1: return launch_persist2_t<128, 128, 64, 64, 2, 2>(p, M_max, stream);
-        case 2: return launch_persist2_t<64, 128, 32, 64, 3, 3>(p, M_max, stream);
-        case 3: return launch_persist2_t<128, 64, 64, 32, 3, 3>(p, M_max, stream);
-        case 4: return launch_persist2_t<64, 64, 32, 32, 4, 4>(p, M_max, stream);
-        case 5: return launch_persist2_t<128, 128, 32, 64, 4, 2>(p, M_max, stream);
-        case 6: return launch_persist2_t<64, 64, 32, 16, 8, 4>(p, M_max, stream);      // 8 waves on a 64x64 tile
-        case 7: return launch_persist2_t<64, 128, 32, 32, 6, 3>(p, M_max, stream);     // 8 waves on a 64x128 tile
-        case 8: return launch_persist2_t<32, 64, 16, 32, 4, 5>(p, M_max, stream);      // 4 waves on a 32x64 tile
+        case 2: return launch_persist2_st<64, 128, 32, 64, 3>(nst, p, M_max, stream);
+        case 3: return launch_persist2_t<128, 64, 64, 32, 2, 3>(p, M_max, stream);
+        case 4: return launch_persist2_st<64, 64, 32, 32, 4>(nst, p, M_max, stream);
+        case 5: return launch_persist2_t<128, 128, 32, 64, 2, 2>(p, M_max, stream);
+        case 6: return launch_persist2_st<64, 64, 32, 16, 4>(nst, p, M_max, stream);       // 8 waves on a 64x64 tile
+        case 7: return launch_persist2_st<64, 128, 32, 32, 3>(nst, p, M_max, stream);      // 8 waves on a 64x128 tile
+        case 8: return launch_persist2_st<32, 64, 16, 32, 5>(nst, p, M_max, stream);       // 4 waves on a 32x64 tile
         default: return FGN_ERR_ARG;
     }
 }

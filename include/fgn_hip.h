@@ -71,7 +71,7 @@ size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, in
 int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
                          int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint);
 /* Tuning knob (no reference counterpart; tools/ only): knob 0 = tile code of conv_pw_persist2_kernel forced for every
- * eligible point-wise launch (-1 heuristic, 0 never, 1 128x128, 2 64x128, 3 128x64, 4 64x64, 5 128x128 on 8 waves, 6 64x64 on 8 waves, 7 64x128 on 8 waves, 8 32x64),
+ * eligible point-wise launch (-1 heuristic, 0 never, 1 128x128, 2 64x128, 3 128x64, 4 64x64, 5 128x128 on 8 waves, 6 64x64 on 8 waves, 7 64x128 on 8 waves, 8 32x64; + 10 x LDS stages (3, 4) for tiles 2, 4, 6, 7, 8),
  * knob 1 = its workgroups per CU (0 = default).  Returns the previous value, FGN_ERR_ARG for an unknown knob. */
 int fgn_conv2d_tune(int knob, int value);
 int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,

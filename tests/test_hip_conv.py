@@ -246,7 +246,7 @@ class _pw2:
         lib.load().fgn_conv2d_tune(0, self.prev)
 
 
-@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8, 34, 44, 32, 42, 36, 47, 38, 48])   # tile + 10 * LDS stages
 @pytest.mark.parametrize('rows,cin,cout,res,relu', [(1000, 64, 72, True, True), (49 * 37, 96, 256, False, True),
                                                      (130, 1024, 512, True, False), (64 * 9 + 1, 32, 4, False, False)])
 def test_persist2_pointwise_matches_fp64_and_round3_kernel(code, rows, cin, cout, res, relu):
@@ -276,7 +276,7 @@ def test_persist2_pointwise_matches_fp64_and_round3_kernel(code, rows, cin, cout
     assert torch.equal(part[:rows - 77], got[:rows - 77]) and float((part[rows - 77:] + 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8, 34, 44, 32, 42, 36, 47, 38, 48])   # tile + 10 * LDS stages
 @pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 64, 128), (5, 4, 512, 64), (100, 4, 32, 256)])
 def test_persist2_grouped_gemm_all_tiles_and_the_tile_scheduler(code, n, tiles, cin, cout):
     """The grouped Winograd GEMM (36 groups, per-group weights): t_pad is a multiple of 64, so with 128-row tiles the

@@ -14,7 +14,8 @@ variants = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0
 SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'    # (ops.conv2d reads the same switch)
 _SCH = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda') if SCHED else None
 ops._sched = lambda dev: _SCH          # one workspace for all (serialised) launches of this tool: no fill kernel per call
-NAMES = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8', 6: '64x64w8', 7: '64x128w8', 8: '32x64'}
+_BASE = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8', 6: '64x64w8', 7: '64x128w8', 8: '32x64'}
+NAMES = {v: _BASE[v % 10] + (f's{v // 10}' if v >= 10 else '') for v in variants}   # code = tile + 10 * LDS stages
 
 
 def time_once(fn):

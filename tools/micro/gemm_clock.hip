@@ -4,7 +4,7 @@
 //   clock  = median over workgroups of  d(s_memtime) / d(s_memrealtime) * 100 MHz
 //   pipe   = MFMA issue cycles per SIMD (32 per v_mfma_f32_16x16x4_f32, 64 per 32x32x2) / median workgroup span in
 //            shader cycles of the LAST launch - the share of the span in which a SIMD's matrix pipe was issuing
-// build (here or on the box):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCONV_CLOCK_STAMPS tools/micro/gemm_clock.hip -o tools/micro/gemm_clock
+// build (here or on the box):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCONV_CLOCK_STAMPS -mllvm -amdgpu-atomic-optimizer-strategy=None tools/micro/gemm_clock.hip -o tools/micro/gemm_clock
 // usage: gemm_clock [seconds]      prints one JSON object per (shape, kernel variant)
 #include "../../fgn_amd/csrc/conv_igemm.hip"
 #include "../../fgn_amd/csrc/abi.hip"
