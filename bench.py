@@ -557,6 +557,8 @@ def main():
                        'rank_placement': rank_info,
                        'gather_stream': (None if world == 1 else 'caller' if gather_on_compute else 'communication'),
                        'jitter_ms_rehearsal': jitter_ms or None,
+                       'peak_memory_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                       'reserved_memory_gib': round(torch.cuda.memory_reserved() / 2 ** 30, 2),
                        'caller_streams': args.streams, 'support_cache': bool(args.cache_supports), 'hip_graph': bool(model.use_graphs),
                        'winograd_3x3': {0: 'off', 2: 'F(2x2,3x3)', 4: 'F(4x4,3x3)'}[model.use_winograd],
                        'episodes_per_step_per_gpu': args.batch,

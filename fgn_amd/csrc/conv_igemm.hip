@@ -1593,9 +1593,24 @@ static int launch_persist2(int code, const ConvParams& p, int M_max, hipStream_t
 // every eligible launch (tools/gemm_time.py A/B); eligible = 1x1 / stride 1 on the LDS-DMA path, no split-K, no fused
 // input scale, Cout % 4 == 0.
 
-static int pick_persist2(long long M, int Cout, int K, bool grouped) {
+static int pick_persist2(long long M, int Cout, int K, bool grouped, int grp_rows = 0, bool has_residual = false) {
     if (g_pw2_force >= 0) return g_pw2_force;
-    (void)M; (void)Cout; (void)K; (void)grouped;
+    if (has_residual) return 0;
+    // Measured on MI355X against the round-3 kernels, interleaved in one process (tools/gemm_variants.py;
+    // profiles/r04_gemm_variants_*.txt, four boxes):
+    //  * the large grouped Winograd GEMMs (AG-RPN 36 x 819 x 1024 x 1024, shared head on 300 RoIs 36 x 1200 x 512 x 512)
+    //    on 64x128 tiles, three workgroups per CU: 466-472 us against 476-485, 178-182 against 182-187 (the row
+    //    count of a launch over 768 slots leaves a shorter last round, and half the L2 -> LDS bytes per MFMA of the
+    //    64x64 tile); the smaller grouped GEMMs are equal or slower -> round-3 kernel;
+    //  * plain 1x1 convolutions of 500..1000 64x64-tile equivalents and K >= 512 (first shared-head conv on the
+    //    feature map 4200 x 1024 > 512, on 100 RoIs 4900 x 1024 > 512, layer2 conv1 26016 x 512 > 128) on 32x64 tiles:
+    //    49-51 us against 55-56, 50-51 against 55-57, 38-39 against 40-42 - twice the workgroups of a grid that fills
+    //    two to four slots per CU unevenly;
+    //  * everything else (residual epilogues: the 16-byte stores from the accumulators touch 16 rows x 64 B per
+    //    instruction, the LDS round trip 4 rows x 256 B; small K; full grids of 64x64 tiles): round-3 kernels.
+    const long long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
+    if (grouped) return (grp_rows >= 800 && Cout >= 512 && K >= 512) ? 2 : 0;
+    if (K >= 512 && tiles64 >= 500 && tiles64 <= 1000) return 8;
     return 0;
 }
 
@@ -1644,8 +1659,9 @@ extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, 
     // conv_pw_persist2_kernel: tile code * 10 + 5 (the grouped Winograd GEMM asks with tile_hint 4)
     if (mode == 1 && (Cout & 3) == 0 && (tile_hint == 0 || tile_hint == 4) &&
         (tile_hint == 4 || plan_splits(M, Cout, K / BK, tile_hint) == 1)) {
-        const int code = pick_persist2(M, Cout, K, tile_hint == 4);
-        if (code) return code * 10 + 5;
+        // (asked per group: M / 36 rows; F(2x2) launches have 16 groups and never reach the row threshold)
+        const int code = pick_persist2(M, Cout, K, tile_hint == 4, tile_hint == 4 ? (int)(M / 36) : 0, has_residual != 0);
+        if (code) return (code % 10) * 10 + 5;
     }
     // point-wise launches with more 64x64 output tiles than resident workgroups run on conv_pw_persist_kernel
     if (mode == 1 && tile == 4 && (Cout & 3) == 0 && persist_blocks() > 0 &&
@@ -1732,7 +1748,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     }
     if (p.splits == 1 && !in_scale && p.x_bytes != 0 && !cin4 && KH == 1 && KW == 1 && stride == 1 && pad == 0 &&
         a_img_div == 1 && (Cout & 3) == 0 && tile_hint == 0) {
-        const int code = pick_persist2(M, Cout, p.K, false);
+        const int code = pick_persist2(M, Cout, p.K, false, 0, residual != nullptr);
         if (code) return launch_persist2(code, p, (int)M, stream);
     }
     switch (tile) {
@@ -1838,7 +1854,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
     p.n_tiles_n = 0;
     {
-        const int code = pick_persist2(rows, Cout, p.K, true);
+        const int code = pick_persist2(rows, Cout, p.K, true, t_pad);
         if (code) return launch_persist2(code, p, (int)rows, stream);
     }
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
