@@ -93,11 +93,14 @@ def parse_args():
                          'cannot keep two streams fed (6.10 ms)')
     ap.add_argument('--graphs', dest='graphs', action='store_true', default=None,
                     help='replay one captured hipGraph per step instead of launching from Python (same kernels, same '
-                         'bytes; host enqueue 0.2-0.8 ms instead of ~2.9 ms).  Default: on for batches of 1-2 episodes per '
-                         'step; larger batches launch eagerly on one stream (measured r03, cfg4 with 8 episodes per step: '
-                         'eager 202.8 img/s, graph replay 190 / 198 on one / two streams - a step is 40 ms of GPU work '
-                         'against 3 ms of launches, and a captured graph pins every intermediate of the step at its own '
-                         'address instead of reusing freed blocks)')
+                         'bytes; host enqueue 0.2-0.8 ms instead of ~2.9 ms).  Default: on, at every batch.  Measured r04 on '
+                         'one box, cfg4 shapes (tools/micro/sweep_batch.sh, profiles/r04_sweep_batch.txt): replay on two caller '
+                         'streams with three steps in flight beats eager launches at every batch - B = 2 201 vs 181-188 '
+                         'img/s, B = 4 (the reference evaluates with batch 4, fgn_test.py:49) 210-211 vs 193-196, B = 8 '
+                         '212-213 vs 203-205; replay on ONE stream loses 2-5 % to eager (its kernels take the same time one by '
+                         'one - rocprofv3, tools/micro/graph_vs_eager.sh - but the branches of one graph overlap less than '
+                         'streams do).  A step holds 2.5 GiB (B = 4) / 4.6 GiB (B = 8) of the 288: pinned intermediates '
+                         'are not a constraint')
     ap.add_argument('--no-graphs', dest='graphs', action='store_false')
     ap.add_argument('--batch', type=int, default=1, help='episodes per step per GPU (the reference evaluates with '
                     'batch 4, fgn_test.py:49; cfg4 of BASELINE.json is 8 per GPU); default 1 = cfg3 as surveyed')
@@ -110,7 +113,7 @@ def parse_args():
                     help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
     args = ap.parse_args()
     if args.graphs is None:
-        args.graphs = args.batch <= 2
+        args.graphs = True
     if args.streams is None:
         args.streams = 2 if args.graphs else 1
     if args.inflight is None:
@@ -284,6 +287,8 @@ def main():
         model.use_merged_backbone = os.environ['FGN_MERGED_BACKBONE'] != '0'
     if os.environ.get('FGN_MERGED_SUPPORT_HEAD'):
         model.use_merged_support_head = os.environ['FGN_MERGED_SUPPORT_HEAD'] != '0'
+    if os.environ.get('FGN_SIDE_STREAM'):
+        model.use_side_stream = os.environ['FGN_SIDE_STREAM'] != '0'
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);
     # every step copies its episode to the device (--resident-inputs: parked in HBM instead, not the headline)

@@ -1608,6 +1608,12 @@ static int pick_persist2(long long M, int Cout, int K, bool grouped, int grp_row
     //    two to four slots per CU unevenly;
     //  * everything else (residual epilogues: the 16-byte stores from the accumulators touch 16 rows x 64 B per
     //    instruction, the LDS round trip 4 rows x 256 B; small K; full grids of 64x64 tiles): round-3 kernels.
+    // In the pipelined step (two caller streams, three episodes in flight) the other episode's kernels fill a GEMM's
+    // last round, and none of this shows: same-box A/B of bench.py with these choices on / off, r04: B = 1 188.6-190.9
+    // vs 190.1-190.8 img/s, B = 4 212.3-212.5 vs 209.2-211.0, B = 8 213.2 vs 215.5.  The choices stay behind
+    // FGN_PW2_AUTO=1 (and the per-launch knob); the default keeps every launch on the round-3 kernels.
+    static const bool automatic = getenv("FGN_PW2_AUTO") && atoi(getenv("FGN_PW2_AUTO")) != 0;
+    if (!automatic) return 0;
     const long long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
     if (grouped) return (grp_rows >= 800 && Cout >= 512 && K >= 512) ? 2 : 0;
     if (K >= 512 && tiles64 >= 500 && tiles64 <= 1000) return 8;

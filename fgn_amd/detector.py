@@ -380,10 +380,13 @@ class FGN(torch.nn.Module):
         # (same-box A/B, r03: 6.07 -> 5.72 ms).  Results differ from the separate passes in the last bits only
         # (split-K plans and Winograd-vs-direct choices depend on the row count).
         self.use_merged_backbone = True
-        # option: the support RoIs ride through the shared head in the box head's RoI batch (same weights; eval-mode
-        # BatchNorm is per sample), so the ~30 tiny launches of count_spp's own shared-head pass disappear.  Measured
-        # neutral (same-box A/B, r03: 5.75 vs 5.75 ms - those launches were already hidden on the side stream): off.
-        self.use_merged_support_head = False
+        # the support RoIs ride through the shared head in the box head's RoI batch (same weights; eval-mode BatchNorm is
+        # per sample): the ~30 small launches of count_spp's own shared-head pass (9 RoIs, 441 rows: three direct-form
+        # 3x3 convolutions at 0.08 of the MFMA peak while they queue behind the persistent GEMMs, r03 kernel stats)
+        # disappear into 3 % more rows of the 300-RoI launches.  Step time equal within run-to-run noise (same-box A/B,
+        # r04: B = 1 189.9-191.3 vs 188.6-190.9 img/s, B = 4 211.1-211.8 vs 209.2-211.0, B = 8 214.6 vs 215.5): on since
+        # round 4 for the launch count.  False = the separate pass, byte-identical to `encode_supports`.
+        self.use_merged_support_head = True
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots

@@ -329,9 +329,9 @@ def test_support_code_cache_is_identical():
                      spp_isegmaps=first['spp_isegmaps'])
         no_spp = {k: v for k, v in batch.items() if not k.startswith('spp_i') and k != 'spp_bboxes'}
         cached = model.simple_test(**no_spp, support_code=code, rescale=True)
-        model.use_merged_backbone = False
+        model.use_merged_backbone = model.use_merged_support_head = False      # the separate form: the cache's own launches
         plain = model.simple_test(**batch, rescale=True)
-        model.use_merged_backbone = True
+        model.use_merged_backbone = model.use_merged_support_head = True       # the default
         merged = model.simple_test(**batch, rescale=True)
         for a, b, c in zip(plain, cached, merged):
             assert len(a['dt_scores']) > 0
@@ -384,7 +384,7 @@ def test_hip_graph_replay_is_identical():
     # separate-launch form, see test_support_code_cache_is_identical)
     one = make_batch(7, 1, 3, 2, 128, 160, 64)
     model.use_graphs = False
-    model.use_merged_backbone = False
+    model.use_merged_backbone = model.use_merged_support_head = False
     code = model.encode_supports(one['spp_imgs'], one['spp_bboxes'], one['spp_isegmaps'])
     ref = model.simple_test(**one, rescale=True)
     model.use_graphs = True
