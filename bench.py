@@ -497,6 +497,33 @@ def main():
             k['issued'] += rec['flop_issued'] * n
             k['direct'] += rec['flop_direct'] * n
         return out
+    def launch_classes(records, kernel):
+        """The launches of one kernel split by what bounds them on paper: algorithmic bytes of a launch = (A + B + C
+        (+ residual)) x 4 B, arithmetic intensity = issued FLOP / those bytes, against the machine balance 157.3 TF/s /
+        8 TB/s = 19.7 FLOP/B.  A 1x1 convolution with K = 64 writes 4 bytes per 128 FLOP of its row: no MFMA rate
+        can make it faster than its output stream."""
+        out = {'mfma_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0), 'hbm_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0)}
+        for rec in records:
+            if rec['kernel'] != kernel or 'gemm' not in rec:
+                continue
+            n = rec['n_img'] if rec['n_img_dev'] is None else min(rec['n_img'], int(rec['n_img_dev'].item()))
+            g, rows, N, K = rec['gemm']
+            M = rows * n if rec['kind'] == 'conv' else rows
+            byts = 4.0 * g * (M * K + N * K + M * N * (2 if rec.get('residual') else 1))
+            flop = rec['flop_issued'] * n
+            c = out['mfma_bound' if flop / max(byts, 1.0) >= PEAK_FP32_MFMA_TFLOPS / 8.0 else 'hbm_bound']
+            c['launches'] += 1
+            c['ms'] += rec['e0'].elapsed_time(rec['e1'])
+            c['flop'] += flop
+            c['bytes'] += byts
+        res = {}
+        for k, c in out.items():
+            if c['launches']:
+                res[k] = {'launches': c['launches'], 'ms': round(c['ms'], 3), 'tflops': round(c['flop'] / c['ms'] / 1e9, 1),
+                          'frac_of_mfma_peak': round(c['flop'] / c['ms'] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          'algorithmic_tb_per_s': round(c['bytes'] / c['ms'] / 1e9, 2),
+                          'frac_of_hbm_peak': round(c['bytes'] / c['ms'] / 1e9 / 8.0, 4)}
+        return res
     by_kernel_overlapped = per_kernel(prof)
     by_kernel = per_kernel(prof_alone) if len(prof_alone) else by_kernel_overlapped
     tot = dict(ms=sum(k['ms'] for k in by_kernel.values()), launches=sum(k['launches'] for k in by_kernel.values()),
@@ -585,6 +612,10 @@ def main():
                          'avg_launch_us': round(dom['ms'] * 1e3 / max(dom['launches'], 1), 2),
                          'kernel_ms_per_step': round(dom['ms'] / n_prof_steps, 3),
                          'share_of_conv_time': round(dom['ms'] / tot['ms'], 3) if tot['ms'] else None,
+                         # `frac` is the average over ALL launches of the kernel; split by the bound a launch has on
+                         # paper (arithmetic intensity against 157.3 TF/s / 8 TB/s): the MFMA-bound ones against the
+                         # MFMA peak, the output-bound 1x1 convolutions of layer1 / layer2 against the HBM peak
+                         'launch_classes': launch_classes(prof_alone if len(prof_alone) else prof, dom_name),
                          'profiled_steps': n_prof_steps,
                          'timing': 'start/stop HIP events stamped by each launch of the kernel itself (hipExtLaunchKernelGGL) on '
                                    'its own stream, in the first step of the timed region, which runs with no other episode '

@@ -292,6 +292,7 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
         prof.append(dict(kind='conv', kernel=kernel_name(kid), e0=e0, e1=e1, flop_direct=flop,
                          flop_issued=flop, n_img=n_img, n_img_dev=n_img_dev,
                          gemm=(1, ho * wo, layer.cout, layer.kh * layer.kw * cin),       # groups, rows per image, N, K
+                         residual=residual is not None,
                          shape=(n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
     return out
 

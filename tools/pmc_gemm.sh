@@ -11,11 +11,12 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES -d "$OUT/p1" --output-format csv -- python3 "$ROOT/tools/gemm_one.py" "$S" 6 > "$OUT/p1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD -d "$OUT/p2" --output-format csv -- python3 "$ROOT/tools/gemm_one.py" "$S" 6 > "$OUT/p2.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_BUSY_CU_CYCLES SQ_CYCLES -d "$OUT/p3" --output-format csv -- python3 "$ROOT/tools/gemm_one.py" "$S" 6 > "$OUT/p3.log" 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/p4" --output-format csv -- python3 "$ROOT/tools/gemm_one.py" "$S" 6 > "$OUT/p4.log" 2>&1 || true
 python3 - "$OUT" "$ROOT/$OUTJ" "$S" <<'PY'
 import csv, glob, json, sys
 out, dst, shape = sys.argv[1:4]
 res = {'shape': shape}
-for ps in ('p1', 'p2', 'p3'):
+for ps in ('p1', 'p2', 'p3', 'p4'):
     for f in glob.glob(f'{out}/{ps}/**/*counter_collection.csv', recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if 'conv_' in r['Kernel_Name']]
         last = max(int(r['Dispatch_Id']) for r in rows)
@@ -49,6 +50,8 @@ if res.get('SQ_INSTS_MFMA') and d:
 if res.get('SQ_WAVE_CYCLES'):
     for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
         if k in res: res[k + '_frac_of_wave_cycles'] = res[k] / res['SQ_WAVE_CYCLES']
+if res.get('TCC_HIT_sum') is not None and res.get('TCC_MISS_sum') is not None and res['TCC_HIT_sum'] + res['TCC_MISS_sum'] > 0:
+    res['l2_hit_rate'] = res['TCC_HIT_sum'] / (res['TCC_HIT_sum'] + res['TCC_MISS_sum'])
 if res.get('SQ_LDS_IDX_ACTIVE'):
     res['lds_bank_conflict_frac'] = res.get('SQ_LDS_BANK_CONFLICT', 0) / res['SQ_LDS_IDX_ACTIVE']
 json.dump(res, open(dst, 'w'), indent=1)
