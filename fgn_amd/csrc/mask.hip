@@ -55,10 +55,15 @@ extern "C" int fgn_mask_logits_f32(const float* x, const float* w, float bias, f
 }
 
 // ----------------------------------------------------------------------------------------------
-// paste: out[d][y][x] = bilinear(prob[d], grid(x,y)) >= thr inside the CPU path's
-// integer-expanded box (floor(x0)-1 .. ceil(x1)+1, clipped), 0 elsewhere
-// (_do_paste_mask with skip_empty=True, one mask per chunk).  grid_sample semantics:
-// align_corners=False, zero padding.  HBM-bound: D*H*W bytes written, 4 pixels per lane.
+// paste: out[d][y][x] = bilinear(prob[d], grid(x,y)) >= thr.  grid_sample semantics: align_corners=False, zero
+// padding.  HBM-bound: D*H*W bytes written, 4 pixels per lane.  Two region semantics, as in mmdet's _do_paste_mask:
+//   skip_empty = 1 (its CPU path, one mask per chunk): only inside the integer-expanded box
+//     (floor(x0)-1 .. ceil(x1)+1, clipped), 0 elsewhere - the oracle's and north_star's "CPU reference";
+//   skip_empty = 0 (its CUDA path: the reference runs on cuda:0, main.py:365): the grid spans the whole image.  A
+//     sample is non-zero only while its source coordinate lies inside (-1, M), i.e. within half a mask pixel =
+//     box_w / (2 M) of the box, so the region computed here is that band (+1 px of slack), not the image; the two
+//     semantics agree for thr >= 0.5 (the value on the box edge is half the border pixel) and differ below it.
+//     (thr <= 0 sets every pixel of the image under this semantic: the region is then the image.)
 // ----------------------------------------------------------------------------------------------
 // One mask sample, separable form shared by the dense paste kernel and the RLE kernel (so both
 // produce the same bits): horizontal lerp of the two neighbouring mask rows, then vertical lerp.
@@ -67,13 +72,26 @@ struct PasteBox {
     float bx0, by0, bx1, by1;
     int x0i, y0i, x1i, y1i;   // integer-expanded region [x0i,x1i) x [y0i,y1i)
 };
-__device__ __forceinline__ PasteBox make_paste_box(const float* b, int H, int W) {
+__device__ __forceinline__ PasteBox make_paste_box(const float* b, int H, int W, int MS, int skip_empty, float thr) {
     PasteBox p;
     p.bx0 = b[0]; p.by0 = b[1]; p.bx1 = b[2]; p.by1 = b[3];
-    p.x0i = max((int)floorf(p.bx0) - 1, 0);
-    p.y0i = max((int)floorf(p.by0) - 1, 0);
-    p.x1i = min((int)ceilf(p.bx1) + 1, W);
-    p.y1i = min((int)ceilf(p.by1) + 1, H);
+    if (skip_empty) {
+        p.x0i = max((int)floorf(p.bx0) - 1, 0);
+        p.y0i = max((int)floorf(p.by0) - 1, 0);
+        p.x1i = min((int)ceilf(p.bx1) + 1, W);
+        p.y1i = min((int)ceilf(p.by1) + 1, H);
+        return p;
+    }
+    // whole-image grid: the band in which a sample can be non-zero; a degenerate axis (width <= 0: the grid
+    // coordinate is inf -> 0, NaN where 0 / 0) samples the mask's centre line everywhere -> the whole axis
+    const float bw = p.bx1 - p.bx0, bh = p.by1 - p.by0;
+    const float mx = bw / (2.f * (float)MS), my = bh / (2.f * (float)MS);
+    const bool all = !(thr > 0.f);
+    const bool fx = all || !(bw > 0.f), fy = all || !(bh > 0.f);
+    p.x0i = fx ? 0 : max((int)floorf(p.bx0 - mx) - 1, 0);
+    p.x1i = fx ? W : min((int)ceilf(p.bx1 + mx) + 1, W);
+    p.y0i = fy ? 0 : max((int)floorf(p.by0 - my) - 1, 0);
+    p.y1i = fy ? H : min((int)ceilf(p.by1 + my) + 1, H);
     return p;
 }
 struct AxisLerp {
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict
                                                          const float* __restrict__ boxes, int box_stride,
                                                          uint8_t* __restrict__ out,
                                                          const int32_t* __restrict__ n_dev, int n_det, int H, int W,
-                                                         int MS, float thr) {
+                                                         int MS, float thr, int skip_empty) {
     int D = n_det;
     if (n_dev) D = min(D, *n_dev);
     const long long HW = (long long)H * W;
@@ -124,7 +142,7 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict
             if (d >= D) continue;
             const int rem = (int)(i - (long long)d * HW);
             const int y = rem / W, x = rem - y * W;
-            const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W);
+            const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W, MS, skip_empty, thr);
             if (x < pb.x0i || x >= pb.x1i || y < pb.y0i || y >= pb.y1i) continue;
             const AxisLerp ax = paste_axis(x, pb.bx0, pb.bx1, MS);
             const AxisLerp ay = paste_axis(y, pb.by0, pb.by1, MS);
@@ -140,13 +158,13 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict
 
 extern "C" int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uint8_t* out,
                                  const int32_t* n_dev, int n_det, int img_h, int img_w, int mask_size, float thr,
-                                 hipStream_t stream) {
+                                 int skip_empty, hipStream_t stream) {
     if (!prob || !boxes || !out) return FGN_ERR_ARG;
     if (n_det == 0) return FGN_OK;
     const long long total4 = ((long long)n_det * img_h * img_w + 3) / 4;
     const int grid = (int)std::min<long long>((total4 + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(mask_paste_kernel, dim3(grid), dim3(256), 0, stream, prob, boxes, box_stride, out, n_dev,
-                       n_det, img_h, img_w, mask_size, thr);
+                       n_det, img_h, img_w, mask_size, thr, skip_empty);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
@@ -249,7 +267,8 @@ __device__ inline void emit_coco_string(const uint32_t* __restrict__ tr, int T, 
 __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
     const float* __restrict__ prob, const float* __restrict__ boxes, int box_stride, uint32_t* __restrict__ trans,
     uint8_t* __restrict__ out_bytes, int32_t* __restrict__ out_len, int32_t* __restrict__ overflow,
-    const int32_t* __restrict__ n_dev, int n_det, int H, int W, int MS, float thr, int trans_cap, int byte_cap) {
+    const int32_t* __restrict__ n_dev, int n_det, int H, int W, int MS, float thr, int trans_cap, int byte_cap,
+    int skip_empty) {
     __shared__ float m[32 * 32];
     __shared__ int wave_sums[RLE_THREADS / 64];
     const int d = blockIdx.x, t = threadIdx.x;
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
     }
     for (int i = t; i < MS * MS; i += RLE_THREADS) m[i] = prob[(size_t)d * MS * MS + i];
     __syncthreads();
-    const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W);
+    const PasteBox pb = make_paste_box(boxes + (size_t)d * box_stride, H, W, MS, skip_empty, thr);
     // columns x0i .. min(x1i, W-1): one past the region closes a run that wraps a full-height column
     const int xs = pb.x0i, xe = min(pb.x1i, W - 1);
     const int ncols = max(xe - xs + 1, 0);
@@ -323,14 +342,14 @@ __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(
 extern "C" int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
                             uint8_t* out_bytes, int32_t* out_len, int32_t* overflow, const int32_t* n_dev,
                             int n_det, int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap,
-                            hipStream_t stream) {
+                            int skip_empty, hipStream_t stream) {
     if (!prob || !boxes || !trans_scratch || !out_bytes || !out_len || !overflow) return FGN_ERR_ARG;
     if (mask_size > 32 || mask_size < 1 || trans_cap < 1 || byte_cap < 8) return FGN_ERR_SHAPE;
     if ((long long)img_h * img_w >= (1ll << 32)) return FGN_ERR_SHAPE;
     if (n_det == 0) return FGN_OK;
     hipLaunchKernelGGL(mask_rle_kernel, dim3(n_det), dim3(RLE_THREADS), 0, stream, prob, boxes, box_stride,
                        trans_scratch, out_bytes, out_len, overflow, n_dev, n_det, img_h, img_w, mask_size, thr,
-                       trans_cap, byte_cap);
+                       trans_cap, byte_cap, skip_empty);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

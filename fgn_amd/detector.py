@@ -352,12 +352,17 @@ class FGN(torch.nn.Module):
         self.cfg = normalise_config(self.n_ways, self.k_shots, backbone, rpn_head, roi_head, test_cfg, train_cfg)
         self.train_cfg = train_cfg
         self.test_cfg = self.cfg['test_cfg']
+        # Region semantics of the mask paste (mmdet `_do_paste_mask`): 'cpu' = skip_empty=True, a mask is pasted inside the
+        # integer-expanded box only - the CPU reference north_star names, this build's oracle and default; 'cuda' =
+        # skip_empty=False, the grid spans the whole image - what the reference computes where it actually runs (cuda:0,
+        # main.py:365).  Identical at the configured threshold 0.5 (fgn_r50_c4_densecl.py:186: the value on the box
+        # edge is half the border pixel), up to box_w / 28 more pixels outside the box under 'cuda' below it.
+        self.paste_semantics = 'cpu'
         if self.test_cfg['rcnn'].get('mask_thr_binary', 0.5) < 0.5:
             import warnings
-            warnings.warn('mask_thr_binary < 0.5: masks are pasted inside the integer-expanded box only (mmdet '
-                          '_do_paste_mask(skip_empty=True), the CPU semantics this build and its oracle follow); the '
-                          'reference on a CUDA device pastes over the whole image and can set up to box_w/28 more '
-                          'pixels outside the box below 0.5 (DESIGN.md section 2)', stacklevel=2)
+            warnings.warn("mask_thr_binary < 0.5: mmdet's CPU and CUDA paste paths differ below 0.5 (skip_empty); this "
+                          "detector follows the CPU path unless `paste_semantics = 'cuda'` is set (DESIGN.md section 2)",
+                          stacklevel=2)
         self._sd = OrderedDict((k, self._canon(k, v)) for k, v in
                                (state_dict if state_dict is not None else init_state_dict(self.cfg, seed)).items())
         # mmcv `Pretrained` init_cfg of the backbone (fgn_r50_c4_densecl.py:39-41) / the deprecated `pretrained=` kwarg:
@@ -390,6 +395,11 @@ class FGN(torch.nn.Module):
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
+
+    def _skip_empty(self) -> bool:
+        if self.paste_semantics not in ('cpu', 'cuda'):
+            raise ValueError(f"paste_semantics must be 'cpu' or 'cuda', got {self.paste_semantics!r}")
+        return self.paste_semantics == 'cpu'
 
     @property
     def use_winograd(self) -> int:
@@ -1050,9 +1060,11 @@ class FGN(torch.nn.Module):
             det, lab, n_det = dets[i], labs[i], n_dets[i]
             mp_i = mprob[i * D:(i + 1) * D]
             # paste + threshold + COCO RLE fused on device: the D x H x W masks are never written
-            rle_bytes, rle_len, rle_ovf = ops.mask_rle(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+            skip_empty = self._skip_empty()
+            rle_bytes, rle_len, rle_ovf = ops.mask_rle(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det,
+                                                       skip_empty=skip_empty)
             if tr is not None:
-                masks = ops.mask_paste(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det)
+                masks = ops.mask_paste(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det, skip_empty=skip_empty)
                 tr.setdefault('per_image', []).append(dict(
                     rois=rois_all[i * R:(i + 1) * R], roi_feats=feats[i * R:(i + 1) * R], Q=Q[i * R:(i + 1) * R],
                     cls_raw=cls_raw[i * R * N:(i + 1) * R * N], reg_raw=reg_raw[i * R * N:(i + 1) * R * N],
@@ -1162,7 +1174,7 @@ class FGN(torch.nn.Module):
                 for j in np.flatnonzero(ovf):
                     dense = ops.mask_paste(di['mask_prob'][j:j + 1].contiguous(),
                                            di.get('det_bboxes_copy', di['det_bboxes'])[j:j + 1].contiguous(),
-                                           ih, iw, thr)
+                                           ih, iw, thr, skip_empty=self._skip_empty())
                     rles[j] = rle.encode(dense[0].cpu().numpy())
             one = {'dt_scores': db[:, 4].reshape(-1).copy(),
                    'dt_bboxes': db[:, [1, 0, 3, 2]].reshape(-1, 4).copy(),

@@ -79,12 +79,13 @@ def interleave(gathered: torch.Tensor) -> torch.Tensor:
 
 
 def results_from_gathered(recs: torch.Tensor, cnts: torch.Tensor, img_hw, mask_thr: float = 0.5,
-                          rle_fn=None) -> List[dict]:
+                          rle_fn=None, skip_empty: bool = True) -> List[dict]:
     """Gathered records of E episodes ([E, max_det, 6 + M*M], [E]) -> the reference's result dicts
     (fgn.py:276-281: ``dt_scores``, ``dt_bboxes`` YXYX, ``dt_cat_ids``, ``dt_isegmaps_rle``).
     ``img_hw``: (H, W) or a list of E such pairs.  ``rle_fn(prob [n,M,M], boxes [n,5], H, W, thr) ->
     list of RLE dicts``; default = the fused HIP paste+RLE kernel on the records' device (with the host
-    encoder only for strings that overflow the device caps), which needs a GPU."""
+    encoder only for strings that overflow the device caps), which needs a GPU; ``skip_empty`` = the paste
+    semantics of the producing detector (``FGN.paste_semantics == 'cpu'``)."""
     e, max_det, f = recs.shape
     m = int(round((f - REC_BOX) ** 0.5))
     if f <= REC_BOX or m * m != f - REC_BOX:
@@ -97,21 +98,22 @@ def results_from_gathered(recs: torch.Tensor, cnts: torch.Tensor, img_hw, mask_t
         rec = recs[i, :n]
         prob = rec[:, REC_BOX:].reshape(n, m, m).contiguous()
         boxes = rec[:, :5].contiguous()
-        rles = (rle_fn or _hip_rle)(prob, boxes, int(h), int(w), mask_thr) if n else []
+        rles = (rle_fn(prob, boxes, int(h), int(w), mask_thr) if rle_fn else
+                _hip_rle(prob, boxes, int(h), int(w), mask_thr, skip_empty)) if n else []
         b = boxes.cpu().numpy()
         out.append({'dt_scores': b[:, 4].copy(), 'dt_bboxes': b[:, [1, 0, 3, 2]].copy(),
                     'dt_cat_ids': rec[:, 5].round().to(torch.int64).cpu().numpy(), 'dt_isegmaps_rle': rles})
     return out
 
 
-def _hip_rle(prob, boxes, h, w, thr):
+def _hip_rle(prob, boxes, h, w, thr, skip_empty=True):
     from . import ops, rle
-    by, ln, ovf = ops.mask_rle(prob, boxes, h, w, thr)
+    by, ln, ovf = ops.mask_rle(prob, boxes, h, w, thr, skip_empty=skip_empty)
     by, ln, ovf = by.cpu().numpy(), ln.cpu().numpy(), ovf.cpu().numpy()
     res = []
     for j in range(prob.shape[0]):
         if ovf[j]:
-            dense = ops.mask_paste(prob[j:j + 1].contiguous(), boxes[j:j + 1].contiguous(), h, w, thr)
+            dense = ops.mask_paste(prob[j:j + 1].contiguous(), boxes[j:j + 1].contiguous(), h, w, thr, skip_empty=skip_empty)
             res.append(rle.encode(dense[0].cpu().numpy()))
         else:
             res.append({'size': [h, w], 'counts': by[j, :ln[j]].tobytes()})

@@ -909,8 +909,9 @@ def mask_logits(x: torch.Tensor, w: torch.Tensor, bias: float, roi_size: int,
 
 
 def mask_paste(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,
-               n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """prob [D, M, M], boxes [D, >=4] (x1,y1,x2,y2 first) -> uint8 [D, H, W]."""
+               n_dev: Optional[torch.Tensor] = None, skip_empty: bool = True) -> torch.Tensor:
+    """prob [D, M, M], boxes [D, >=4] (x1,y1,x2,y2 first) -> uint8 [D, H, W].  ``skip_empty``: mmdet's CPU paste
+    (inside the integer-expanded box) / False: its CUDA paste (grid over the whole image); equal for thr >= 0.5."""
     _chk(prob, 'prob')
     _chk(boxes, 'boxes')
     d, m, _ = prob.shape
@@ -918,7 +919,7 @@ def mask_paste(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, 
         raise _lib.FgnHipError('mask_paste: boxes shape mismatch')
     out = torch.empty((d, img_h, img_w), device=prob.device, dtype=torch.uint8)
     rc = _lib.load().fgn_mask_paste_u8(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(out), _ptr(n_dev), d, img_h,
-                                       img_w, m, float(thr), _stream())
+                                       img_w, m, float(thr), int(bool(skip_empty)), _stream())
     _lib.check(rc, 'fgn_mask_paste_u8')
     return out
 
@@ -928,7 +929,7 @@ RLE_BYTE_CAP = 16384      # COCO string bytes per detection
 
 
 def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,
-             n_dev: Optional[torch.Tensor] = None):
+             n_dev: Optional[torch.Tensor] = None, skip_empty: bool = True):
     """Fused paste + threshold + COCO RLE.  Returns (bytes [D,RLE_BYTE_CAP] u8, lens [D] i32,
     overflow [D] i32), all on device."""
     _chk(prob, 'prob')
@@ -943,7 +944,7 @@ def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, th
     ovf = zeros((d,), dev, torch.int32)
     rc = _lib.load().fgn_mask_rle(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(scratch), _ptr(out), _ptr(lens),
                                   _ptr(ovf), _ptr(n_dev), d, img_h, img_w, m, float(thr), RLE_TRANS_CAP,
-                                  RLE_BYTE_CAP, _stream())
+                                  RLE_BYTE_CAP, int(bool(skip_empty)), _stream())
     _lib.check(rc, 'fgn_mask_rle')
     return out, lens, ovf
 

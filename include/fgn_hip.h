@@ -236,9 +236,12 @@ int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_r
 int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logits, float* prob,
                         const int32_t* n_dev, int n_det, int roi_size, int C, void* stream);
 
-/* _do_paste_mask + threshold (fgn_roi_head.py:668-671): out uint8 [D,H,W] */
+/* _do_paste_mask + threshold (fgn_roi_head.py:668-671): out uint8 [D,H,W].
+ * skip_empty = 1: mmdet's CPU path (paste inside the integer-expanded box only - the CPU reference of north_star);
+ * skip_empty = 0: its CUDA path (the grid spans the whole image; the reference runs on cuda:0, main.py:365).  The two
+ * agree for thr >= 0.5 (the configured 0.5, fgn_r50_c4_densecl.py:186) and differ below it. */
 int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uint8_t* out, const int32_t* n_dev,
-                      int n_det, int img_h, int img_w, int mask_size, float thr, void* stream);
+                      int n_det, int img_h, int img_w, int mask_size, float thr, int skip_empty, void* stream);
 
 /* Fused paste + threshold + COCO RLE (replaces get_seg_masks -> .cpu() -> pycocotools encode,
  * fgn_roi_head.py:668-671 + fgn.py:267,281): out_bytes [D,byte_cap] holds the COCO "counts"
@@ -246,7 +249,8 @@ int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uin
  * overflow[d] != 0: a cap was too small, use fgn_mask_paste_u8 + host RLE for that detection. */
 int fgn_mask_rle(const float* prob, const float* boxes, int box_stride, uint32_t* trans_scratch,
                  uint8_t* out_bytes, int32_t* out_len, int32_t* overflow, const int32_t* n_dev, int n_det,
-                 int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap, void* stream);
+                 int img_h, int img_w, int mask_size, float thr, int trans_cap, int byte_cap, int skip_empty,
+                 void* stream);
 
 /* COCO RLE of dense binary masks on the device: the query's ground-truth masks, which the reference copies to
  * the GPU with the batch (fgn.py:92-99) and encodes on the host with pycocotools (fgn.py:298, `qry_isegmaps_rle`).

@@ -126,3 +126,51 @@ def test_dense_mask_rle_matches_host_encoder(hw):
     assert ovf[:3].sum() == 0
     out = ops.dense_mask_rle(torch.zeros(0, h, w, dtype=torch.bool, device='cuda'))
     assert out[0].shape[0] == 0
+
+
+@pytest.mark.parametrize('hw', [(97, 131), (300, 400)])
+def test_cuda_paste_semantics_match_the_whole_image_grid_and_agree_with_the_cpu_path_at_half(hw):
+    """mmdet pastes with ``skip_empty=(device.type == 'cpu')``: on the CUDA device the reference runs on (main.py:365)
+    the sampling grid spans the whole image.  (1) ``skip_empty=False`` of the kernels == the oracle's whole-image
+    paste at thresholds 0.5, 0.3 and 0.1 (pixel differences only where the oracle's own sample sits within 1e-5 of
+    the threshold), although the kernels only visit the band around the box in which a sample can be non-zero;
+    (2) below 0.5 that semantic sets pixels OUTSIDE the CPU path's window (the two definitions really differ there);
+    (3) at 0.5 - the reference's configured threshold (fgn_r50_c4_densecl.py:186) - both semantics give the same masks
+    and the same RLE strings; (4) fused RLE == RLE of the dense paste under either semantic."""
+    from fgn_amd import ops, rle
+    from oracle import fgn_ref_cpu as O
+    h, w = hw
+    g = torch.Generator().manual_seed(21)
+    d = 10
+    prob = torch.rand(d, 14, 14, generator=g) * 0.5 + 0.5          # borders well above 0.2: visible halo below 0.5
+    prob[0] = 1.0
+    boxes = _boxes(g, d, h, w)
+    boxes[1, :4] = torch.tensor([w * 0.3, h * 0.3, w * 0.3 + 56.0, h * 0.3 + 84.0])   # halo of 2 / 3 px
+    boxes[2, :4] = torch.tensor([0., 0., float(w), float(h)])
+    boxes[3, :4] = torch.tensor([5.0, 7.0, 5.0, 40.0])             # zero width: the grid coordinate degenerates
+    pc, bc = prob.cuda(), boxes.cuda()
+    outside_total = 0
+    for thr in (0.5, 0.3, 0.1):
+        dense = ops.mask_paste(pc, bc, h, w, thr, skip_empty=False).cpu().numpy().astype(bool)
+        samples = []
+        ref = O.paste_masks(prob[:, None], boxes.numpy(), h, w, thr, samples=samples, skip_empty=False)
+        for j in range(d):
+            ys, xs = np.nonzero(dense[j] != ref[j])
+            if len(ys):
+                smp = samples[j][2]
+                assert np.abs(smp[ys, xs] - thr).max() <= 1e-5, (thr, j, np.abs(smp[ys, xs] - thr).max())
+        cpu_sem = ops.mask_paste(pc, bc, h, w, thr).cpu().numpy().astype(bool)
+        ref_cpu = O.paste_masks(prob[:, None], boxes.numpy(), h, w, thr)
+        if thr == 0.5:
+            assert np.array_equal(dense, cpu_sem)
+            a = ops.mask_rle(pc, bc, h, w, thr, skip_empty=False)
+            b = ops.mask_rle(pc, bc, h, w, thr)
+            assert torch.equal(a[1], b[1]) and all(torch.equal(a[0][j, :int(a[1][j])], b[0][j, :int(b[1][j])]) for j in range(d))
+        else:
+            outside_total += int((ref & ~ref_cpu).sum())
+            assert (dense & ~cpu_sem).sum() >= 0.9 * (ref & ~ref_cpu).sum()
+        by, ln, ovf = [t.cpu().numpy() for t in ops.mask_rle(pc, bc, h, w, thr, skip_empty=False)]
+        assert ovf.sum() == 0
+        for j in range(d):
+            assert by[j, :ln[j]].tobytes() == rle.encode(dense[j])['counts'], (thr, j)
+    assert outside_total > 0          # the whole-image semantic does reach outside the CPU window below 0.5

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, in one GPU-box call: bash tools/collect_round.sh r03
+# Everything profiles/ holds for one round, in one GPU-box call: bash tools/collect_round.sh r04
 set -uo pipefail
-R=${1:-r03}
+R=${1:-r04}
 : "${GRAFT_REPO_ROOT:?run on the GPU box}"
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/collect_$R
@@ -12,7 +12,7 @@ last_json() { grep '^{' "$1" | tail -1; }
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_default.out" 2> "$OUT/bench_default.err"; last_json "$OUT/bench_default.out" > "$OUT/${R}_bench_line.json"
 echo "default: $(cut -c1-160 "$OUT/${R}_bench_line.json")"
 # 2. the other configs of BASELINE.json
-for w in "cfg4 8" "cfg5 1" "cfg1 1" "cfg2 1"; do set -- $w
+for w in "cfg4 4" "cfg4 8" "cfg5 1" "cfg1 1" "cfg2 1"; do set -- $w
   python bench.py --workload $1 --batch $2 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/b.out" 2> "$OUT/bench_$1.err"; last_json "$OUT/b.out" > "$OUT/${R}_bench_$1_b$2.json"
   echo "$1 b$2: $(cut -c1-160 "$OUT/${R}_bench_$1_b$2.json")"
 done
@@ -24,4 +24,7 @@ cp "$OUT"/stats_b8/*/*kernel_stats.csv "$OUT/${R}_kernel_stats_cfg4_b8.csv" 2>/d
 # 4. multi-rank rehearsal on the one GPU (gloo, 5 ranks: the box allows 6 GPU processes)
 FGN_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 5 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/r5.out" 2> "$OUT/r5.err"; last_json "$OUT/r5.out" > "$OUT/${R}_rehearsal_5rank_gloo.json"
 echo "5 ranks: $(cut -c1-160 "$OUT/${R}_rehearsal_5rank_gloo.json")"
+# 5. per-launch roofline table of one episode, in-kernel clock of the large GEMMs under sustained load
+timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch.csv" 7 > "$OUT/per_launch.txt" 2>&1; tail -14 "$OUT/per_launch.txt"
+timeout -k 10 200 tools/micro/gemm_clock 2.5 0 > "$OUT/${R}_gemm_clock.jsonl" 2> "$OUT/gemm_clock.err"; cut -c1-260 "$OUT/${R}_gemm_clock.jsonl"
 ls "$OUT"
