@@ -371,6 +371,7 @@ class FGN(torch.nn.Module):
         ic = ic[0] if isinstance(ic, (list, tuple)) and ic else ic
         self.backbone_pretrained = pretrained or (ic.get('checkpoint') if isinstance(ic, dict) and
                                                   ic.get('type') == 'Pretrained' else None) or None
+        self._frozen_stages = int((backbone or {}).get('frozen_stages', 4)) if isinstance(backbone, dict) else 4
         self._packed_device = None
         self._PT = None                           # train-mode layers of the shared head (fgn_amd.train.pack_train)
         self.debug_trace: Optional[dict] = None   # set to {} to capture intermediates (tests)
@@ -450,6 +451,19 @@ class FGN(torch.nn.Module):
     @staticmethod
     def _canon(name: str, v: torch.Tensor) -> torch.Tensor:
         return v.detach().cpu() if name.endswith('num_batches_tracked') else v.detach().float().cpu()
+
+    @property
+    def backbone(self):
+        """What main.py:402-405 reads off ``model.backbone`` right after ``build_detector``: ``frozen_stages`` (from the
+        reference's config dict; 4 = the DenseCL configuration, -1 = from scratch), the list of stage names it shortens
+        to drop res5 (this detector is C4 by construction: three stages), and ``eval()`` (BatchNorm is folded from the
+        running statistics at pack time: there is no train-mode backbone to switch)."""
+        from types import SimpleNamespace
+        ns = SimpleNamespace(frozen_stages=self._frozen_stages, norm_eval=bool(self.cfg['backbone'].get('norm_eval', True)),
+                             res_layers=[f'layer{i + 1}' for i in range(len(self.cfg['backbone']['stage_blocks']) + 1)])
+        ns.eval = lambda: ns
+        ns.train = lambda mode=True: ns
+        return ns
 
     def init_weights(self) -> None:
         """mmcv ``BaseModule.init_weights`` as far as this path needs it: the backbone's ``Pretrained`` init_cfg
