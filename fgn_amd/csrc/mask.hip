@@ -62,7 +62,8 @@ extern "C" int fgn_mask_logits_f32(const float* x, const float* w, float bias, f
 //   skip_empty = 0 (its CUDA path: the reference runs on cuda:0, main.py:365): the grid spans the whole image.  A
 //     sample is non-zero only while its source coordinate lies inside (-1, M), i.e. within half a mask pixel =
 //     box_w / (2 M) of the box, so the region computed here is that band (+1 px of slack), not the image; the two
-//     semantics agree for thr >= 0.5 (the value on the box edge is half the border pixel) and differ below it.
+//     semantics agree for thr >= 0.5 on boxes of positive width and height (the value on the box edge is half the
+//     border pixel) and differ below it.
 //     (thr <= 0 sets every pixel of the image under this semantic: the region is then the image.)
 // ----------------------------------------------------------------------------------------------
 // One mask sample, separable form shared by the dense paste kernel and the RLE kernel (so both

@@ -355,8 +355,8 @@ class FGN(torch.nn.Module):
         # Region semantics of the mask paste (mmdet `_do_paste_mask`): 'cpu' = skip_empty=True, a mask is pasted inside the
         # integer-expanded box only - the CPU reference north_star names, this build's oracle and default; 'cuda' =
         # skip_empty=False, the grid spans the whole image - what the reference computes where it actually runs (cuda:0,
-        # main.py:365).  Identical at the configured threshold 0.5 (fgn_r50_c4_densecl.py:186: the value on the box
-        # edge is half the border pixel), up to box_w / 28 more pixels outside the box under 'cuda' below it.
+        # main.py:365).  Identical at the configured threshold 0.5 for boxes of positive width and height
+        # (fgn_r50_c4_densecl.py:186: the value on the box edge is half the border pixel), up to box_w / 28 more pixels outside the box under 'cuda' below it.
         self.paste_semantics = 'cpu'
         if self.test_cfg['rcnn'].get('mask_thr_binary', 0.5) < 0.5:
             import warnings

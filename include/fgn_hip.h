@@ -239,7 +239,8 @@ int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logit
 /* _do_paste_mask + threshold (fgn_roi_head.py:668-671): out uint8 [D,H,W].
  * skip_empty = 1: mmdet's CPU path (paste inside the integer-expanded box only - the CPU reference of north_star);
  * skip_empty = 0: its CUDA path (the grid spans the whole image; the reference runs on cuda:0, main.py:365).  The two
- * agree for thr >= 0.5 (the configured 0.5, fgn_r50_c4_densecl.py:186) and differ below it. */
+ * agree for thr >= 0.5 (the configured 0.5, fgn_r50_c4_densecl.py:186) on boxes of positive width and height, and
+ * differ below it (and on degenerate boxes, whose grid coordinate mmdet sets to 0: the mask's centre line everywhere). */
 int fgn_mask_paste_u8(const float* prob, const float* boxes, int box_stride, uint8_t* out, const int32_t* n_dev,
                       int n_det, int img_h, int img_w, int mask_size, float thr, int skip_empty, void* stream);
 

@@ -136,7 +136,7 @@ def test_cuda_paste_semantics_match_the_whole_image_grid_and_agree_with_the_cpu_
     the threshold), although the kernels only visit the band around the box in which a sample can be non-zero;
     (2) below 0.5 that semantic sets pixels OUTSIDE the CPU path's window (the two definitions really differ there);
     (3) at 0.5 - the reference's configured threshold (fgn_r50_c4_densecl.py:186) - both semantics give the same masks
-    and the same RLE strings; (4) fused RLE == RLE of the dense paste under either semantic."""
+    and the same RLE strings for every box of positive width and height; (4) fused RLE == RLE of the dense paste under either semantic."""
     from fgn_amd import ops, rle
     from oracle import fgn_ref_cpu as O
     h, w = hw
@@ -162,10 +162,14 @@ def test_cuda_paste_semantics_match_the_whole_image_grid_and_agree_with_the_cpu_
         cpu_sem = ops.mask_paste(pc, bc, h, w, thr).cpu().numpy().astype(bool)
         ref_cpu = O.paste_masks(prob[:, None], boxes.numpy(), h, w, thr)
         if thr == 0.5:
-            assert np.array_equal(dense, cpu_sem)
+            # every box of positive width and height: same mask, same string.  (The zero-width box 3 is mmdet's own
+            # quirk: its grid coordinate is inf -> 0, so the whole-image grid samples the mask's centre column in EVERY
+            # column of the image, the CPU window only in its three columns - the semantics differ there at any threshold.)
+            ok = [j for j in range(d) if j != 3]
+            assert np.array_equal(dense[ok], cpu_sem[ok]) and not np.array_equal(dense[3], cpu_sem[3])
             a = ops.mask_rle(pc, bc, h, w, thr, skip_empty=False)
             b = ops.mask_rle(pc, bc, h, w, thr)
-            assert torch.equal(a[1], b[1]) and all(torch.equal(a[0][j, :int(a[1][j])], b[0][j, :int(b[1][j])]) for j in range(d))
+            assert all(int(a[1][j]) == int(b[1][j]) and torch.equal(a[0][j, :int(a[1][j])], b[0][j, :int(b[1][j])]) for j in ok)
         else:
             outside_total += int((ref & ~ref_cpu).sum())
             assert (dense & ~cpu_sem).sum() >= 0.9 * (ref & ~ref_cpu).sum()
