@@ -306,7 +306,20 @@ def main():
         episodes.append(e)
 
     max_det = cfg['test_cfg']['rcnn']['max_per_img']
-    comm_stream = torch.cuda.Stream()
+    # Hardware-queue budget: HIP maps streams onto four hardware queues (GPU_MAX_HW_QUEUES) in stream-creation
+    # order, work of streams that share a queue runs in order, and a stream that waits for another queue's event blocks
+    # whatever shares its queue.  More queues are NOT better: 2 / 3 / 4 / 5 / 6 / 8 queues give 170 / 172 / 190 / 114 /
+    # 142 / 138 img/s, transfer streams in the high-priority pool 140 (profiles/r04_hw_queues.txt).  The fewer streams an
+    # episode touches, the fewer cross-queue waits it pays:
+    # (graph mode only: an eager episode uploads its inputs on the upload stream one episode ahead, which needs that stream)
+    # Measured r04 (profiles/r04_hw_queues.txt): with one episode per step every cross-queue wait counts - the transfers of
+    # an episode on its own caller stream (mode 3: no upload / copy streams at all) 196.6-198.3 img/s against 190.5-192.1
+    # with an upload and a copy stream per caller, over 200 steps (the driver's 20-step window: equal); at 4 / 8 episodes
+    # per step the transfers are larger and the separate streams are equal or 1 % better.
+    xfer_mode = int(os.environ.get('FGN_XFER_MODE', '3' if args.batch <= 2 else '0'))
+    if args.graphs and xfer_mode:
+        model.transfer_stream(xfer_mode)
+    comm_stream = torch.cuda.Stream() if world > 1 else None
     ep_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else [None]
     gathered_last = {}
     gather_on_compute = bool(os.environ.get('FGN_BENCH_GATHER_ON_COMPUTE'))
@@ -346,7 +359,6 @@ def main():
             with ctx:
                 dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
                                            e['img_shape'], support_code=e['code'], qry_isegmaps=e['qry_isegmaps'])
-                done = torch.cuda.current_stream().record_event()
         finally:
             ops.PROFILE = None
         if world > 1:

@@ -393,6 +393,7 @@ class FGN(torch.nn.Module):
         # r04: B = 1 189.9-191.3 vs 188.6-190.9 img/s, B = 4 211.1-211.8 vs 209.2-211.0, B = 8 214.6 vs 215.5): on since
         # round 4 for the launch count.  False = the separate pass, byte-identical to `encode_supports`.
         self.use_merged_support_head = True
+        self.transfer_mode = 0                    # 0: upload + copy stream per caller; 1 / 2: see transfer_stream()
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
@@ -816,12 +817,36 @@ class FGN(torch.nn.Module):
             self._graphs = {}
 
     def _stream_for(self, role: str, main) -> 'torch.cuda.Stream':
-        """One auxiliary HIP stream per (role, caller stream)."""
-        key = (role, main.cuda_stream)
+        """One auxiliary HIP stream per (role, caller stream), or what ``transfer_mode`` prescribes for the 'upload' and
+        'copy' roles (``transfer_stream``).
+
+        HIP maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default; the k-th stream created
+        takes queue k mod 4 once the pool is full), work of streams that share a queue runs in order, and a pool larger
+        than 4 is time-sliced by the firmware: measured r04 (profiles/r04_hw_queues.txt) 2 / 3 / 4 / 5 / 6 / 8 queues
+        give 170 / 172 / 190 / 114 / 142 / 138 img/s, and transfer streams in the high-priority pool (= more active
+        queues) 140.  So the budget is four queues, and which streams share one matters."""
+        mode = self.transfer_mode
+        if (mode in (2, 3) and role == 'copy') or (mode == 3 and role == 'upload'):
+            return main                                   # the transfers of an episode ride on its caller stream
+        if (mode == 1 and role in ('upload', 'copy')) or (mode == 2 and role == 'upload'):
+            key = ('xfer', 0)                             # one stream for every caller
+        else:
+            key = (role, main.cuda_stream)
         st = self._streams.get(key)
         if st is None:
             st = self._streams[key] = torch.cuda.Stream()
         return st
+
+    def transfer_stream(self, mode: int = 2) -> 'torch.cuda.Stream':
+        """Select a transfer arrangement and create its shared stream NOW - a serving loop calls this BEFORE it creates
+        its caller streams, so that the shared stream and each of up to three caller streams get a hardware queue of
+        their own.  mode 2: the result copies of an episode ride on its caller stream (no copy stream: a stream that
+        waits for an episode's results blocks whatever shares its queue), one upload stream for all callers; mode 1: one
+        stream for uploads AND result copies (measured r04: serialises the episodes, 190 -> 159 img/s - an upload queued
+        behind a copy that waits for the previous episode holds up the next); mode 0: one upload and one copy stream
+        per caller stream (round 3)."""
+        self.transfer_mode = int(mode)
+        return self._stream_for('upload', torch.cuda.current_stream())
 
     def _upload(self, tensors: dict, gt_masks, dev, main):
         """``modify_input`` (fgn.py:79-108): host -> device copies of one batch, on an upload stream so that they

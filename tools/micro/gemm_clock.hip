@@ -91,12 +91,23 @@ static int run(const Shape& sh, int variant, double seconds) {
             rmin = std::min(rmin, r0); rmax = std::max(rmax, r1);
         }
     }
+    const std::vector<unsigned long long> raw = h;
     std::fill(h.begin(), h.end(), 0ull);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clock_stamps), h.data(), h.size() * 8));
     if (ws.empty()) { fprintf(stderr, "%s v%d: no stamps\n", sh.name, variant); return 1; }
     auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
     std::vector<double> clk, span, start_us, end_us;
     for (auto& w : ws) { clk.push_back(w.clk); span.push_back(w.span); start_us.push_back((w.r0 - (double)rmin) * 0.01); end_us.push_back(((double)rmax - w.r1) * 0.01); }
+    if (getenv("GEMM_CLOCK_PLACEMENT")) {      // block -> (XCC, CU key) of the first blocks of XCD share 0 (blocks 0, 8, 16, ...)
+        fprintf(stderr, "%s v%d placement of blocks b = 8 i (xcc:cu):", sh.name, variant);
+        for (int i = 0; i < 48; ++i) {
+            const int b = 8 * i;
+            fprintf(stderr, " %llu:%02llx", raw[b * 6 + 4] & 0xf, (raw[b * 6 + 5] >> 8) & 0xff);
+        }
+        fprintf(stderr, "\n  blocks 0..15:");
+        for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu:%02llx", raw[b * 6 + 4] & 0xf, (raw[b * 6 + 5] >> 8) & 0xff);
+        fprintf(stderr, "\n");
+    }
     // workgroups per CU (as placed in the last launch), and the median span of a workgroup by how crowded its CU was
     std::vector<unsigned> cus; for (auto& w : ws) cus.push_back(w.cu);
     std::sort(cus.begin(), cus.end());
