@@ -395,14 +395,16 @@ def test_hip_graph_replay_is_identical():
     assert len(model._graphs) == 3
 
 
-@pytest.mark.parametrize('in_flight', [2, 3, 5])
-def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager(in_flight):
+@pytest.mark.parametrize('in_flight,xfer_mode', [(2, 0), (3, 0), (5, 0), (3, 3), (5, 3), (3, 2), (3, 1)])
+def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager(in_flight, xfer_mode):
     """bench.py's execution mode (round 3): hipGraph replay, steps alternating between two caller streams, two to five
     episodes queued before the first is packed (three is bench.py's default: a caller stream then holds two replays of
     its graph, the second waiting on the GPU for the download of the first) - one captured graph, one set of static
     buffers, one side / upload / copy stream and one ring of pinned result slots per caller stream.  Twelve steps over
     five distinct episodes must give, step by step, the bytes of a serial eager run (boxes, scores, labels, detection
-    RLE, ground-truth RLE)."""
+    RLE, ground-truth RLE).  ``xfer_mode``: the transfer arrangements of ``FGN.transfer_stream`` - 3 (bench.py's choice
+    at one episode per step, round 4): uploads and result copies ride on the caller stream itself, no upload / copy
+    streams; 2: copies on the caller stream, one upload stream for all; 1: one stream for both."""
     from fgn_amd.config import tiny_config
     from fgn_amd.detector import FGN
     from fgn_amd.episodes import make_batch
@@ -415,6 +417,8 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
     want = [model.simple_test(**e, rescale=True) for e in eps]
     assert all(len(w[0]['dt_scores']) > 0 for w in want)
     model.use_graphs = True
+    if xfer_mode:
+        model.transfer_stream(xfer_mode)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     pending, got = [], []
 
