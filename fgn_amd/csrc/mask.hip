@@ -400,14 +400,13 @@ __global__ __launch_bounds__(RLE_THREADS) void dense_rle_kernel(const uint8_t* _
     // change bits of chunk c: bit r set iff pixel (x, 16*k + r) differs from its predecessor in scan order
     auto chunk_bits = [&](int c, int& prev) -> unsigned {
         const uint4 v = *reinterpret_cast<const uint4*>(m + (size_t)c * 16);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        unsigned bits = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = (w[r >> 2] >> (8 * (r & 3))) & 1;
-            bits |= (unsigned)(b != prev) << r;
-            prev = b;
-        }
+        // the 16 bytes are 0 / 1 (mask_to_columns_kernel normalises them): a multiply gathers the four low bits of a
+        // word into one nibble (b0 | b1 << 1 | b2 << 2 | b3 << 3 lands in bits 24..27, the partial products never
+        // carry), and "differs from its predecessor" is one XOR against the value shifted by a pixel
+        const unsigned px = ((v.x * 0x01020408u) >> 24 & 0xfu) | ((v.y * 0x01020408u) >> 20 & 0xf0u) |
+                            ((v.z * 0x01020408u) >> 16 & 0xf00u) | ((v.w * 0x01020408u) >> 12 & 0xf000u);
+        const unsigned bits = (px ^ ((px << 1) | (unsigned)prev)) & 0xffffu;
+        prev = (int)(px >> 15);
         const int k = c % cpc;
         const int valid = min(16, H - 16 * k);                  // pad rows never differ, but mask them anyway
         return valid >= 16 ? bits : (bits & ((1u << valid) - 1u));
