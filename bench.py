@@ -320,6 +320,15 @@ def main():
     if args.graphs and xfer_mode:
         model.transfer_stream(xfer_mode)
     comm_stream = torch.cuda.Stream() if world > 1 else None
+    if world > 1 and backend == 'nccl':
+        # RCCL runs a collective on an internal stream of its own, which takes the next hardware queue when it is first
+        # used.  One warm-up collective HERE - after the communication stream, before the caller streams exist - gives
+        # that stream a queue no caller stream shares: an all-gather that waits for a late rank then blocks nobody's
+        # compute (same reasoning as for the transfer streams above).
+        with torch.cuda.stream(comm_stream):
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+        comm_stream.synchronize()
     ep_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else [None]
     gathered_last = {}
     gather_on_compute = bool(os.environ.get('FGN_BENCH_GATHER_ON_COMPUTE'))
