@@ -12,10 +12,11 @@
 // x : [D][P*P][4][C]  (post-ReLU upsample output);  w : [C], bias scalar
 // prob/logit out : [D][2P][2P]
 __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float bias, float* __restrict__ logits,
-                                                          float* __restrict__ prob,
+                                                          float bias, const float* __restrict__ bias_dev,
+                                                          float* __restrict__ logits, float* __restrict__ prob,
                                                           const int32_t* __restrict__ n_dev, int n_det, int P,
                                                           int C) {
+    if (bias_dev) bias = *bias_dev;          // device-resident bias (training: no host read of the updated parameter)
     int D = n_det;
     if (n_dev) D = min(D, *n_dev);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -42,13 +43,13 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     }
 }
 
-extern "C" int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logits, float* prob,
+extern "C" int fgn_mask_logits_f32(const float* x, const float* w, float bias, const float* bias_dev, float* logits, float* prob,
                                    const int32_t* n_dev, int n_det, int roi_size, int C, hipStream_t stream) {
     if (!x || !w || !logits || !prob) return FGN_ERR_ARG;
     if (C % 4) return FGN_ERR_SHAPE;
     if (n_det == 0) return FGN_OK;
     const int waves = n_det * roi_size * roi_size * 4;
-    hipLaunchKernelGGL(mask_logits_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, x, w, bias, logits, prob,
+    hipLaunchKernelGGL(mask_logits_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, x, w, bias, bias_dev, logits, prob,
                        n_dev, n_det, roi_size, C);
     FGN_LAUNCH_CHECK();
     return FGN_OK;

@@ -628,7 +628,10 @@ class FGN(torch.nn.Module):
         w4 = wt.permute(2, 3, 1, 0).reshape(4 * cout_u, cin_u, 1, 1).contiguous()
         P['upsample'] = ops.pack_conv(w4, bias=sd['roi_head.mask_head.upsample.bias'].repeat(4), relu=True)
         P['logit_w'] = sd['roi_head.mask_head.conv_logits.weight'].reshape(-1).clone()
-        P['logit_b'] = float(sd['roi_head.mask_head.conv_logits.bias'][0])
+        # a float for host-resident weights; the device-resident master weights of a Trainer stay on the device (the
+        # kernel reads the bias through a pointer: no host synchronisation at the end of every training step)
+        lb = sd['roi_head.mask_head.conv_logits.bias']
+        P['logit_b'] = lb.reshape(-1)[:1].float().contiguous().clone() if lb.is_cuda else float(lb[0])
         return P
 
     # --- stages ---------------------------------------------------------------------------

@@ -57,7 +57,7 @@ SIGNATURES = {
     'fgn_conv2d_pair_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p] + [_i] * 8 + [_p]),
     'fgn_det_post_scratch_bytes': (C.c_size_t, [_i, _i]),
     'fgn_det_post_f32': (_i, [_p] * 7 + [_i] + [_p] * 3 + [_i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f), _f, _f, _f, _i, _p]),
-    'fgn_mask_logits_f32': (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
+    'fgn_mask_logits_f32': (_i, [_p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p]),
     'fgn_mask_paste_u8': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     'fgn_mask_rle': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     'fgn_dense_rle_scratch_bytes': (C.c_size_t, [_i, _i, _i, _i]),

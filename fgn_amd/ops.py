@@ -891,9 +891,10 @@ def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n
     return det, lab, n_det
 
 
-def mask_logits(x: torch.Tensor, w: torch.Tensor, bias: float, roi_size: int,
+def mask_logits(x: torch.Tensor, w: torch.Tensor, bias, roi_size: int,
                 n_dev: Optional[torch.Tensor] = None):
-    """x [D, P, P, 4*C] (deconv output, sub-position major) -> logits, prob [D, 2P, 2P]."""
+    """x [D, P, P, 4*C] (deconv output, sub-position major) -> logits, prob [D, 2P, 2P].  ``bias``: a float, or a
+    one-element device tensor the kernel reads itself (no host read of a parameter a training step has just updated)."""
     _chk(x, 'x')
     _chk(w, 'w')
     d = x.shape[0]
@@ -902,8 +903,12 @@ def mask_logits(x: torch.Tensor, w: torch.Tensor, bias: float, roi_size: int,
         raise _lib.FgnHipError('mask_logits: x shape inconsistent with weight')
     logits = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
     prob = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
-    rc = _lib.load().fgn_mask_logits_f32(_ptr(x), _ptr(w), float(bias), _ptr(logits), _ptr(prob), _ptr(n_dev), d,
-                                         roi_size, c, _stream())
+    bias_dev = None
+    if isinstance(bias, torch.Tensor):
+        _chk(bias, 'bias')
+        bias_dev, bias = bias, 0.0
+    rc = _lib.load().fgn_mask_logits_f32(_ptr(x), _ptr(w), float(bias), _ptr(bias_dev), _ptr(logits), _ptr(prob),
+                                         _ptr(n_dev), d, roi_size, c, _stream())
     _lib.check(rc, 'fgn_mask_logits_f32')
     return logits, prob
 

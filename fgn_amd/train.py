@@ -372,10 +372,17 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     avg = max(float(n_rois), 1.0)                     # every sampled RoI has label weight > 0
     if n_rois:
         losses['loss_cls'] = ops.softmax_ce_sum(cls_score, labels, lw, avg).view(())
-        pred_h = cls_score.argmax(dim=-1).cpu().numpy()                                   # get_accuracy: on the host
-        acc = float((pred_h == lab_h).mean())
-        bal = float(np.mean([(pred_h[lab_h == c] == c).mean() for c in np.unique(lab_h)]))
-        losses['ACC-Unbalanced'], losses['ACC-Balanced'] = torch.Tensor([acc]), torch.Tensor([bal])
+        # get_accuracy (fgn_roi_head.py:100-116: accuracy_score / balanced_accuracy_score of sklearn) on the DEVICE, in
+        # fp64 like numpy: no host read of the predictions in the middle of the step (round 4: the step had three host
+        # synchronisations - the assignment vectors, this one and the logit bias of the re-pack - and two of them only
+        # made the GPU wait for the next burst of launches).  Returned as one-element device tensors.
+        hit = (cls_score.argmax(dim=-1) == labels).double()
+        onehot = torch.nn.functional.one_hot(labels, N + 1).double()
+        cnt = onehot.sum(0)
+        present = (cnt > 0).double()
+        recall = (onehot * hit[:, None]).sum(0) / cnt.clamp(min=1.0)
+        losses['ACC-Unbalanced'] = hit.mean().float().reshape(1)
+        losses['ACC-Balanced'] = ((recall * present).sum() / present.sum()).float().reshape(1)
     pos_pred = pos_tgt = None
     if pos_rows_h.size:
         pos_pred = bbox_pred.view(n_rois, -1, 4)[pos_rows, labels[pos_rows]].contiguous()

@@ -232,8 +232,9 @@ int fgn_det_post_f32(const float* rois, const float* cls_raw, const float* reg_r
                      void* stream);
 
 /* conv_logits (1x1, one class) + sigmoid on the un-shuffled deconv output [D,P*P,4,C];
- * logits/prob [D,2P,2P] (FCNMaskHead, fgn_roi_head.py:380; sigmoid of get_seg_masks) */
-int fgn_mask_logits_f32(const float* x, const float* w, float bias, float* logits, float* prob,
+ * logits/prob [D,2P,2P] (FCNMaskHead, fgn_roi_head.py:380; sigmoid of get_seg_masks).  bias_dev (optional): the bias
+ * as one float in device memory, read by the kernel instead of `bias` (a training loop updates it on the device). */
+int fgn_mask_logits_f32(const float* x, const float* w, float bias, const float* bias_dev, float* logits, float* prob,
                         const int32_t* n_dev, int n_det, int roi_size, int C, void* stream);
 
 /* _do_paste_mask + threshold (fgn_roi_head.py:668-671): out uint8 [D,H,W].
