@@ -480,3 +480,51 @@ extern "C" int fgn_winograd4_output2_f32(const float* Mo, const float* shift, fl
     if (!y1) return FGN_ERR_ARG;
     return wg4_output_launch(Mo, y0, shift, nullptr, n_img0, H0, W0, C, t_pad, relu, y1, n_img1, H1, W1, stream);
 }
+
+// ----------------------------------------------------------------------------------------------
+// Weight side of the Winograd forms: U[g = a * R + b][co][ci] = sum_ij G[a][i] * w[co][ci][i][j] * G[b][j], R = m + 2,
+// computed in fp64 from the fp32 weights and rounded once - the transform `ops.pack_winograd` does with torch ops on
+// the host when a model is built.  A training loop re-derives U from the updated master weights after EVERY step
+// (fgn_amd.train.Trainer.refresh): there it was ~40 small torch kernels and 300 MB of fp64 intermediates per layer;
+// here one launch writes U in place (rows [cout, cout_pad) of a group keep the zeros of the first pack).
+// G [R][3] fp64 is handed over by the caller (the host's table is the single definition of the interpolation points).
+// ----------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void wg_pack_weights_kernel(const float* __restrict__ w, const double* __restrict__ G,
+                                                              float* __restrict__ U, int cout, int cin, int cout_pad) {
+    __shared__ double g[R][3];
+    if (threadIdx.x < R * 3) g[threadIdx.x / 3][threadIdx.x % 3] = G[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)cout * cin;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(q / cin), ci = (int)(q - (long long)co * cin);
+        double k[3][3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k[i / 3][i % 3] = (double)w[q * 9 + i];
+        double t[R][3];
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[a][j] = g[a][0] * k[0][j] + g[a][1] * k[1][j] + g[a][2] * k[2][j];
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int b = 0; b < R; ++b)
+                U[((size_t)(a * R + b) * cout_pad + co) * cin + ci] =
+                    (float)(t[a][0] * g[b][0] + t[a][1] * g[b][1] + t[a][2] * g[b][2]);
+    }
+}
+
+extern "C" int fgn_winograd_pack_weights_f32(const float* w, const double* G, float* U, int cout, int cin, int cout_pad,
+                                             int m, hipStream_t stream) {
+    if (!w || !G || !U) return FGN_ERR_ARG;
+    if ((m != 2 && m != 4) || cout < 1 || cin < 1 || cout_pad < cout) return FGN_ERR_SHAPE;
+    const long long total = (long long)cout * cin;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    if (m == 4)
+        hipLaunchKernelGGL(wg_pack_weights_kernel<6>, dim3(grid), dim3(256), 0, stream, w, G, U, cout, cin, cout_pad);
+    else
+        hipLaunchKernelGGL(wg_pack_weights_kernel<4>, dim3(grid), dim3(256), 0, stream, w, G, U, cout, cin, cout_pad);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}

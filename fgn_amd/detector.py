@@ -634,6 +634,48 @@ class FGN(torch.nn.Module):
         P['logit_b'] = lb.reshape(-1)[:1].float().contiguous().clone() if lb.is_cuda else float(lb[0])
         return P
 
+    def _repack_heads_(self, sd) -> None:
+        """``_pack_heads`` of updated DEVICE weights into the layers ``self._P`` already holds (same shapes): one strided
+        copy per convolution, one kernel per Winograd layer, no allocation - the re-pack between two training steps
+        (round 4: 2.5 ms of ~150 torch kernels -> a few dozen launches).  Same values as a fresh ``_pack_heads``."""
+        P = self._P
+        ops.repack_conv_(P['rpn_conv'], sd['rpn_head.rpn_conv.weight'], sd['rpn_head.rpn_conv.bias'])
+        if P['rpn_conv_wg'] is not None:
+            ops.repack_winograd_(P['rpn_conv_wg'], sd['rpn_head.rpn_conv.weight'], sd['rpn_head.rpn_conv.bias'])
+        # fused objectness + delta 1x1 conv: channels [0, A) | [A, 5A) (+ zero rows up to a multiple of 4)
+        h = P['rpn_head']
+        a = sd['rpn_head.rpn_cls.weight'].shape[0]
+        n = a + sd['rpn_head.rpn_reg.weight'].shape[0]
+        h.w[:a, :h.cin].copy_(sd['rpn_head.rpn_cls.weight'].reshape(a, h.cin))
+        h.w[a:n, :h.cin].copy_(sd['rpn_head.rpn_reg.weight'].reshape(n - a, h.cin))
+        h.shift[:a].copy_(sd['rpn_head.rpn_cls.bias'])
+        h.shift[a:n].copy_(sd['rpn_head.rpn_reg.bias'])
+        wrel = sd['roi_head.cls_reg_shared_conv.weight']
+        c = wrel.shape[1] // 2
+        P['rel_q'].w[:wrel.shape[0], :c].copy_(wrel[:, :c, 0, 0])
+        P['rel_s'].w[:wrel.shape[0], :c].copy_(wrel[:, c:, 0, 0])
+        P['rel_s'].shift.copy_(sd['roi_head.cls_reg_shared_conv.bias'])
+        P['gn_w'].copy_(sd['roi_head.cls_reg_shared_conv_norm.weight'])
+        P['gn_b'].copy_(sd['roi_head.cls_reg_shared_conv_norm.bias'])
+        nc = sd['roi_head.bbox_head.fc_cls.weight'].shape[0]
+        P['fc_w'][:nc].copy_(sd['roi_head.bbox_head.fc_cls.weight'])
+        P['fc_w'][nc:].copy_(sd['roi_head.bbox_head.fc_reg.weight'])
+        P['fc_b'][:nc].copy_(sd['roi_head.bbox_head.fc_cls.bias'])
+        P['fc_b'][nc:].copy_(sd['roi_head.bbox_head.fc_reg.bias'])
+        for i, (layer, wg) in enumerate(zip(P['mask_convs'], P['mask_convs_wg'])):
+            w, b = sd[f'roi_head.mask_head.convs.{i}.conv.weight'], sd[f'roi_head.mask_head.convs.{i}.conv.bias']
+            ops.repack_conv_(layer, w, b)
+            if wg is not None:
+                ops.repack_winograd_(wg, w, b)
+        # ConvTranspose2d(k=2,s=2) [Cin,Cout,2,2] -> 1x1 conv with 4*Cout outputs, n=(dy*2+dx)*Cout+co
+        wt = sd['roi_head.mask_head.upsample.weight']
+        cin_u, cout_u = wt.shape[:2]
+        up = P['upsample']
+        up.w[:4 * cout_u].view(2, 2, cout_u, up.w.shape[1])[..., :cin_u].copy_(wt.permute(2, 3, 1, 0))
+        up.shift.view(4, cout_u).copy_(sd['roi_head.mask_head.upsample.bias'].expand(4, cout_u))
+        P['logit_w'].copy_(sd['roi_head.mask_head.conv_logits.weight'].reshape(-1))
+        P['logit_b'].copy_(sd['roi_head.mask_head.conv_logits.bias'].reshape(-1)[:1])
+
     # --- stages ---------------------------------------------------------------------------
     def extract_feat(self, img_nchw: torch.Tensor) -> torch.Tensor:
         """ResNet-50 stages 1-3 (fgn.py:67-77): NCHW fp32 in, NHWC [B,h,w,1024] out."""

@@ -32,6 +32,7 @@ SIGNATURES = {
     'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_variant': (_i, [_i, _i, _i]),
+    'fgn_winograd_pack_weights_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'fgn_winograd4_input2_f32': (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _i, _i, _p]),
     'fgn_winograd4_output2_f32': (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_nchw3_to_nhwc4_f32': (_i, [_p, _p, _i, _i, _i, _p]),

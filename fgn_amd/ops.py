@@ -399,6 +399,45 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
                          cout_pad, relu, m)
 
 
+_WG_G_DEV: dict = {}
+
+
+def repack_conv_(layer: ConvLayer, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> ConvLayer:
+    """``pack_conv`` of updated weights INTO an existing packed layer (no BatchNorm fold, Cin != 4): one strided copy -
+    what a training step needs after its optimizer update.  The padding rows / columns keep the zeros of the first pack."""
+    cout, cin, kh, kw = weight.shape
+    if (cout, cin, kh, kw) != (layer.cout, layer.cin, layer.kh, layer.kw) or cin == 4 or layer.scale is not None:
+        raise _lib.FgnHipError('repack_conv_: layer and weight do not match (or the layer folds a BatchNorm)')
+    k = kh * kw * cin
+    if layer.w.shape[1] == k:                      # rows are exactly K long: one strided copy
+        layer.w[:cout].view(cout, kh, kw, cin).copy_(weight.detach().permute(0, 2, 3, 1))
+    else:                                          # K padded to a multiple of 32: through a contiguous temporary
+        layer.w[:cout, :k].copy_(weight.detach().permute(0, 2, 3, 1).reshape(cout, k))
+    if bias is not None:
+        layer.shift.copy_(bias.detach())
+    return layer
+
+
+def repack_winograd_(layer: WinogradLayer, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> WinogradLayer:
+    """``pack_winograd`` of updated weights INTO an existing layer: one kernel (``fgn_winograd_pack_weights_f32``, fp64
+    arithmetic on the device, one rounding - the host transform's arithmetic) instead of ~40 torch kernels."""
+    cout, cin, kh, kw = weight.shape
+    if (cout, cin, kh, kw) != (layer.cout, layer.cin, 3, 3):
+        raise _lib.FgnHipError('repack_winograd_: layer and weight do not match')
+    w = weight.detach()
+    _chk(w, 'weight')
+    key = (layer.m, w.device)
+    G = _WG_G_DEV.get(key)
+    if G is None:
+        G = _WG_G_DEV[key] = _WG_G[layer.m].to(w.device).contiguous()
+    rc = _lib.load().fgn_winograd_pack_weights_f32(_ptr(w), _ptr(G), _ptr(layer.u), cout, cin, layer.cout_pad, layer.m,
+                                                   _stream())
+    _lib.check(rc, 'fgn_winograd_pack_weights_f32')
+    if bias is not None:
+        layer.shift.copy_(bias.detach())
+    return layer
+
+
 def _wg_tiles(H: int, W: int, m: int) -> int:
     return ((H + m - 1) // m) * ((W + m - 1) // m)
 

@@ -23,6 +23,7 @@ trainable heads, the Adagrad update and the re-pack of the kernel layouts itself
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Optional
 
@@ -53,6 +54,16 @@ class _SharedBlockTrain:
                 name = f'{prefix}.bn{i}.{k}'
                 b[k] = buffers[name] if buffers is not None else sd[name].detach().float().clone()
             self.bn.append(b)
+
+    def repack_(self, sd: dict) -> None:
+        """The updated weights into the packed layers this block already holds (in place; the BatchNorm affine
+        parameters alias the trainer's master weights and the running buffers are the trainer's own)."""
+        p = self.prefix
+        ops.repack_conv_(self.conv1, sd[p + '.conv1.weight'])
+        ops.repack_conv_(self.conv2, sd[p + '.conv2.weight'])
+        if self.conv2_wg is not None:
+            ops.repack_winograd_(self.conv2_wg, sd[p + '.conv2.weight'])
+        ops.repack_conv_(self.conv3, sd[p + '.conv3.weight'])
 
     def to(self, device):
         for l in (self.conv1, self.conv2, self.conv3, self.conv2_wg):
@@ -93,9 +104,10 @@ def pack_train(model, device, weights: Optional[dict] = None, buffers: Optional[
         weights, buffers = tr.W, tr.buffers
     src = model._sd if weights is None else weights
     anchors = model._PT['anchors'] if getattr(model, '_PT', None) else {}
+    pinned = model._PT.get('pinned', {}) if getattr(model, '_PT', None) else {}
     model._PT = {'shared': [_SharedBlockTrain(src, f'roi_head.shared_head.{b}', model.use_winograd, buffers).to(device)
                             for b in range(nb)],
-                 'device': torch.device(device), 'anchors': anchors}
+                 'device': torch.device(device), 'anchors': anchors, 'pinned': pinned}
 
 
 def shared_head_train(model, x, momentum: float, tape: Optional[list] = None):
@@ -154,6 +166,15 @@ def _choose(cand: np.ndarray, num: int, perm_fn) -> np.ndarray:
 
 
 _PERM_LOCK = threading.Lock()
+
+
+def _pinned(model, name: str, n: int) -> torch.Tensor:
+    """A cached pinned int32 host buffer of at least ``n`` elements (allocating pinned memory costs milliseconds)."""
+    cache = model._PT.setdefault('pinned', {})
+    buf = cache.get(name)
+    if buf is None or buf.numel() < n:
+        buf = cache[name] = torch.empty(max(n, 1), dtype=torch.int32, pin_memory=True)
+    return buf[:max(n, 1)] if buf.numel() != max(n, 1) else buf
 
 
 def _perm(perm_fn, n: int) -> torch.Tensor:
@@ -252,6 +273,12 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         gts = torch.from_numpy(grp_gt_h[g]).to(dev, non_blocking=True) if len(grp_gt_h[g]) else gt_xyxy[0][:0]
         ops.box_assign(anchors, gts, tc['pos_iou_thr'], tc['neg_iou_thr'], tc['min_pos_iou'], tc['match_low_quality'],
                        inside=inside, out=gi_all[g])
+    # the anchor assignment starts its way to the host NOW (pinned buffer, no wait): the host samples the AG-RPN sets
+    # from it while the GPU runs the proposal stage, the proposals' assignment and the support branch queued below
+    # (round 4: one blocking copy after all of that left the GPU idle through ~1.5 ms of host sampling)
+    gi_pin = _pinned(model, 'gi_all', G * n_total)
+    gi_pin.copy_(gi_all.view(-1), non_blocking=True)
+    gi_ready = torch.cuda.current_stream().record_event()
     # ---- proposals with train_cfg.rpn_proposal (fgn.py:161-167)
     rc = tcfg['rcnn']
     if proposals is None:
@@ -272,10 +299,14 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     # count_spp with the shared head in training mode (fgn_roi_head.py:491, 419-449): queued before the host copy too
     spp_tape = [] if tape is not None else None
     model._support_back(sc, B, dev, shared=lambda t: shared_head_train(model, t, bn_momentum, spp_tape))
-    # ONE device->host copy (one sync) per step: both stages' assignment vectors and the proposal counts; the
-    # reference-style sampling bookkeeping then runs on the host copy
-    packed_all = torch.cat([gi_all.view(-1)] + gis + [n_props.to(torch.int32)]).cpu().numpy()
-    gi_host = packed_all[:G * n_total].reshape(G, n_total)
+    # second (small) copy: the proposals' assignment vectors and counts; the reference-style sampling bookkeeping runs on
+    # the host copies - the AG-RPN part as soon as the first copy has landed
+    tail_dev = torch.cat(gis + [n_props.to(torch.int32)])
+    tail_pin = _pinned(model, 'gi_tail', tail_dev.numel())
+    tail_pin.copy_(tail_dev, non_blocking=True)
+    tail_ready = torch.cuda.current_stream().record_event()
+    gi_ready.synchronize()
+    gi_host = gi_pin.numpy()[:G * n_total].reshape(G, n_total)
     n_pos_total = n_neg_total = 0
     sets_h, flat, ycat, pos_flat, pos_anchor, pos_gt = [], [], [], [], [], []
     for g in range(G):
@@ -312,7 +343,8 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         tape['rpn'] = dict(x=x, head=head, sets=sets_h, x_cat=x_cat, y_cat=y_cat, w_cat=w_cat, n_samples=n_samples,
                            preds=preds, tgts=tgts, qry_fmap=qry_fmap, vec=sc['vec'], A=A, n_ways=N, n_total=n_total)
 
-    packed = packed_all[G * n_total:]
+    tail_ready.synchronize()
+    packed = tail_pin.numpy()[:tail_dev.numel()].copy()
     counts = packed[-B:].tolist()
     if tr is not None:
         tr['proposals'] = [prop_list[i][:counts[i]] for i in range(B)]
@@ -822,10 +854,19 @@ class Trainer:
     def refresh(self) -> None:
         """Re-derive every packed head layer from the master weights (device-side torch ops)."""
         m = self.model
-        heads = m._pack_heads(self.W)
-        for k, v in heads.items():
-            m._P[k] = v if not isinstance(v, torch.Tensor) else v.float().contiguous()
-        pack_train(m, self.device, self.W, self.buffers)
+        key = (m.use_winograd, m._packed_device, id(m._P))
+        if getattr(self, '_repack_key', None) == key and os.environ.get('FGN_TRAIN_REPACK_IN_PLACE', '1') != '0':
+            # every later refresh: the updated weights go INTO the packed layers built below (round 4: 3.8 ms of ~250
+            # torch kernels per step -> one strided copy per convolution and one kernel per Winograd layer)
+            m._repack_heads_(self.W)
+            for blk in m._PT['shared']:
+                blk.repack_(self.W)
+        else:
+            heads = m._pack_heads(self.W)
+            for k, v in heads.items():
+                m._P[k] = v if not isinstance(v, torch.Tensor) else v.float().contiguous()
+            pack_train(m, self.device, self.W, self.buffers)
+            self._repack_key = (m.use_winograd, m._packed_device, id(m._P))
         m._shared_dirty = {**self.W, **self.buffers}      # the inference form of the shared head is rebuilt lazily
         m._graphs = {}
 

@@ -129,6 +129,12 @@ int fgn_winograd4_output2_f32(const float* Mo, const float* shift, float* y0, in
  * channel vector width of a thread (1, 2 or 4 floats) * 10 + 1 when the input transform issues all 36 loads up front.
  * Informational (lets a profiler name the kernel of a launch); the transforms choose it themselves. */
 int fgn_winograd4_variant(int tiles_total, int C, int is_output);
+/* Weight side of both Winograd forms on the device: U[(a*R+b)][co][ci] = sum_ij G[a][i] w[co][ci][i][j] G[b][j] (R = m + 2,
+ * fp64 arithmetic, one rounding), written IN PLACE into U [R*R][cout_pad][Cin] (rows past cout untouched).  w is the
+ * torch-layout weight [Cout][Cin][3][3], G the [R][3] fp64 table of the interpolation points.  What mmcv's optimizer
+ * step + the next forward need between two training steps (no reference counterpart: cuDNN picks its own algorithm). */
+int fgn_winograd_pack_weights_f32(const float* w, const double* G, float* U, int cout, int cin, int cout_pad, int m,
+                                  void* stream);
 
 /* NCHW [n,3,H,W] -> NHWC4 [n,H,W,4] (input side of fgn.py:212,215) */
 int fgn_nchw3_to_nhwc4_f32(const float* x, float* y, int n_img, int H, int W, void* stream);

@@ -1,6 +1,7 @@
 """``forward_train``: the HIP kernels of the training path against the training oracle.
 Selection (assignment, sampling, proposal ranking / NMS) is bit-exact; losses carry an fp32 tolerance stated per test."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -733,3 +734,53 @@ def test_weight_gradient_gemm_matches_fp64(R, M, N):
     got = ops.gemm_tn(a.cuda(), b.cuda())
     assert float((got.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     assert torch.equal(got, ops.gemm_tn(a.cuda(), b.cuda()))
+
+
+def test_in_place_repack_equals_a_fresh_pack():
+    """Round 4: between two steps ``Trainer.refresh`` writes the updated weights INTO the packed layers (one strided copy
+    per convolution, ``fgn_winograd_pack_weights_f32`` per Winograd layer) instead of re-building them with torch ops.
+    (1) the device transform == the host transform of ``pack_winograd`` (fp64 arithmetic, one rounding: at most the
+    last bit of an element differs, by the summation order inside fp64); every other packed tensor is bitwise the fresh
+    pack's.  (2) three steps with the in-place re-pack end on the weights of three steps with fresh packs."""
+    from fgn_amd import ops
+    from fgn_amd.config import tiny_config
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.train import Trainer
+    g = torch.Generator().manual_seed(0)
+    for m, (cout, cin) in ((4, (96, 64)), (2, (64, 128)), (4, (256, 32))):
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        fresh = ops.pack_winograd(w, bias=b, relu=True, m=m)
+        w2, b2 = (w * 1.7 + 0.01).contiguous(), b + 1.0
+        want = ops.pack_winograd(w2, bias=b2, relu=True, m=m)
+        ops.repack_winograd_(fresh, w2, b2)
+        assert torch.equal(fresh.shift, want.shift)
+        d = (fresh.u - want.u).abs().max().item()
+        assert d <= 2.5e-7 * want.u.abs().max().item(), d
+        assert float((fresh.u != want.u).float().mean()) < 0.01
+        assert float(fresh.u[:, cout:].abs().max()) == 0.0 if fresh.cout_pad > cout else True
+    cfg = tiny_config(3, 2, width_div=2)
+    bt = make_batch(2, 1, 3, 2, 160, 224, 64)
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['FGN_TRAIN_REPACK_IN_PLACE'] = mode
+        try:
+            m1, _ = _models(cfg)
+            t = Trainer(m1)
+            for it in range(3):
+                torch.manual_seed(it)
+                t.step(bt)
+            res[mode] = ({k: v.clone() for k, v in t.W.items()},
+                         {k: (v.w.clone() if hasattr(v, 'w') else v.clone()) for k, v in m1._P.items()
+                          if k in ('rpn_conv', 'rpn_head', 'rel_q', 'rel_s', 'upsample', 'fc_w', 'fc_b', 'gn_w', 'logit_w')})
+        finally:
+            os.environ.pop('FGN_TRAIN_REPACK_IN_PLACE', None)
+    # Adagrad's first steps move a weight by ~lr whatever the size of its gradient, so a last-bit difference of a Winograd
+    # weight that flips one ReLU changes single elements by up to a step (5e-4 under roi_head); all but a handful agree
+    # to 1e-5, none is further apart than one step
+    for k in res['1'][0]:
+        d = (res['1'][0][k] - res['0'][0][k]).abs()
+        assert d.max().item() <= 5e-4 and (d > 1e-5).float().mean().item() <= 2e-3, (k, d.max().item())
+    for k in res['1'][1]:
+        a, b_ = res['1'][1][k], res['0'][1][k]
+        assert a.shape == b_.shape and (a - b_).abs().max().item() <= 5e-4, k
