@@ -90,7 +90,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 
