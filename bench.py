@@ -458,6 +458,8 @@ def main():
     prof_steps = [args.steps // 2] if args.steps >= 4 else []
     if os.environ.get('FGN_BENCH_NO_ISOLATED'):      # tuning aid: what the isolated instrumented step costs
         alone_steps = []
+    if os.environ.get('FGN_BENCH_NO_OVERLAPPED'):    # tuning aid: what the overlapped instrumented step costs
+        prof_steps = []
     prof = ops.ConvProfile().reserve(2 * len(prime) + 16)            # overlapped step
     prof_alone = ops.ConvProfile().reserve(2 * len(prime) + 16)      # isolated step -> roofline
     for ev in prof.pool + prof_alone.pool:
