@@ -64,6 +64,10 @@ struct ConvParams {
     // every further one from the counter of their share, so the last tiles of a launch go to whichever workgroups are
     // free first instead of to a fixed 1/3 of them.  nullptr: fixed tile order (tile, tile + grid, ...).
     int32_t* sched;
+    // Stream-K launch (conv_pw_streamk_kernel; 0 = off): tiles [0, sk_dp) are walked whole, the rest is shared out in
+    // ranges of sk_U K-tiles; `ws` holds the pieces (2 slabs of 64x64 floats per workgroup), `tickets` one word per
+    // remaining tile (the words of `sched` behind the scheduler's: FGN_SCHED_WORDS covers both).
+    int sk_U, sk_dp;
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
     // grouped GEMM (Winograd; 64x64 kernel, point-wise mode): rows [g*grp_rows, (g+1)*grp_rows) use the weight
     // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
@@ -77,7 +81,9 @@ struct ConvParams {
 #define CONV_DMA_STAGES 2
 #endif
 constexpr int BK = 32;
-constexpr int FGN_SCHED_WORDS = 8 * 16;
+constexpr int FGN_TILE_SCHED_WORDS = 8 * 16;         // conv_pw_persist2_kernel's counters
+constexpr int FGN_STREAMK_MAX_GRID = 1280;           // tickets of conv_pw_streamk_kernel: one per remaining tile < grid
+constexpr int FGN_SCHED_WORDS = FGN_TILE_SCHED_WORDS + FGN_STREAMK_MAX_GRID;
 constexpr int LDS_STRIDE = 36;  // floats
 
 // Diagnostic build only (-DCONV_CLOCK_STAMPS, tools/micro/gemm_clock.hip; the product library never defines it): one
@@ -429,6 +435,17 @@ __device__ __forceinline__ void lds_dma16(const i32x4& rs, unsigned lds_base, un
 // other for plain stores; a release fence instead would write back the whole L2).
 __device__ __forceinline__ void store_wt16(float* ptr, const f32x4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+// 16-byte load at agent scope (sc1): reads what store_wt16 of a workgroup on another XCD published, without the
+// acquire fence's invalidation of this XCD's L2 (which holds the operands every other workgroup is streaming).  The
+// caller waits with wait_loads() before it uses the value.
+__device__ __forceinline__ f32x4 load_agent16(const float* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
@@ -1108,6 +1125,276 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stream-K form of the persistent point-wise kernel (round 4): the work of a launch is tiles x K-tiles, and what
+// conv_pw_persist_kernel and the one-tile-per-workgroup kernel lose is the LAST round of whole tiles - 7.31 rounds take
+// 7.75 tile times on the AG-RPN GEMM, 408 tiles on 1024 resident slots leave 104 CUs with one workgroup and 152 with two.
+// Here the tiles beyond the last full round of the grid (all tiles, when there are fewer than workgroups) are shared out by
+// K-TILE: the workgroups of an XCD split the K-tiles of that XCD's remaining tiles into equal contiguous ranges of
+// U <= KT K-tiles (a range touches at most two tiles).  A workgroup first runs its range, then its whole tiles
+// (tile = blockIdx, + grid, ...) exactly as conv_pw_persist_kernel does.
+//   * A range that covers a tile from K-tile 0 to KT - 1 ends in the normal epilogue.
+//   * Any other range is a PIECE: the raw 64x64 partial sums go to the workgroup's private slab (ws + (2 * blockIdx +
+//     seg) * 4096 floats, seg = 0 if the workgroup's range starts inside this tile, 1 if it started in the tile before)
+//     with write-through stores, then one ticket per tile (tickets[remaining tile], zero before the launch and again
+//     after it).  The workgroup that draws the last ticket of a tile sums the pieces IN K ORDER (its own from LDS, the
+//     others from their slabs: a fixed order whoever comes last - deterministic results), applies the epilogue and
+//     stores.  Nobody waits for anybody: no workgroup depends on another one being resident.
+// Remaining tiles keep the XCD-contiguous numbering of the whole-tile walk: tile = dp_tiles + 8 * rl + xcd is the rl-th
+// remaining tile of XCD xcd's run, and only that XCD's workgroups (blockIdx & 7 == xcd) work on it, so its operands stay
+// in one L2.  Per output element the K order is that of the other kernels; the grouping of the partial sums differs
+// (pieces are summed after the fact), so results agree with conv_pw_persist_kernel to rounding, not bitwise.
+// LDS: the two stages + one flag word.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void conv_pw_streamk_kernel(const ConvParams p, const int total_tiles,
+                                                                 const int dp_tiles, const int U, const int dbg) {
+    constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
+    constexpr int A_LD = 2, B_LD = 2;
+    constexpr int STAGE = (BM + BN) * BK;          // floats
+    constexpr int PITCH = BN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
+    int grp_valid = p.grp_valid;
+    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+
+    const int col4 = t & 7, row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const int KT = p.K / BK;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    const int nq = total_tiles >> 3, nr = total_tiles & 7;
+    auto coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
+        int tile_m = bid / p.n_tiles_n;
+        int tile_n = bid - tile_m * p.n_tiles_n;
+        if (p.band_nt > 0) {
+            const int per_grp = p.band_mt * p.n_tiles_n;
+            const int grp = bid / per_grp;
+            int r = bid - grp * per_grp;
+            const int per_band = p.band_mt * p.band_nt;
+            const int band = r / per_band;
+            r -= band * per_band;
+            const int mi = r / p.band_nt;
+            tile_m = grp * p.band_mt + mi;
+            tile_n = band * p.band_nt + (r - mi * p.band_nt);
+        }
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        if (m0 >= M) return false;
+        if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
+        return true;
+    };
+
+    // this workgroup's share of the remaining tiles' K-tiles: units [u, u_end) of its XCD's run, unit = rl * KT + kt
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int rem_x = nq + (xcd < nr ? 1 : 0) - (dp_tiles >> 3);
+    const int units_x = rem_x * KT;
+    int u = min(li * U, units_x);
+    const int u_end = min(u + U, units_x);
+    int dp_cur = blockIdx.x;
+    struct Item { int m0, n0, k0, k1, rl; };            // rl < 0: a whole tile of the fixed walk
+    auto next_item = [&](Item& it) -> bool {
+        while (u < u_end) {
+            const int rl = u / KT, k0 = u - rl * KT, k1 = min(KT, k0 + (u_end - u));
+            u += k1 - k0;
+            if (coords(dp_tiles + rl * 8 + xcd, it.m0, it.n0)) {
+                it.k0 = k0; it.k1 = k1; it.rl = rl;
+                return true;
+            }
+        }
+        for (; dp_cur < dp_tiles; dp_cur += gridDim.x)
+            if (coords(dp_cur, it.m0, it.n0)) {
+                it.k0 = 0; it.k1 = KT; it.rl = -1;
+                dp_cur += gridDim.x;
+                return true;
+            }
+        return false;
+    };
+
+    unsigned a_voff[A_LD], b_voff[B_LD];
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+        }
+        int b0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+        if (p.grp_rows) b0 += (m0 / p.grp_rows) * p.grp_w_stride * 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * 32 * p.K * 4);
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+        const unsigned ko = (unsigned)(kt * BK * 4);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * 32 * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        const unsigned sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * 32 * 128, b_voff[i] + ko);
+    };
+
+    const int frag_row = lane & 31;
+    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+    float* const cbase = smem + STAGE;              // stage 1
+    volatile int* const s_last = reinterpret_cast<volatile int*>(smem + 2 * STAGE);
+    const int r16 = lane & 15, g16 = lane >> 4;
+    constexpr int C4 = BN / 4, RPP = 256 / C4;       // 16 float4 per row, 16 rows per pass
+    const int c4 = t % C4, rr = t / C4;
+
+    Item it;
+    if (!next_item(it)) return;
+    CLOCK_STAMP_BEGIN();
+    set_offsets(it.m0, it.n0);
+    issue_tile(it.k0, 0);
+
+    while (true) {
+        f32x4 acc4[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = it.k0; kt < it.k1; ++kt) {
+            if (kt + 1 < it.k1) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float4 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = r16 + 16 * i;
+                    const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
+                    af[i] = *reinterpret_cast<const float4*>(As + (row - frag_row) * BK + pc);
+                    bf[i] = *reinterpret_cast<const float4*>(Bs + (row - frag_row) * BK + pc);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        // both stages are free: the first K-tile of the next item goes to stage 0 while this one drains through stage 1
+        Item nx;
+        const bool more = next_item(nx);
+        if (more) {
+            set_offsets(nx.m0, nx.n0);
+            issue_tile(nx.k0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* cw = cbase + (wm * WM + 16 * i + 4 * g16) * PITCH + wn * WN + 16 * j + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
+            }
+        __syncthreads();
+        const int n = it.n0 + c4 * 4;
+        // rl0 / rl1: first and last workgroup (index within the XCD) with K-tiles of this remaining tile
+        const bool piece = it.rl >= 0 && (it.k0 != 0 || it.k1 != KT);
+        bool reduce = false;
+        int i0 = 0, i1 = 0;
+        if (piece && dbg == 1) {
+            // timing experiment (tuning knob 5): pieces are dropped - WRONG results, the cost of the exchange by difference
+        } else if (piece) {
+            float* slab = p.ws + ((size_t)blockIdx.x * 2 + ((li * U) / KT == it.rl ? 0 : 1)) * (BM * BN);
+#pragma unroll
+            for (int k = 0; k < BM / RPP; ++k) {
+                const int row = rr + RPP * k;
+                const float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
+                store_wt16(slab + row * BN + c4 * 4, f32x4{v.x, v.y, v.z, v.w});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's slab stores are acknowledged
+            __syncthreads();                                        // ... and every thread's
+            i0 = (it.rl * KT) / U;
+            i1 = (it.rl * KT + KT - 1) / U;
+            if (t == 0) {
+                int32_t* tk = p.tickets + (it.rl * 8 + xcd);
+                const int got = atomicAdd(tk, 1);
+                *s_last = got == i1 - i0;
+                if (got == i1 - i0) *tk = 0;                        // ready for the next launch
+            }
+            __syncthreads();
+            reduce = *s_last != 0;
+        }
+        if ((!piece || reduce) && n < p.Cout) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+            float4 res[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = it.m0 + rr + RPP * k;
+                res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.residual && m < M) res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
+            }
+            f32x4 sum[4];
+            if (reduce) {
+                // pieces in K order, whoever came last: the own one from LDS, the others from their slabs (agent-scope loads)
+                for (int i = i0; i <= i1; ++i) {
+                    f32x4 b[4];
+                    if (i == li) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const f32x4*>(cbase + (rr + RPP * k) * PITCH + c4 * 4);
+                    } else {
+                        const float* src = p.ws + ((size_t)(i * 8 + xcd) * 2 + ((i * U) / KT == it.rl ? 0 : 1)) * (BM * BN) + c4 * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) b[k] = load_agent16(src + (rr + RPP * k) * BN);
+                        wait_loads(b[0], b[1], b[2], b[3]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (i == i0) sum[k] = b[k];
+                        else sum[k] += b[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = rr + RPP * k;
+                const int m = it.m0 + row;
+                if (m >= M) continue;
+                float4 v;
+                if (reduce)
+                    v = make_float4(sum[k][0], sum[k][1], sum[k][2], sum[k][3]);
+                else
+                    v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+            }
+        }
+        if (!more) break;
+        it = nx;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLOCK_STAMP_END(blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent point-wise kernel, second form (round 4): any workgroup tile BM x BN out of wave tiles WM x WN
 // (NW = (BM/WM)*(BN/WN) waves), v_mfma_f32_16x16x4_f32 only, and NO LDS round trip in the epilogue.
 //   * The MFMA is issued with its operands SWAPPED (B fragment as "A", A fragment as "B"): the 16x16 result tile is then
@@ -1417,10 +1704,38 @@ static int persist_blocks() {
     return n / 8 * 8;
 }
 
+// Stream-K plan (conv_pw_streamk_kernel) for a point-wise launch of `tiles` 64x64 output tiles with KT K-tiles each.
+// g_sk_mode 0: never; 1: launches with more tiles than resident workgroups whose last round is at most g_sk_fill_pct
+// per cent full; 2: also launches of g_sk_min_tiles .. grid tiles (today's one-tile-per-workgroup launches); 3: every
+// eligible launch.  Tuning knobs 2..4 of fgn_conv2d_tune.
+static int g_sk_mode = getenv("FGN_STREAMK") ? atoi(getenv("FGN_STREAMK")) : 0;
+static int g_sk_fill_pct = getenv("FGN_STREAMK_FILL") ? atoi(getenv("FGN_STREAMK_FILL")) : 85;
+static int g_sk_debug = 0;
+static int g_sk_min_tiles = getenv("FGN_STREAMK_MIN_TILES") ? atoi(getenv("FGN_STREAMK_MIN_TILES")) : 320;
+static size_t streamk_ws_bytes() { return (size_t)persist_blocks() * 2 * 64 * 64 * sizeof(float); }
+static bool plan_streamk(long long tiles, int KT, int* dp_tiles, int* U) {
+    const int G = persist_blocks();
+    if (g_sk_mode <= 0 || G <= 0 || G > FGN_STREAMK_MAX_GRID || KT < 4 || tiles <= 0 || tiles >= (1ll << 30)) return false;
+    const int dp = (int)(tiles / G) * G;
+    const int rem = (int)(tiles - dp);
+    if (rem == 0) return false;
+    if (g_sk_mode < 3) {
+        if (rem * 100ll > (long long)g_sk_fill_pct * G) return false;       // a nearly full round gains nothing
+        if (dp == 0 && (g_sk_mode < 2 || tiles < g_sk_min_tiles)) return false;
+    }
+    const int nq = (int)(tiles >> 3), nr = (int)(tiles & 7);
+    const int rem_max = nq + (nr ? 1 : 0) - dp / 8;                         // remaining tiles of the longest XCD run
+    const int per = cdiv(rem_max * KT, G / 8);
+    *U = std::max(per, std::min(KT, 4));                                    // <= KT: rem_max <= G / 8
+    *dp_tiles = dp;
+    return true;
+}
+
 // split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
-static int plan_splits(long long M, int Cout, int KT, int tile_hint) {
+static int plan_splits(long long M, int Cout, int KT, int tile_hint, bool pw = false) {
     if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
     if (Cout % 4) return 1;
+    if (g_sk_mode == 3 && tile_hint == 0 && pw) return 1;   // Stream-K for every eligible 1x1 launch (tools/, tests)
     const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
     static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
     if (forced > 0) return std::max(1, std::min(forced, KT / 2));
@@ -1461,7 +1776,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     const dim3 grid(m_tiles * p.n_tiles_n, p.splits);
     set_band(p, BM, BN, m_tiles);
     // the in-launch reduce lives in the LDS-DMA kernel's 16-byte epilogue
-    if (p.in_scale || p.x_bytes == 0 || cin4 || (p.Cout & 3) != 0 || p.splits <= 1) p.tickets = nullptr;
+    if (p.in_scale || p.x_bytes == 0 || cin4 || (p.Cout & 3) != 0 || (p.splits <= 1 && p.sk_U == 0)) p.tickets = nullptr;
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static unsigned long long lds_ok[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>), &lds_ok[0]);
@@ -1480,7 +1795,14 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
         if (cin4)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
-        else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && persist_blocks() > 0 &&
+        else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && p.sk_U > 0 && p.ws && p.tickets) {
+            static unsigned long long sk_ok = 0ull;
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_streamk_kernel), &sk_ok);
+            if (attr != hipSuccess) return (int)attr;
+            const size_t sklds = (size_t)2 * (64 + 64) * BK * sizeof(float) + 16;
+            FGN_LAUNCH_TIMED(conv_pw_streamk_kernel, dim3(persist_blocks()), dim3(256), sklds, stream, p, (int)grid.x,
+                             p.sk_dp, p.sk_U, g_sk_debug);
+        } else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && persist_blocks() > 0 &&
                  (int)grid.x > persist_blocks()) {
             // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel)
             static unsigned long long pk_ok = 0ull;
@@ -1624,7 +1946,8 @@ static int pick_persist2(long long M, int Cout, int K, bool grouped, int grp_row
 // rule 24).  knob 0: tile code of conv_pw_persist2_kernel for every eligible point-wise launch (-1 = heuristic,
 // 0 = never); knob 1: its workgroups per CU (0 = the tile's default).  Returns the previous value.
 extern "C" int fgn_conv2d_tune(int knob, int value) {
-    int* k = knob == 0 ? &g_pw2_force : knob == 1 ? &g_pw2_wgs : nullptr;
+    int* k = knob == 0 ? &g_pw2_force : knob == 1 ? &g_pw2_wgs : knob == 2 ? &g_sk_mode : knob == 3 ? &g_sk_fill_pct :
+             knob == 4 ? &g_sk_min_tiles : knob == 5 ? &g_sk_debug : nullptr;
     if (!k) return FGN_ERR_ARG;
     const int prev = *k;
     *k = value;
@@ -1664,14 +1987,19 @@ extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, 
         mode = cin4 ? 2 : (KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1) ? 1 : 0;
     // conv_pw_persist2_kernel: tile code * 10 + 5 (the grouped Winograd GEMM asks with tile_hint 4)
     if (mode == 1 && (Cout & 3) == 0 && (tile_hint == 0 || tile_hint == 4) &&
-        (tile_hint == 4 || plan_splits(M, Cout, K / BK, tile_hint) == 1)) {
+        (tile_hint == 4 || plan_splits(M, Cout, K / BK, tile_hint, true) == 1)) {
         // (asked per group: M / 36 rows; F(2x2) launches have 16 groups and never reach the row threshold)
         const int code = pick_persist2(M, Cout, K, tile_hint == 4, tile_hint == 4 ? (int)(M / 36) : 0, has_residual != 0);
         if (code) return (code % 10) * 10 + 5;
     }
+    // Stream-K launches: mode 6 (conv_pw_streamk_kernel)
+    if (mode == 1 && tile == 4 && (Cout & 3) == 0 && tile_hint == 0 && plan_splits(M, Cout, K / BK, tile_hint, true) == 1) {
+        int dp = 0, U = 0;
+        if (plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), K / BK, &dp, &U)) return tile * 10 + 6;
+    }
     // point-wise launches with more 64x64 output tiles than resident workgroups run on conv_pw_persist_kernel
     if (mode == 1 && tile == 4 && (Cout & 3) == 0 && persist_blocks() > 0 &&
-        ((M + 63) / 64) * cdiv(Cout, 64) > persist_blocks() && plan_splits(M, Cout, K / BK, tile_hint) == 1)
+        ((M + 63) / 64) * cdiv(Cout, 64) > persist_blocks() && plan_splits(M, Cout, K / BK, tile_hint, true) == 1)
         mode = 4;
     return tile * 10 + mode;
 }
@@ -1684,16 +2012,27 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     const long long M = (long long)n_img * Ho * Wo;
     const int KT = cdiv(KH * KW * Cin, BK);
     if (tile_hint > 0 && tile_hint != 4) return 0;
-    const int s = plan_splits(M, Cout, KT, tile_hint);
-    return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
+    const bool pw = KH == 1 && KW == 1 && stride == 1 && pad == 0;
+    const int s = plan_splits(M, Cout, KT, tile_hint, pw);
+    if (s > 1) return (size_t)s * M * Cout * sizeof(float);
+    // Stream-K pieces (conv_pw_streamk_kernel).  Asked without the residual / input-scale flags of the launch, so a
+    // launch that ends up on another kernel may be given a workspace it does not use.
+    int dp = 0, U = 0;
+    if (tile_hint == 0 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && (Cout & 3) == 0 && Cin % BK == 0 &&
+        plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), KT, &dp, &U))
+        return streamk_ws_bytes();
+    return 0;
 }
 
 // int32 tickets the in-launch split-K reduce of this layer needs (one per 64x64 output tile; 0: the layer is not split)
 extern "C" int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                          int pad, int tile_hint) {
-    if (fgn_conv2d_workspace_bytes(n_img, H, W, Cin, Cout, KH, KW, stride, pad, tile_hint) == 0) return 0;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || n_img <= 0) return 0;
     const long long M = (long long)n_img * Ho * Wo;
+    if (tile_hint >= 100) tile_hint -= 100;
+    if (tile_hint > 0 && tile_hint != 4) return 0;
+    if (plan_splits(M, Cout, cdiv(KH * KW * Cin, BK), tile_hint, KH == 1 && KW == 1 && stride == 1 && pad == 0) <= 1) return 0;
     return (int)(((M + 63) / 64) * cdiv(Cout, 64));
 }
 
@@ -1712,6 +2051,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
     p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.tickets = splitk_tickets; p.sched = sched;
+    p.sk_U = 0; p.sk_dp = 0;
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -1745,7 +2085,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     tile = pick_tile(M, Cout, residual != nullptr, tile_hint);
     if (tile == 4 && splitk_ws) {
         const int KT = p.K / BK;
-        const int sp = plan_splits(M, Cout, KT, tile_hint);
+        const int sp = plan_splits(M, Cout, KT, tile_hint, KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1 && !in_scale);
         if (sp > 1 && splitk_ws_bytes >= (size_t)sp * M * Cout * sizeof(float)) {
             p.ws = splitk_ws;
             p.kt_per_split = cdiv(KT, sp);
@@ -1756,6 +2096,11 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
         a_img_div == 1 && (Cout & 3) == 0 && tile_hint == 0) {
         const int code = pick_persist2(M, Cout, p.K, false, 0, residual != nullptr);
         if (code) return launch_persist2(code, p, (int)M, stream);
+        int dp = 0, U = 0;
+        if (tile == 4 && splitk_ws && sched && splitk_ws_bytes >= streamk_ws_bytes() &&
+            plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), p.K / BK, &dp, &U)) {
+            p.ws = splitk_ws; p.tickets = sched + FGN_TILE_SCHED_WORDS; p.sk_U = U; p.sk_dp = dp;
+        }
     }
     switch (tile) {
         case 1: return launch_cfg<128, 128, 64, 64, 2>(p, (int)M, cin4, stream);
@@ -1789,6 +2134,7 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
         ConvParams& p = ps[i];
         p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
         p.in_scale = nullptr; p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = nullptr;
+        p.sk_U = 0; p.sk_dp = 0;
         p.n_img = ns[i]; p.H = Hs[i]; p.W = Ws[i]; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
         p.stride = stride; p.pad = pad; p.a_img_div = 1; p.relu = relu;
         p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -1838,9 +2184,16 @@ extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) /
 // int32 words of the tile scheduler workspace (`sched` of fgn_conv2d_nhwc_f32 / fgn_winograd_gemm_f32)
 extern "C" int fgn_gemm_sched_words(void) { return FGN_SCHED_WORDS; }
 
+// bytes of the Stream-K workspace `ws` of fgn_winograd_gemm_f32 for this shape (0: the launch does not use one)
+extern "C" size_t fgn_winograd_gemm_workspace_bytes(int t_pad, int Cin, int Cout, int n_groups) {
+    if (t_pad <= 0 || t_pad % 64 || Cin % BK || (Cout & 3)) return 0;
+    int dp = 0, U = 0;
+    return plan_streamk((long long)n_groups * (t_pad / 64) * cdiv(Cout, 64), Cin / BK, &dp, &U) ? streamk_ws_bytes() : 0;
+}
+
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                                      int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
-                                     int32_t* sched, hipStream_t stream) {
+                                     int32_t* sched, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (!V || !U || !Mo) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
@@ -1852,6 +2205,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
     p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = sched;
+    p.sk_U = 0; p.sk_dp = 0;
     p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = Cin / BK;
@@ -1862,6 +2216,11 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     {
         const int code = pick_persist2(rows, Cout, p.K, true, t_pad);
         if (code) return launch_persist2(code, p, (int)rows, stream);
+        int dp = 0, Uk = 0;
+        if (ws && sched && ws_bytes >= streamk_ws_bytes() &&
+            plan_streamk((rows / 64) * cdiv(Cout, 64), p.K / BK, &dp, &Uk)) {
+            p.ws = ws; p.tickets = sched + FGN_TILE_SCHED_WORDS; p.sk_U = Uk; p.sk_dp = dp;
+        }
     }
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

@@ -26,7 +26,8 @@ SIGNATURES = {
     'fgn_conv2d_splitk_tickets': (_i, [_i] * 10),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_t_pad': (_i, [_i]),
-    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, C.c_size_t, _p]),
+    'fgn_winograd_gemm_workspace_bytes': (C.c_size_t, [_i, _i, _i, _i]),
     'fgn_gemm_sched_words': (_i, []),
     'fgn_winograd4_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -90,7 +91,7 @@ SIGNATURES = {
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 

@@ -151,6 +151,12 @@ def _sched(device):
     return zeros((_lib.load().fgn_gemm_sched_words(),), device, torch.int32)
 
 
+def _gemm_ws(L, t_pad, cin, cout, groups, device):
+    """Stream-K workspace of a grouped Winograd GEMM launch (None when the launch does not take that kernel)."""
+    n = L.fgn_winograd_gemm_workspace_bytes(t_pad, cin, cout, groups)
+    return (torch.empty(n, device=device, dtype=torch.uint8), n) if n and GEMM_SCHED else (None, 0)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -282,7 +288,7 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
         layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _ptr(tickets),
-        _ptr(_sched(x.device) if layer.kh == 1 and layer.stride == 1 and not ws_bytes else None), _stream())
+        _ptr(_sched(x.device) if layer.kh == 1 and layer.kw == 1 and layer.stride == 1 else None), _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         kid = L.fgn_conv2d_kernel_id(n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw, layer.stride,
@@ -491,8 +497,10 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
+    gws, gws_n = _gemm_ws(L, t_pad, cin, layer.cout, G, x.device)
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, G, _ptr(_sched(x.device)), st), 'fgn_winograd_gemm_f32')
+                                       layer.cout, layer.cout_pad, G, _ptr(_sched(x.device)), _ptr(gws), gws_n, st),
+               'fgn_winograd_gemm_f32')
     if ev is not None:
         ev.append(prof.arm())
     _lib.check(f_out(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W, layer.cout, t_pad,
@@ -561,8 +569,9 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
+    gws, gws_n = _gemm_ws(L, t_pad, cin, cout, G, dev)
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
-                                       G, _ptr(_sched(dev)), st), 'fgn_winograd_gemm_f32')
+                                       G, _ptr(_sched(dev)), _ptr(gws), gws_n, st), 'fgn_winograd_gemm_f32')
     if prof is not None:
         ev.append(prof.arm())
     if pair:

@@ -62,7 +62,12 @@ int fgn_profile_next_launch(void* start_event, void* stop_event);
  *   counter instead of walking a fixed order, so the last tiles of a launch go to whichever workgroups are free.
  *   Used by 1x1 / stride 1 launches (and fgn_winograd_gemm_f32) that run on that kernel, ignored otherwise; one
  *   workspace per launch IN FLIGHT (launches that may overlap on the GPU must not share one).  NULL = fixed order.
- *   Results do not depend on it (each output tile is computed by one workgroup either way). */
+ *   Results do not depend on it (each output tile is computed by one workgroup either way).
+ *   Stream-K (conv_pw_streamk_kernel, tuning knob 2 of fgn_conv2d_tune / FGN_STREAMK): a 1x1 / stride 1 launch whose
+ *   64x64 output tiles do not fill a whole number of rounds of the resident workgroups shares the K loop of the tiles of
+ *   its last round among ALL workgroups; the partial tiles travel through `splitk_ws` (fgn_conv2d_workspace_bytes covers
+ *   it), the tickets live in the words of `sched` behind the scheduler's.  Needs both; pieces are summed in K order
+ *   whoever finishes last (bit-reproducible), results agree with the whole-tile kernels to rounding. */
 int fgn_gemm_sched_words(void);
 size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                   int pad, int tile_hint);
@@ -72,7 +77,10 @@ int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pa
                          int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint);
 /* Tuning knob (no reference counterpart; tools/ only): knob 0 = tile code of conv_pw_persist2_kernel forced for every
  * eligible point-wise launch (-1 heuristic, 0 never, 1 128x128, 2 64x128, 3 128x64, 4 64x64, 5 128x128 on 8 waves, 6 64x64 on 8 waves, 7 64x128 on 8 waves, 8 32x64; + 10 x LDS stages (3, 4) for tiles 2, 4, 6, 7, 8),
- * knob 1 = its workgroups per CU (0 = default).  Returns the previous value, FGN_ERR_ARG for an unknown knob. */
+ * knob 1 = its workgroups per CU (0 = default); knob 2 = Stream-K mode (0 never, 1 launches of more tiles than resident
+ * workgroups, 2 also smaller launches of at least knob-4 tiles, 3 every eligible launch), knob 3 = largest fill of the last
+ * round in per cent that still takes Stream-K, knob 4 = smallest tile count for mode 2.  Returns the previous value,
+ * FGN_ERR_ARG for an unknown knob. */
 int fgn_conv2d_tune(int knob, int value);
 int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                         const float* shift, const float* residual, const float* in_scale,
@@ -108,7 +116,9 @@ int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, cons
 int fgn_winograd_t_pad(int tiles_total);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                           int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, int32_t* sched,
-                          void* stream);
+                          float* ws, size_t ws_bytes, void* stream);
+/* ws / ws_bytes: optional Stream-K workspace (see fgn_conv2d_nhwc_f32's splitk_ws); size from this query, 0 = none. */
+size_t fgn_winograd_gemm_workspace_bytes(int t_pad, int Cin, int Cout, int n_groups);
 int fgn_winograd_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                             int H, int W, int C, int t_pad, int relu, void* stream);
 /* F(4x4,3x3) form of the same convolutions (the default): 36 tile positions (n_groups = 36 in

@@ -295,7 +295,7 @@ def test_persist2_grouped_gemm_all_tiles_and_the_tile_scheduler(code, n, tiles, 
         with _pw2(force):
             rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
                                          n, tiles, t_pad, cin, cout, U.shape[1], 36,
-                                         None if sched is None else sched.data_ptr(), st)
+                                         None if sched is None else sched.data_ptr(), None, 0, st)
         assert rc == 0
         torch.cuda.synchronize()
         if sched is not None:
@@ -323,3 +323,110 @@ def test_persist2_grouped_gemm_all_tiles_and_the_tile_scheduler(code, n, tiles, 
     part = run(code, cnt)
     v2 = (n - 1) * tiles
     assert torch.equal(part[:, :v2], got[:, :v2]) and float((part[:, v2:] + 7.0).abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# conv_pw_streamk_kernel (round 4): the K loop of the last round's tiles shared among all workgroups
+# ------------------------------------------------------------------------------------------------
+class _streamk:
+    """``with _streamk(mode):`` sets the Stream-K mode (fgn_conv2d_tune knob 2; 3 = every eligible launch)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from fgn_amd import lib
+        L = lib.load()
+        self.prev = L.fgn_conv2d_tune(2, self.mode)
+        self.prev0 = L.fgn_conv2d_tune(0, 0)
+
+    def __exit__(self, *a):
+        from fgn_amd import lib
+        L = lib.load()
+        L.fgn_conv2d_tune(2, self.prev)
+        L.fgn_conv2d_tune(0, self.prev0)
+
+
+@pytest.mark.parametrize('rows,cin,cout,res,relu', [
+    (64 * 400 + 5, 128, 64, True, True),        # 401 tiles x 4 K-tiles: ranges of 4 = whole tiles only
+    (6504, 1024, 256, False, True),             # layer3 conv1 of a cfg3 episode: 408 tiles x 32 K-tiles, ranges of 13
+    (4900, 512, 1024, True, True),              # 1232 tiles: one whole round + 208 tiles in pieces, residual epilogue
+    (130, 1024, 512, True, False),              # 24 tiles: minimum range (4 K-tiles), most workgroups idle
+    (64 * 9 + 1, 256, 4, False, False),         # Cout inside one 16-byte vector, 10 tiles
+    (14700, 1024, 1024, False, True),           # 3680 tiles = 3 rounds + 608
+])
+def test_stream_k_pointwise_matches_fp64_and_the_whole_tile_kernels(rows, cin, cout, res, relu):
+    from fgn_amd import ops, lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(rows + cin + cout)
+    x = torch.randn(rows, cin, 1, 1, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    r = torch.randn(rows, cout, 1, 1, generator=g) if res else None
+    ref = _ref(x, wt, None, bn, 1, 0, r, relu)
+    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
+    xc, rc = _nhwc(x).cuda(), None if r is None else _nhwc(r).cuda()
+    with _streamk(0):
+        old = ops.conv2d(xc, layer, residual=rc).clone()
+    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
+    keep, ops._sched = ops._sched, (lambda dev: sched)
+    try:
+        with _streamk(3):
+            assert L.fgn_conv2d_kernel_id(rows, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, int(res), 0) % 10 == 6
+            got = ops.conv2d(xc, layer, residual=rc).clone()
+            torch.cuda.synchronize()
+            assert int(sched.abs().max()) == 0            # every ticket is back at zero
+            for _ in range(3):                             # the order of arrival changes, the sums do not
+                assert torch.equal(ops.conv2d(xc, layer, residual=rc), got)
+            cnt = torch.tensor([rows - 77], dtype=torch.int32, device='cuda')
+            part = torch.full((rows, 1, 1, cout), -7.0, device='cuda')
+            ops.conv2d(xc, layer, residual=rc, n_img_dev=cnt, out=part)
+            torch.cuda.synchronize()
+            assert int(sched.abs().max()) == 0
+    finally:
+        ops._sched = keep
+    scale = ref.abs().max().item() + 1e-6
+    assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * scale + 1e-6
+    assert (got - old).abs().max().item() <= 4e-6 * scale          # pieces are summed after the fact: rounding only
+    assert torch.equal(part[:rows - 77], got[:rows - 77]) and float((part[rows - 77:] + 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 1024, 128), (5, 4, 512, 64), (100, 4, 256, 256), (300, 4, 128, 512)])
+def test_stream_k_grouped_gemm(n, tiles, cin, cout):
+    """The grouped Winograd GEMM on conv_pw_streamk_kernel: banded tile order, groups cut at their valid rows, a device-side
+    item count that empties some of the remaining tiles."""
+    from fgn_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(n * tiles + cin)
+    t_pad = L.fgn_winograd_t_pad(n * tiles)
+    V = torch.randn(36, t_pad, cin, generator=g).cuda()
+    U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) / cin ** 0.5).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
+
+    def run(mode, cnt=None):
+        Mo = torch.full((36, t_pad, cout), -7.0, device='cuda')
+        with _streamk(mode):
+            nb = L.fgn_winograd_gemm_workspace_bytes(t_pad, cin, cout, 36)
+            assert (nb > 0) == (mode == 3)
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device='cuda')
+            rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
+                                         n, tiles, t_pad, cin, cout, U.shape[1], 36, sched.data_ptr(), ws.data_ptr(), nb, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(sched.abs().max()) == 0
+        return Mo
+    old, got = run(0), run(3)
+    valid = n * tiles
+    ref = torch.einsum('gtc,gnc->gtn', V[:, :valid].double(), U[:, :cout].double()).float()
+    assert (got[:, :valid] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (got[:, :valid] - old[:, :valid]).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    for _ in range(3):
+        assert torch.equal(run(3), got)
+    cnt = torch.tensor([n - 1], dtype=torch.int32, device='cuda')
+    part = run(3, cnt)
+    v2 = (n - 1) * tiles
+    assert torch.equal(part[:, :v2], got[:, :v2])
+    lim = (v2 + 63) // 64 * 64                  # rows of a started 64-row tile are written, nothing beyond
+    assert float((part[:, lim:] + 7.0).abs().max()) == 0.0 if lim < t_pad else True

@@ -21,7 +21,7 @@ for name, n, tiles, cin, cout in (('agrpn', 3, 273, 1024, 1024), ('sh300', 300, 
     U = (torch.randn(G, (cout + 127) // 128 * 128, cin, generator=g) * 0.03).cuda()
     Mo = torch.empty(G, t_pad, cout, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
-    fn = lambda: lib.check(L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], G, None, st), 'g')
+    fn = lambda: lib.check(L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], G, None, None, 0, st), 'g')
     ms = t(fn)
     fl = 2.0 * G * n * tiles * cin * cout
     print(f'wino gemm {name:6s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TF/s', flush=True)

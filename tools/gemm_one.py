@@ -16,7 +16,7 @@ if name in W:
     U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) * 0.03).cuda()
     Mo = torch.empty(36, t_pad, cout, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
-    fn = lambda: L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], 36, None, st)
+    fn = lambda: L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout, U.shape[1], 36, None, None, 0, st)
     flop = 2.0 * 36 * n * tiles * cin * cout
 else:
     cin, cout, res = {'relq': (1024, 1024, False), 'conv3': (512, 1024, True)}[name]

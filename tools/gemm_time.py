@@ -29,7 +29,7 @@ for name, (n, tiles, cin, cout) in {'wino agrpn': (3, 273, 1024, 1024), 'wino sh
     Mo = torch.empty(36, t_pad, cout, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
     us = timeit(lambda: L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout,
-                                                U.shape[1], 36, None, st))
+                                                U.shape[1], 36, None, None, 0, st))
     flop = 2.0 * 36 * n * tiles * cin * cout
     print(f'{name:14s} {us:8.1f} us  {flop / us / 1e6:6.1f} TF/s', flush=True)
 for name, (rows, cin, cout, res) in {'relq 14700x1024>1024': (14700, 1024, 1024, False), 'sh conv3 14700x512>1024': (14700, 512, 1024, True),

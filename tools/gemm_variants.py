@@ -1,6 +1,7 @@
 """Interleaved A/B of the point-wise GEMM kernels on the GEMM-shaped launches of a cfg3 episode (one process, rounds of
 all variants per shape, medians: cdna_hip_programming.md 5.4 rule 24).  Variant 0 = the dispatcher's round-3 choice
-(conv_pw_persist_kernel / conv_igemm_dma_kernel), 1..5 = conv_pw_persist2_kernel tile codes (fgn_conv2d_tune knob 0).
+(conv_pw_persist_kernel / conv_igemm_dma_kernel), 1..8 (+10 x stages) = conv_pw_persist2_kernel tile codes (fgn_conv2d_tune
+knob 0), 1001..1003 = conv_pw_streamk_kernel in mode 1..3 (knob 2).
 Every variant's output is compared with variant 0's.  usage: gemm_variants.py [rounds] [reps] [variants, e.g. 0,1,5]"""
 import json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +16,14 @@ SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'    # (ops.conv2d reads the 
 _SCH = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda') if SCHED else None
 ops._sched = lambda dev: _SCH          # one workspace for all (serialised) launches of this tool: no fill kernel per call
 _BASE = {0: 'r3', 1: '128x128', 2: '64x128', 3: '128x64', 4: '64x64', 5: '128x128w8', 6: '64x64w8', 7: '64x128w8', 8: '32x64'}
-NAMES = {v: _BASE[v % 10] + (f's{v // 10}' if v >= 10 else '') for v in variants}   # code = tile + 10 * LDS stages
+NAMES = {v: f'sk{v - 1000}' if v >= 1000 else _BASE[v % 10] + (f's{v // 10}' if v >= 10 else '') for v in variants}
+_WS = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')       # Stream-K pieces (>= fgn_winograd_gemm_workspace_bytes)
+
+
+def set_variant(v):
+    L.fgn_conv2d_tune(0, 0 if v >= 1000 else v)
+    L.fgn_conv2d_tune(2, (v - 1000) % 10 if v >= 1000 else 0)
+    L.fgn_conv2d_tune(5, (v - 1000) // 10 if v >= 1000 else 0)      # 1013: pieces dropped (timing only)
 
 
 def time_once(fn):
@@ -30,7 +38,7 @@ def time_once(fn):
 def run_shape(name, fn, out, flop):
     res, ref = {}, None
     for v in variants:
-        L.fgn_conv2d_tune(0, v)
+        set_variant(v)
         out.zero_()
         fn(); torch.cuda.synchronize()
         if ref is None:
@@ -42,9 +50,10 @@ def run_shape(name, fn, out, flop):
     times = {v: [] for v in variants}
     for _ in range(rounds):
         for v in variants:
-            L.fgn_conv2d_tune(0, v)
+            set_variant(v)
             times[v].append(time_once(fn))
     L.fgn_conv2d_tune(0, -1)
+    L.fgn_conv2d_tune(2, 0)
     line = f'{name:30s}'
     for v in variants:
         med, mn = statistics.median(times[v]), min(times[v])
@@ -68,7 +77,7 @@ for name, (n, tiles, cin, cout) in {'wino agrpn 3x273 1024>1024': (3, 273, 1024,
     st = torch.cuda.current_stream().cuda_stream
     sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda') if SCHED else None
     fn = lambda: L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None, n, tiles, t_pad, cin, cout,
-                                         U.shape[1], 36, None if sched is None else sched.data_ptr(), st)
+                                         U.shape[1], 36, None if sched is None else sched.data_ptr(), _WS.data_ptr(), _WS.numel(), st)
     table[name] = run_shape(name, fn, Mo, 2.0 * 36 * n * tiles * cin * cout)
     del V, U, Mo
 for name, (rows, cin, cout, res) in {'relq 14700x1024>1024': (14700, 1024, 1024, False), 'sh conv3 14700x512>1024 +res': (14700, 512, 1024, True),

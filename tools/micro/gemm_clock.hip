@@ -29,6 +29,7 @@ static float* dev_random(size_t n, float scale, unsigned seed) {
 
 struct Shape { const char* name; bool grouped; int n, tiles, rows, cin, cout; };
 
+static int n_variants = 1;
 static int run(const Shape& sh, int variant, double seconds) {
     hipStream_t st; CK(hipStreamCreate(&st));
     float *A = nullptr, *W = nullptr, *Y = nullptr;
@@ -49,16 +50,22 @@ static int run(const Shape& sh, int variant, double seconds) {
         flop = 2.0 * sh.rows * sh.cin * sh.cout;
     }
     if (!A || !W) return 1;
-    fgn_conv2d_tune(0, variant);
+    // 1001..1003: conv_pw_streamk_kernel mode 1..3; 1013: mode 3 with the pieces dropped (timing only, wrong results)
+    fgn_conv2d_tune(0, variant >= 1000 ? 0 : variant);
+    fgn_conv2d_tune(2, variant >= 1000 ? (variant - 1000) % 10 : 0);
+    fgn_conv2d_tune(5, variant >= 1000 ? (variant - 1000) / 10 : 0);
+    float* skws = nullptr;
+    const size_t skws_bytes = (size_t)64 << 20;
+    CK(hipMalloc(&skws, skws_bytes));
     int32_t* sched = nullptr;
     if (getenv("GEMM_CLOCK_SCHED") ? atoi(getenv("GEMM_CLOCK_SCHED")) : 1) {
         CK(hipMalloc(&sched, fgn_gemm_sched_words() * 4));
         CK(hipMemset(sched, 0, fgn_gemm_sched_words() * 4));
     }
     auto launch = [&]() -> int {
-        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, sched, st)
+        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, sched, skws, skws_bytes, st)
                           : fgn_conv2d_nhwc_f32(A, W, Y, nullptr, nullptr, nullptr, nullptr, nullptr, sh.rows, 1, 1, sh.cin, sh.cout,
-                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, nullptr, 0, nullptr, sched, st);
+                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, skws, skws_bytes, nullptr, sched, st);
     };
     for (int i = 0; i < 3; ++i) rc |= launch();
     CK(hipStreamSynchronize(st));
@@ -108,6 +115,30 @@ static int run(const Shape& sh, int variant, double seconds) {
         for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu:%02llx", raw[b * 6 + 4] & 0xf, (raw[b * 6 + 5] >> 8) & 0xff);
         fprintf(stderr, "\n");
     }
+    if (getenv("GEMM_CLOCK_TAIL_BLOCKS")) {
+        // the workgroups that own one output tile more than the others (blocks < R of a fixed walk): on how many CUs do
+        // they sit, and how much longer is their span?  R: comma-separated, one per shape, 0 = skip
+        static int shape_no = 0;
+        std::vector<int> rs;
+        for (const char* c = getenv("GEMM_CLOCK_TAIL_BLOCKS"); *c;) { rs.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; }
+        const int R = rs.empty() ? 0 : rs[std::min<size_t>(shape_no / (int)std::max<size_t>(1, (size_t)n_variants), rs.size() - 1)];
+        ++shape_no;
+        if (R > 0) {
+            std::vector<unsigned> tail_cu; std::vector<double> s_tail, s_rest;
+            for (int b = 0; b < 16384; ++b) {
+                const unsigned long long t0s = raw[b * 6], t1s = raw[b * 6 + 1];
+                if (t1s <= t0s) continue;
+                const unsigned key = (((unsigned)raw[b * 6 + 4] & 0xf) << 8) | (((unsigned)raw[b * 6 + 5] >> 8) & 0xff);
+                if (b < R) { tail_cu.push_back(key); s_tail.push_back((double)(t1s - t0s)); } else s_rest.push_back((double)(t1s - t0s));
+            }
+            std::sort(tail_cu.begin(), tail_cu.end());
+            int th[8] = {0}; size_t ncu = 0;
+            for (size_t i = 0; i < tail_cu.size();) { size_t j = i; while (j < tail_cu.size() && tail_cu[j] == tail_cu[i]) ++j; th[std::min<size_t>(j - i, 7)]++; ++ncu; i = j; }
+            fprintf(stderr, "%s v%d: blocks < %d sit on %zu CUs (per CU: 1:%d 2:%d 3:%d 4:%d 5+:%d); span p50 %0.f cycles vs %0.f of the other %zu blocks\n",
+                    sh.name, variant, R, ncu, th[1], th[2], th[3], th[4], th[5] + th[6] + th[7], s_tail.empty() ? 0. : q(s_tail, 0.5),
+                    s_rest.empty() ? 0. : q(s_rest, 0.5), s_rest.size());
+        }
+    }
     // workgroups per CU (as placed in the last launch), and the median span of a workgroup by how crowded its CU was
     std::vector<unsigned> cus; for (auto& w : ws) cus.push_back(w.cu);
     std::sort(cus.begin(), cus.end());
@@ -147,6 +178,7 @@ int main(int argc, char** argv) {
         {"relq 14700x1024>1024", false, 0, 0, 14700, 1024, 1024},
         {"sh conv1 14700x1024>512 (r3: 128x128 DMA kernel)", false, 0, 0, 14700, 1024, 512},
     };
+    n_variants = (int)variants.size();
     int rc = 0;
     for (const auto& sh : shapes)
         for (int v : variants) rc |= run(sh, v, seconds);
