@@ -45,6 +45,8 @@ def kernel_name(kid: int) -> str:
                                                                3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4),
                                                                5: (128, 128, 32, 64, 4), 6: (64, 64, 32, 16, 8),
                                                                7: (64, 128, 32, 32, 6), 8: (32, 64, 16, 32, 4)}[kid // 10]
+    if mode == 6:
+        return 'conv_pw_streamk_kernel'
     bm, bn, wm, wn, mw = _TILES[kid // 10]
     if mode == 4:      # template argument = MFMA shape (16x16x4 unless the tuning knob FGN_PW_M16=0 selects 32x32x2)
         return 'conv_pw_persist_kernel<%s>' % ('false' if os.environ.get('FGN_PW_M16') == '0' else 'true')
@@ -139,10 +141,13 @@ class ConvProfile(list):
         return pair
 
 
-# Tile scheduler workspace of the persistent point-wise GEMM (include/fgn_hip.h, `sched`): 128 zero int32 per launch,
-# returned to zero by the launch.  Taken from the episode's zero arena (one private range per launch, so launches in
-# flight never share one); without an open arena a fresh torch.zeros (tests, tools).  FGN_GEMM_SCHED=0: fixed tile order.
-GEMM_SCHED = os.environ.get('FGN_GEMM_SCHED', '1') != '0'
+# Workspace of the opt-in point-wise GEMM kernels (include/fgn_hip.h, `sched`: the tile scheduler's counters of
+# conv_pw_persist2_kernel and the tickets of conv_pw_streamk_kernel): fgn_gemm_sched_words() zero int32 per launch, returned
+# to zero by the launch.  Taken from the episode's zero arena (one private range per launch, so launches in flight never
+# share one); without an open arena a fresh torch.zeros (tests, tools).  The default kernels use neither, so no words are
+# taken unless one of those kernels is switched on (FGN_PW2 / FGN_PW2_AUTO / FGN_STREAMK) or FGN_GEMM_SCHED=1 asks.
+_OPT_IN_GEMM = any(os.environ.get(k, '0') not in ('', '0', '-1') for k in ('FGN_PW2', 'FGN_PW2_AUTO', 'FGN_STREAMK'))
+GEMM_SCHED = os.environ.get('FGN_GEMM_SCHED', '1' if _OPT_IN_GEMM else '0') != '0'
 
 
 def _sched(device):
