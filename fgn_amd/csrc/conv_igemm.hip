@@ -116,6 +116,17 @@ __device__ unsigned long long g_clock_stamps[16384 * 6];
 #define CLOCK_STAMP_BEGIN() do { } while (0)
 #define CLOCK_STAMP_END(slot) do { } while (0)
 #endif
+// Diagnostic build only (-DCONV_PW_EXP=<bits>, tools/micro/gemm_clock.hip; WRONG results, timing only): take one
+// ingredient at a time out of the K loop of conv_pw_persist_kernel to see what its saturated rate is made of.
+// 1: no LDS-DMA inside the K loop (the loop re-reads the tile's first K-tile), 2: no s_barrier in the K loop,
+// 4: the wait before the barrier does not wait for the DMA (lgkmcnt only), 8: operand fragments are read from LDS once
+// per output tile instead of once per 16-deep step, 16: the epilogue does not store to global memory, 32: the first
+// K-tile of the next output tile is not fetched, 64: no epilogue at all.
+#ifdef CONV_PW_EXP
+#define PW_EXP(bit) ((CONV_PW_EXP) & (bit))
+#else
+#define PW_EXP(bit) 0
+#endif
 
 // Per-thread staging state, fixed for the whole K loop: for each A row this thread loads, the
 // element offset of the (ky=0,kx=0) tap and a bit mask of the filter taps that fall inside the
@@ -1011,11 +1022,24 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
+        float4 af_x[2][2], bf_x[2][2];                  // PW_EXP(8) only
+        if (PW_EXP(8)) {
+            const int r16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = r16 + 16 * i;
+                    const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
+                    af_x[kk][i] = *reinterpret_cast<const float4*>(rd_a + (row - frag_row) * BK + pc);
+                    bf_x[kk][i] = *reinterpret_cast<const float4*>(rd_b + (row - frag_row) * BK + pc);
+                }
+        }
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            if (kt + 1 < KT && !PW_EXP(1)) issue_tile(kt + 1, cur ^ 1);
             asm volatile("" ::: "memory");
-            const float* As = rd_a + cur * STAGE;
-            const float* Bs = rd_b + cur * STAGE;
+            const float* As = rd_a + (PW_EXP(1) ? 0 : cur) * STAGE;
+            const float* Bs = rd_b + (PW_EXP(1) ? 0 : cur) * STAGE;
             if (M16) {
                 const int r16 = lane & 15, g16 = lane >> 4;
 #pragma unroll
@@ -1025,6 +1049,11 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
                     for (int i = 0; i < 2; ++i) {
                         const int row = r16 + 16 * i;                       // row within the wave's 32
                         const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
+                        if (PW_EXP(8)) {
+                            af[i] = af_x[kk][i]; bf[i] = bf_x[kk][i];
+                            asm volatile("" : "+v"(af[i].x), "+v"(bf[i].x));      // keep the loop's MFMAs in the loop
+                            continue;
+                        }
                         af[i] = *reinterpret_cast<const float4*>(As + (row - frag_row) * BK + pc);
                         bf[i] = *reinterpret_cast<const float4*>(Bs + (row - frag_row) * BK + pc);
                     }
@@ -1057,8 +1086,9 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
             }
             }
             // see conv_igemm_dma_kernel: reads of stage `cur` must have returned before the barrier is signalled
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (PW_EXP(4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (!PW_EXP(2)) __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
         // both stages are free now.  Next output tile: its first K-tile goes to stage 0 while the epilogue below
@@ -1068,7 +1098,16 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         const int next = next_active(tile + gridDim.x, nm0, nn0);
         if (next >= 0) {
             set_offsets(nm0, nn0);
-            issue_tile(0, 0);
+            if (!PW_EXP(32)) issue_tile(0, 0);
+        }
+        if (PW_EXP(64)) {           // no epilogue at all: the accumulators are only kept alive
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc4[i][j]));
+            if (next < 0) break;
+            tile = next; m0 = nm0; n0 = nn0;
+            continue;
         }
         if (M16) {
             // 16x16 C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -1113,7 +1152,8 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
                     if (p.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+                    if (PW_EXP(16)) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    else *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
                 }
             }
         }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -177,10 +178,13 @@ int main(int argc, char** argv) {
         {"wino sh300 36x(300x4) 512>512", true, 300, 4, 0, 512, 512},
         {"relq 14700x1024>1024", false, 0, 0, 14700, 1024, 1024},
         {"sh conv1 14700x1024>512 (r3: 128x128 DMA kernel)", false, 0, 0, 14700, 1024, 512},
+        {"perfect 16384x1024>1024 (4 whole rounds)", false, 0, 0, 16384, 1024, 1024},
     };
     n_variants = (int)variants.size();
+    const char* only = getenv("GEMM_CLOCK_SHAPES");        // substring of the shape names to run
     int rc = 0;
     for (const auto& sh : shapes)
-        for (int v : variants) rc |= run(sh, v, seconds);
+        if (!only || strstr(sh.name, only))
+            for (int v : variants) rc |= run(sh, v, seconds);
     return rc;
 }
