@@ -441,6 +441,18 @@ __device__ __forceinline__ void lds_dma16(const i32x4& rs, unsigned lds_base, un
         : "v"(voff), "s"(lds_base), "s"(rs)
         : "memory");
 }
+// The same with the K offset in the instruction's scalar offset and M0 left as written (no save / restore: nothing else
+// in these kernels reads M0): per K-tile no vector arithmetic at all - `voff` is the tile's row offset (or the
+// out-of-range constant: the range check looks at voff alone) and `soff` the byte offset of the K-tile.
+__device__ __forceinline__ void lds_dma16_s(const i32x4& rs, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %2, %3 offen lds"
+        :
+        : "v"(voff), "s"(lds_base), "s"(rs), "s"(soff)
+        : "memory", "m0");
+}
 // 16-byte store that writes through the XCD's L2 to device-coherent memory (sc1 = agent scope): how a workgroup publishes
 // a split-K partial tile that a workgroup on another XCD will read (the L2s of the eight XCDs are not coherent with each
 // other for plain stores; a release fence instead would write back the whole L2).
@@ -628,6 +640,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const bool ok = (a_taps[i] >> tap) & 1ull;
+            if (PW) {       // one tap, a_off >= 0: the K-tile's offset rides in the scalar offset (the range check sees voff alone)
+                lds_dma16_s(x_rs, sa + i * 32 * 128, ok ? (unsigned)a_off[i] : OOB, (unsigned)tap_off);
+                continue;
+            }
             const unsigned voff = ok ? (unsigned)(a_off[i] + tap_off) : OOB;   // OOB lanes are zero-filled
             lds_dma16(x_rs, sa + i * 32 * 128, voff);
         }
@@ -635,7 +651,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
         const unsigned bko = (unsigned)(kt * BK * 4);
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
-            lds_dma16(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4) + bko);
+            lds_dma16_s(w_rs, sb + i * 32 * 128, (unsigned)(b_off0 + i * 32 * p.K * 4), bko);
     };
 
     f32x16 acc[TM][TN];
@@ -988,11 +1004,13 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
     auto issue_tile = [&](int kt, int stage) {
         const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
         const unsigned ko = (unsigned)(kt * BK * 4);
+        // the K-tile's byte offset rides in the instruction's scalar offset: no vector arithmetic per K-tile (round 4:
+        // +1..2.5 % on the large GEMMs against `voff + ko` with its select for out-of-range rows and M0 save / restore)
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * 32 * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
         const unsigned sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * 32 * 128, b_voff[i] + ko);
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * 32 * 128, b_voff[i], ko);
     };
 
     const int frag_row = lane & 31, half = lane >> 5;
@@ -1274,10 +1292,10 @@ __global__ __launch_bounds__(256, 4) void conv_pw_streamk_kernel(const ConvParam
         const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
         const unsigned ko = (unsigned)(kt * BK * 4);
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * 32 * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
         const unsigned sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * 32 * 128, b_voff[i] + ko);
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * 32 * 128, b_voff[i], ko);
     };
 
     const int frag_row = lane & 31;
@@ -1563,10 +1581,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_pers
         const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
         const unsigned ko = (unsigned)(kt * BK * 4);
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) lds_dma16(x_rs, sa + i * RPP * 128, a_voff[i] == OOB ? OOB : a_voff[i] + ko);
+        for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * RPP * 128, a_voff[i], ko);
         const unsigned sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16(w_rs, sb + i * RPP * 128, b_voff[i] + ko);
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * RPP * 128, b_voff[i], ko);
     };
 
     const int r16 = lane & 15, g16 = lane >> 4;
