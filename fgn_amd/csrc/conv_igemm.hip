@@ -121,7 +121,7 @@ __device__ unsigned long long g_clock_stamps[16384 * 6];
 // 1: no LDS-DMA inside the K loop (the loop re-reads the tile's first K-tile), 2: no s_barrier in the K loop,
 // 4: the wait before the barrier does not wait for the DMA (lgkmcnt only), 8: operand fragments are read from LDS once
 // per output tile instead of once per 16-deep step, 16: the epilogue does not store to global memory, 32: the first
-// K-tile of the next output tile is not fetched, 64: no epilogue at all.
+// K-tile of the next output tile is not fetched, 64: no epilogue at all, 256: one M0 write per K-tile instead of four.
 #ifdef CONV_PW_EXP
 #define PW_EXP(bit) ((CONV_PW_EXP) & (bit))
 #else
@@ -452,6 +452,10 @@ __device__ __forceinline__ void lds_dma16_s(const i32x4& rs, unsigned lds_base, 
         :
         : "v"(voff), "s"(lds_base), "s"(rs), "s"(soff)
         : "memory", "m0");
+}
+// (diagnostic builds only: the same without the M0 write - the data lands where the previous load's did)
+__device__ __forceinline__ void lds_dma16_s_nom0(const i32x4& rs, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 // 16-byte store that writes through the XCD's L2 to device-coherent memory (sc1 = agent scope): how a workgroup publishes
 // a split-K partial tile that a workgroup on another XCD will read (the L2s of the eight XCDs are not coherent with each
@@ -1006,6 +1010,13 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         const unsigned ko = (unsigned)(kt * BK * 4);
         // the K-tile's byte offset rides in the instruction's scalar offset: no vector arithmetic per K-tile (round 4:
         // +1..2.5 % on the large GEMMs against `voff + ko` with its select for out-of-range rows and M0 save / restore)
+        if (PW_EXP(256)) {          // one M0 write per K-tile instead of four (what a per-wave contiguous LDS layout would issue)
+            lds_dma16_s(x_rs, sa, a_voff[0], ko);
+            lds_dma16_s_nom0(x_rs, a_voff[1], ko);
+            lds_dma16_s_nom0(w_rs, b_voff[0], ko);
+            lds_dma16_s_nom0(w_rs, b_voff[1], ko);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
         const unsigned sb = sa + BM * 128;
