@@ -722,6 +722,63 @@ extern "C" int fgn_gemm_small_f32(const float* A, const float* B, float* C, int 
     return FGN_OK;
 }
 
+// The same update for up to FGN_ADAGRAD_MAX_TENSORS parameter tensors in ONE launch (the heads have ~40 tensors from 1 to
+// 9.4 M elements; one launch each was launch-rate-bound: 0.4 ms of a 14 ms step).  The table travels as a kernel argument;
+// block b works on chunk b of the concatenation of all tensors cut into 4096-element chunks (first_chunk = prefix sums).
+// Element-wise, so the result is that of the one-tensor launches bit for bit.
+constexpr int FGN_ADAGRAD_MAX_TENSORS = 64;
+struct AdagradTable {
+    float* p[FGN_ADAGRAD_MAX_TENSORS];
+    const float* g[FGN_ADAGRAD_MAX_TENSORS];
+    float* s[FGN_ADAGRAD_MAX_TENSORS];
+    long long n[FGN_ADAGRAD_MAX_TENSORS];
+    int first_chunk[FGN_ADAGRAD_MAX_TENSORS + 1];
+    float lr[FGN_ADAGRAD_MAX_TENSORS];
+    int count;
+};
+__global__ __launch_bounds__(256) void adagrad_multi_kernel(const AdagradTable t, float wd, float eps) {
+    const int chunk = blockIdx.x;
+    int k = 0;
+    while (k + 1 < t.count && t.first_chunk[k + 1] <= chunk) ++k;          // block-uniform, <= 64 steps over SGPRs
+    const long long base = (long long)(chunk - t.first_chunk[k]) * 4096;
+    float* __restrict__ p = t.p[k];
+    const float* __restrict__ g = t.g[k];
+    float* __restrict__ state = t.s[k];
+    const long long end = min(t.n[k], base + 4096);
+    const float lr = t.lr[k];
+    for (long long i = base + threadIdx.x; i < end; i += 256) {
+        const float pv = p[i];
+        const float gv = g[i] + wd * pv;
+        const float st = state[i] + gv * gv;
+        state[i] = st;
+        p[i] = pv - lr * gv / (sqrtf(st) + eps);
+    }
+}
+
+extern "C" int fgn_adagrad_multi_f32(float* const* params, const float* const* grads, float* const* state_sums,
+                                     const long long* n, const float* lr, int count, float weight_decay, float eps,
+                                     hipStream_t stream) {
+    if (count < 0 || (count > 0 && (!params || !grads || !state_sums || !n || !lr))) return FGN_ERR_ARG;
+    for (int c0 = 0; c0 < count; c0 += FGN_ADAGRAD_MAX_TENSORS) {
+        AdagradTable t;
+        t.count = 0;
+        int chunks = 0;
+        for (int i = c0; i < count && t.count < FGN_ADAGRAD_MAX_TENSORS; ++i) {
+            if (n[i] <= 0) continue;
+            if (!params[i] || !grads[i] || !state_sums[i]) return FGN_ERR_ARG;
+            const int k = t.count++;
+            t.p[k] = params[i]; t.g[k] = grads[i]; t.s[k] = state_sums[i]; t.n[k] = n[i]; t.lr[k] = lr[i];
+            t.first_chunk[k] = chunks;
+            chunks += (int)((n[i] + 4095) / 4096);
+        }
+        t.first_chunk[t.count] = chunks;
+        if (t.count == 0) continue;
+        hipLaunchKernelGGL(adagrad_multi_kernel, dim3(chunks), dim3(256), 0, stream, t, weight_decay, eps);
+        FGN_LAUNCH_CHECK();
+    }
+    return FGN_OK;
+}
+
 extern "C" int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr,
                                     float weight_decay, float eps, hipStream_t stream) {
     if (n > 0 && (!param || !grad || !state_sum)) return FGN_ERR_ARG;

@@ -89,9 +89,10 @@ SIGNATURES = {
     'fgn_gemm_tn_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'fgn_gemm_tn_f32': (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     'fgn_adagrad_step_f32': (_i, [_p, _p, _p, C.c_longlong, _f, _f, _f, _p]),
+    'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 

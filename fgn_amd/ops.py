@@ -1308,6 +1308,39 @@ def gemm_small(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False) -> torch
     return out
 
 
+def adagrad_multi(params, grads, states, lrs, weight_decay: float, eps: float = 1e-10, table: Optional[dict] = None) -> None:
+    """``adagrad_step`` for a list of tensors in one launch (each with its own learning rate).  ``table``: a dict the
+    caller keeps between steps - the checked parameter / state pointer arrays are built once per (tensors, lrs) and only
+    the gradient pointers are refreshed (the parameters of a ``Trainer`` never move)."""
+    import ctypes as C
+    k = len(params)
+    if not (len(grads) == len(states) == len(lrs) == k):
+        raise _lib.FgnHipError('adagrad_multi: list lengths differ')
+    if not k:
+        return
+    key = (tuple(p.data_ptr() for p in params), tuple(s.data_ptr() for s in states), tuple(float(v) for v in lrs))
+    if table is None or table.get('key') != key:
+        for p, s in zip(params, states):
+            _chk(p, 'param'); _chk(s, 'state')
+            if not (p.is_contiguous() and s.is_contiguous()) or s.numel() != p.numel():
+                raise _lib.FgnHipError('adagrad_multi: parameters and states must be contiguous and of equal size')
+        built = dict(key=key, pa=(C.c_void_p * k)(*key[0]), sa=(C.c_void_p * k)(*key[1]),
+                     na=(C.c_longlong * k)(*[p.numel() for p in params]), la=(C.c_float * k)(*key[2]),
+                     ga=(C.c_void_p * k)(), numel=[p.numel() for p in params])
+        if table is None:
+            table = built
+        else:
+            table.clear(); table.update(built)
+    ga = table['ga']
+    for i, g in enumerate(grads):
+        if not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != table['numel'][i]:
+            raise _lib.FgnHipError('adagrad_multi: gradients must be contiguous fp32 device tensors of the parameters\' sizes')
+        ga[i] = g.data_ptr()
+    rc = _lib.load().fgn_adagrad_multi_f32(table['pa'], ga, table['sa'], table['na'], table['la'], k, float(weight_decay),
+                                           float(eps), _stream())
+    _lib.check(rc, 'fgn_adagrad_multi_f32')
+
+
 def adagrad_step(param: torch.Tensor, grad: torch.Tensor, state: torch.Tensor, lr: float, weight_decay: float,
                  eps: float = 1e-10) -> None:
     for t, nm in ((param, 'param'), (grad, 'grad'), (state, 'state')):

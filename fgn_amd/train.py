@@ -205,8 +205,49 @@ def _sample(gt_inds: np.ndarray, num: int, pos_fraction: float, perm_fn):
     return pos, neg
 
 
-def _dev_idx(a, dev) -> torch.Tensor:
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev, non_blocking=True)
+class _Staging:
+    """Pinned staging memory for the small host arrays of a training step (sampled indices, labels, box targets: ~15
+    per step).  A ``torch.from_numpy(a).to(dev)`` from pageable memory is a SYNCHRONOUS copy - the host waits ~50 us for
+    each while the GPU idles between them (rocprofv3 timeline, round 4: 0.7 ms per step); from pinned memory the same
+    copy is queued and the host moves on.  Two arenas alternate per ``forward_train`` call: a call waits for the GPU at
+    least once after its first copy (the assignment vectors), so every copy of call n has left its arena before call
+    n + 2 writes there.  An array that does not fit takes the pageable path."""
+
+    def __init__(self, nbytes: int = 4 << 20):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self.cur, self.off = 0, 0
+
+    def next_call(self) -> None:
+        self.cur ^= 1
+        self.off = 0
+
+    def h2d(self, a: np.ndarray, dev) -> torch.Tensor:
+        a = np.ascontiguousarray(a)
+        start = (self.off + 63) // 64 * 64
+        if a.nbytes == 0 or start + a.nbytes > self.bufs[self.cur].numel():
+            return torch.from_numpy(a).to(dev, non_blocking=True)
+        self.off = start + a.nbytes
+        host = self.bufs[self.cur][start:self.off]
+        host.numpy().view(a.dtype).reshape(a.shape)[...] = a
+        return host.view(torch.from_numpy(a[:0]).dtype).view(a.shape).to(dev, non_blocking=True)
+
+
+def _staging(model) -> _Staging:
+    cache = model._PT.setdefault('pinned', {})
+    st = cache.get('h2d')
+    if st is None:
+        st = cache['h2d'] = _Staging()
+    return st
+
+
+def _h2d(model, a, dev, dtype=None) -> torch.Tensor:
+    a = np.asarray(a)
+    return _staging(model).h2d(a if dtype is None else a.astype(dtype, copy=False), dev)
+
+
+def _dev_idx(a, dev, model=None) -> torch.Tensor:
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return _staging(model).h2d(a, dev) if model is not None else torch.from_numpy(a).to(dev, non_blocking=True)
 
 
 def _zero(dev):
@@ -239,7 +280,8 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     gt_h = [torch.as_tensor(b).detach().cpu().float().reshape(-1, 4)[:, [1, 0, 3, 2]].contiguous().numpy()
             for b in qry_bboxes]                                            # host copies drive the bookkeeping
     cat_h = [torch.as_tensor(c).detach().cpu().long().reshape(-1).numpy() for c in qry_cat_ids]
-    gt_xyxy = [torch.from_numpy(g).to(dev, non_blocking=True) for g in gt_h]
+    _staging(model).next_call()
+    gt_xyxy = [_h2d(model, g, dev) for g in gt_h]
     ih, iw = int(img_shape[0][0]), int(img_shape[0][1])
     if any(int(s[0]) != ih or int(s[1]) != iw for s in img_shape):
         raise ValueError('all images of a batch must share img_shape (the dataset batches by size)')
@@ -270,7 +312,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     grp_gt_h = [gt_h[g // N][cat_h[g // N] == (g % N)] for g in range(G)]
     gi_all = torch.empty((G, n_total), device=dev, dtype=torch.int32)
     for g in range(G):
-        gts = torch.from_numpy(grp_gt_h[g]).to(dev, non_blocking=True) if len(grp_gt_h[g]) else gt_xyxy[0][:0]
+        gts = _h2d(model, grp_gt_h[g], dev) if len(grp_gt_h[g]) else gt_xyxy[0][:0]
         ops.box_assign(anchors, gts, tc['pos_iou_thr'], tc['neg_iou_thr'], tc['min_pos_iou'], tc['match_low_quality'],
                        inside=inside, out=gi_all[g])
     # the anchor assignment starts its way to the host NOW (pinned buffer, no wait): the host samples the AG-RPN sets
@@ -322,15 +364,15 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
             pos_gt.append(grp_gt_h[g][gi_host[g][pos] - 1])
     n_samples = n_pos_total + n_neg_total
     pw = 1.0 if tc['pos_weight'] <= 0 else float(tc['pos_weight'])
-    x_cat = logits_all.reshape(-1)[_dev_idx(np.concatenate(flat), dev)].contiguous()
-    y_cat = torch.from_numpy(np.concatenate(ycat)).to(dev, non_blocking=True)
+    x_cat = logits_all.reshape(-1)[_dev_idx(np.concatenate(flat), dev, model)].contiguous()
+    y_cat = _h2d(model, np.concatenate(ycat), dev)
     w_cat = None if pw == 1.0 else torch.where(y_cat > 0, pw, 1.0).float().contiguous()
     loss_rpn_cls = ops.bce_logits_sum(x_cat, y_cat, w_cat, n_samples) / N              # the 1/N balancer
     preds = tgts = None
     if pos_flat:
-        preds = deltas_all.reshape(-1, 4)[_dev_idx(np.concatenate(pos_flat), dev)].contiguous()
-        tgts = ops.bbox2delta(anchors[_dev_idx(np.concatenate(pos_anchor), dev)].contiguous(),
-                              torch.from_numpy(np.concatenate(pos_gt).astype(np.float32)).to(dev),
+        preds = deltas_all.reshape(-1, 4)[_dev_idx(np.concatenate(pos_flat), dev, model)].contiguous()
+        tgts = ops.bbox2delta(anchors[_dev_idx(np.concatenate(pos_anchor), dev, model)].contiguous(),
+                              _h2d(model, np.concatenate(pos_gt), dev, np.float32),
                               rp['target_means'], rp['target_stds'])
         loss_rpn_bbox = ops.smooth_l1_sum(preds, tgts, None, n_samples) / N
     else:
@@ -359,7 +401,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
             gi = np.concatenate([np.arange(1, k + 1, dtype=np.int32), gi])
         pos, neg = _sample(gi, rc['num'], rc['pos_fraction'], perm_fn)
         assigned = (gi[pos] - 1).astype(np.int64)
-        sel = boxes[_dev_idx(np.concatenate([pos, neg]), dev)]
+        sel = boxes[_dev_idx(np.concatenate([pos, neg]), dev, model)]
         samples.append(dict(pos_bboxes=sel[:pos.size], n_pos=int(pos.size), n_neg=int(neg.size),
                             pos_assigned_gt_inds=assigned, pos_gt_bboxes_h=gt_h[i][assigned].reshape(-1, 4),
                             pos_gt_labels=torch.from_numpy(cat_h[i][assigned]), pos_inds=torch.from_numpy(pos),
@@ -396,9 +438,9 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         bbox_pred = torch.zeros((0, 4 * N), device=dev)
     # FGNBBoxHead.get_targets / loss (fgn_roi_head.py:58-160): background label = n_ways
     lab_h = np.concatenate(lab_parts) if lab_parts else np.zeros(0, np.int64)
-    labels = torch.from_numpy(lab_h).to(dev)
+    labels = _h2d(model, lab_h, dev, np.int64)
     pos_rows_h = np.flatnonzero(lab_h < N)
-    pos_rows = _dev_idx(pos_rows_h, dev)
+    pos_rows = _dev_idx(pos_rows_h, dev, model)
     pw = 1.0 if rc['pos_weight'] <= 0 else float(rc['pos_weight'])
     lw = None if pw == 1.0 else torch.where(labels < N, pw, 1.0).float().contiguous()
     avg = max(float(n_rois), 1.0)                     # every sampled RoI has label weight > 0
@@ -419,8 +461,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     if pos_rows_h.size:
         pos_pred = bbox_pred.view(n_rois, -1, 4)[pos_rows, labels[pos_rows]].contiguous()
         pos_tgt = ops.bbox2delta(torch.cat([s['pos_bboxes'] for s in samples]).contiguous(),
-                                 torch.from_numpy(np.concatenate([s['pos_gt_bboxes_h'] for s in samples])
-                                                  .astype(np.float32)).to(dev),
+                                 _h2d(model, np.concatenate([s['pos_gt_bboxes_h'] for s in samples]), dev, np.float32),
                                  bh['target_means'], bh['target_stds'])
         losses['loss_bbox'] = ops.smooth_l1_sum(pos_pred, pos_tgt, None, float(n_rois)).view(())
     else:
@@ -440,7 +481,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
     n_pos = int(pos_rows_h.size)
     if n_pos:
         img_of_h = np.concatenate([np.full(s['n_pos'], i, np.int64) for i, s in enumerate(samples)])
-        vrows = _dev_idx(lab_h[pos_rows_h] + N * img_of_h, dev)
+        vrows = _dev_idx(lab_h[pos_rows_h] + N * img_of_h, dev, model)
         vmask = sc['cat_mean_mp'][vrows].contiguous()                                     # spp_vecs_mask
         mfeat = feats[pos_rows].contiguous()
         if tape is None:
@@ -459,7 +500,7 @@ def forward_train(model, qry_img, qry_bboxes, qry_cat_ids, qry_isegmaps, qry_bbo
         pb = torch.stack([pb[:, 0].clamp(0, mw_), pb[:, 1].clamp(0, mh_), pb[:, 2].clamp(0, mw_),
                           pb[:, 3].clamp(0, mh_)], 1)
         gidx = np.concatenate([s['pos_assigned_gt_inds'] + int(first[i]) for i, s in enumerate(samples)])
-        mrois = torch.cat([torch.from_numpy(gidx.astype(np.float32)).to(dev)[:, None], pb], 1).contiguous()
+        mrois = torch.cat([_h2d(model, gidx, dev, np.float32)[:, None], pb], 1).contiguous()
         ms = rc['mask_size']
         tgt = ops.roi_align_mask(masks_all, mrois, ms, 1.0, 0, True)                  # [n_pos, ms, ms] in [0,1]
         if tuple(mlog.shape[1:]) != (ms, ms):
@@ -623,7 +664,7 @@ def _backward_roi_stage(model, W: dict, tape: dict, grads: dict) -> None:
         # index_add_ would accumulate with atomics, in an order that changes from run to run)
         d_cat_mean_mp = torch.zeros((tape['spp']['B'] * N, C), device=dev)
         for r_ in np.unique(tm['rows_h']):
-            sel = _dev_idx(np.flatnonzero(tm['rows_h'] == r_), dev)
+            sel = _dev_idx(np.flatnonzero(tm['rows_h'] == r_), dev, model)
             ops.colsum(d_vmask[sel].contiguous(), out=d_cat_mean_mp[int(r_)])
 
     # ---- box head losses -> relation head (fgn_roi_head.py:58-118, 253-279, 302-326) ---------------------
@@ -707,9 +748,9 @@ def _backward_rpn_stage(model, W: dict, tape: dict, grads: dict) -> None:
             li.append((g * hw + idx // A) * CH + idx % A)
         ri.append(((g * hw + pos // A) * CH + A + 4 * (pos % A))[:, None] + np.arange(4)[None])
     dflat = dhead.view(-1)
-    dflat[_dev_idx(np.concatenate(li), dev)] = dx_cat
+    dflat[_dev_idx(np.concatenate(li), dev, model)] = dx_cat
     if dpred is not None:
-        dflat[_dev_idx(np.concatenate(ri).reshape(-1), dev)] = dpred.reshape(-1)
+        dflat[_dev_idx(np.concatenate(ri).reshape(-1), dev, model)] = dpred.reshape(-1)
     rows = torch.nonzero(dhead.abs().sum(-1).view(-1) > 0).view(-1)          # active (pass, pixel) rows: <= num * G
     Cf = t['x'].shape[-1]
     dH = dhead.view(-1, CH)[rows]
@@ -906,9 +947,13 @@ class Trainer:
         losses = self.forward_backward(batch, perm_fn)
         from .dist import allreduce_mean
         self.grads = allreduce_mean(self.grads, keys=sorted(self.W))
-        for k in self.W:
-            lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
-            ops.adagrad_step(self.W[k], self.grads[k].contiguous(), self.state[k], lr, self.wd, self.eps)
+        keys = list(self.W)
+        if not hasattr(self, '_adagrad_table'):
+            self._adagrad_table = {}
+        ops.adagrad_multi([self.W[k] for k in keys], [self.grads[k].contiguous() for k in keys],
+                          [self.state[k] for k in keys],
+                          [self.lr * (self.mult if k.startswith('roi_head') else 1.0) for k in keys], self.wd, self.eps,
+                          table=self._adagrad_table)
         self.n_steps += 1
         self.refresh()
         return losses

@@ -375,6 +375,10 @@ int fgn_gemm_small_f32(const float* A, const float* B, float* C, int M, int N, i
                        int trans_a, void* stream);
 
 /* torch.optim.Adagrad step (fgn_train_schedule.py:5-13): g += wd*p; state += g*g; p -= lr*g/(sqrt(state)+eps) */
+/* the same update for `count` parameter tensors (each with its own learning rate) in one launch; element-wise, so
+ * bit-identical to `count` calls of fgn_adagrad_step_f32 (Trainer.step: ~40 tensors of the heads) */
+int fgn_adagrad_multi_f32(float* const* params, const float* const* grads, float* const* state_sums, const long long* n,
+                          const float* lr, int count, float weight_decay, float eps, void* stream);
 int fgn_adagrad_step_f32(float* param, const float* grad, float* state_sum, long long n, float lr, float weight_decay,
                          float eps, void* stream);
 

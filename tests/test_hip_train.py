@@ -784,3 +784,47 @@ def test_in_place_repack_equals_a_fresh_pack():
     for k in res['1'][1]:
         a, b_ = res['1'][1][k], res['0'][1][k]
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= 5e-4, k
+
+
+@pytest.mark.gpu
+def test_adagrad_of_all_tensors_in_one_launch_equals_one_launch_per_tensor():
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 4095, 4096, 4097, 75 * 1024, 9437184 // 8, 6, 0, 512]
+    mk = lambda: [torch.randn(n, generator=g).cuda() for n in sizes]
+    P1, G1, S1 = mk(), mk(), [t.abs() for t in mk()]
+    P2, S2 = [t.clone() for t in P1], [t.clone() for t in S1]
+    lrs = [0.01 * (1 + i % 3) for i in range(len(sizes))]
+    for p, gr, s, lr in zip(P1, G1, S1, lrs):
+        ops.adagrad_step(p, gr, s, lr, 1e-5, 1e-10)
+    ops.adagrad_multi(P2, G1, S2, lrs, 1e-5, 1e-10)
+    for a, b in zip(P1 + S1, P2 + S2):
+        assert torch.equal(a, b)
+    # more tensors than one table holds
+    many = 150
+    P3 = [torch.randn(17 + i, generator=g).cuda() for i in range(many)]
+    G3 = [torch.randn(17 + i, generator=g).cuda() for i in range(many)]
+    S3 = [torch.zeros(17 + i).cuda() for i in range(many)]
+    P4, S4 = [t.clone() for t in P3], [t.clone() for t in S3]
+    for p, gr, s in zip(P3, G3, S3):
+        ops.adagrad_step(p, gr, s, 0.005, 1e-5, 1e-10)
+    ops.adagrad_multi(P4, G3, S4, [0.005] * many, 1e-5, 1e-10)
+    for a, b in zip(P3 + S3, P4 + S4):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pinned_staging_of_the_small_host_arrays():
+    from fgn_amd import train as TR
+    st = TR._Staging(nbytes=1 << 12)
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(0)
+    for call in range(3):
+        st.next_call()
+        arrs = [rng.integers(0, 1 << 40, 37).astype(np.int64), rng.random((5, 4)).astype(np.float32), np.zeros(0, np.int64),
+                rng.integers(0, 255, 300).astype(np.uint8), rng.random(2000)]            # the last one does not fit: pageable path
+        outs = [st.h2d(a, dev) for a in arrs]
+        torch.cuda.synchronize()
+        for a, t in zip(arrs, outs):
+            assert t.dtype == torch.from_numpy(a[:0]).dtype and tuple(t.shape) == a.shape
+            assert np.array_equal(t.cpu().numpy(), a)

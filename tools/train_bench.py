@@ -22,6 +22,12 @@ cfg = fgn_r50_c4_config(3, 3)
 sd = init_state_dict(cfg, 0)
 m = FGN(3, 3, state_dict=sd)
 batches = [make_batch(i * a.batch, a.batch, **CONFIGS['cfg3']) for i in range(4)]
+if not os.environ.get('TRAIN_BENCH_PAGEABLE'):
+    # page-locked input tensors, the protocol of bench.py (and of a DataLoader with pin_memory=True): a pageable 12.8 MB
+    # image is uploaded in staging-buffer pieces with the host copying between them - ~1 ms of every step with the GPU idle
+    batches = [{k: (v.pin_memory() if isinstance(v, torch.Tensor) else
+                    [t.pin_memory() if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, (list, tuple)) else v)
+                for k, v in b.items()} for b in batches]
 
 
 def timed(fn, n):
@@ -35,7 +41,7 @@ def timed(fn, n):
 
 
 res = {'workload': f'cfg3 training step, batch {a.batch}: 3-way 3-shot, 800x1333, ResNet-50-C4 (frozen), heads trained',
-       'batch': a.batch}
+       'batch': a.batch, 'inputs': 'pageable host tensors' if os.environ.get('TRAIN_BENCH_PAGEABLE') else 'page-locked host tensors'}
 res['forward_train_ms'] = timed(lambda b: m.forward_train(**b), a.steps)
 tr = Trainer(m)
 res['forward_backward_ms'] = timed(lambda b: tr.forward_backward(b), a.steps)
