@@ -319,7 +319,18 @@ def main():
     xfer_mode = int(os.environ.get('FGN_XFER_MODE', '3' if args.batch <= 2 else '0'))
     if args.graphs and xfer_mode:
         model.transfer_stream(xfer_mode)
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    # FGN_BENCH_EMULATE_COMM=1 (one rank, no process group): the stream arrangement of a multi-rank run on ONE GPU - a
+    # communication stream and a second stream standing in for RCCL's internal one are created and used BEFORE the caller
+    # streams, and every step packs its records and copies them on the communication stream behind an event, as the
+    # all-gather's local part would.  What a rank pays for the arrangement itself, without peers (profiles/).
+    emulate_comm = world == 1 and bool(os.environ.get('FGN_BENCH_EMULATE_COMM'))
+    comm_stream = torch.cuda.Stream() if (world > 1 or emulate_comm) else None
+    if emulate_comm:
+        rccl_like = torch.cuda.Stream()
+        for s_ in (comm_stream, rccl_like):
+            with torch.cuda.stream(s_):
+                torch.zeros(1, device=dev).add_(1)
+            s_.synchronize()
     if world > 1 and backend == 'nccl':
         # RCCL runs a collective on an internal stream of its own, which takes the next hardware queue when it is first
         # used.  One warm-up collective HERE - after the communication stream, before the caller streams exist - gives
@@ -330,6 +341,25 @@ def main():
             dist.all_reduce(warm)
         comm_stream.synchronize()
     ep_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else [None]
+    # Phase lock of the two caller streams (FGN.phase_counter / phase_point, detector.py).  Two streams that replay
+    # episodes side by side settle in one of several steady states of their relative phase - the same binary on the same
+    # box ran 192-195 img/s in most runs and 203 in some, and small changes of the stream set-up flipped it one way or the
+    # other (profiles/r04_phase_lock.txt).  With the lock an episode starts when the previous one, on the other stream,
+    # has passed a mark at the end of its backbone ('rpn': present on every path through the detector, the support cache
+    # included): every run then sits in the fast state - one episode per step
+    # 192-195 -> 202-203 img/s over 200 steps (186-190 -> 194-197 in the driver's 20-step window), two per step
+    # 192.6 -> 213.6; marks from 'layer1' to 'rpn' are equal, 'rpn_conv' / 'proposals' / 'mask' are worse (197 / 200 /
+    # 185).  At 4 / 8 episodes per step the lock needs the transfers on the caller streams (FGN_XFER_MODE=3) and then
+    # gives 209 -> 217 / 213.5 -> 220; it is left off there by default because that arrangement disturbs the isolated
+    # instrumented step the roofline is taken from (its transforms and GEMMs run 10-25 % longer - not yet explained).
+    # FGN_BENCH_PHASE=off disables, =<mark> selects.
+    phase_point = os.environ.get('FGN_BENCH_PHASE', 'rpn' if (args.batch <= 2 and args.graphs and args.streams == 2) else '')
+    if phase_point in ('off', '0', 'none'):
+        phase_point = ''
+    # (armed after the warm-up: the counters' values are read once, behind a synchronisation, and counted on the host
+    # from there - every launch bumps its stream's counter exactly once)
+    phase_counters = torch.zeros(2, device=dev, dtype=torch.int32) if (phase_point and len(ep_streams) == 2) else None
+    phase_armed, phase_base, phase_sent = [False], [0, 0], [0, 0]
     gathered_last = {}
     gather_on_compute = bool(os.environ.get('FGN_BENCH_GATHER_ON_COMPUTE'))
     gather_pool = None
@@ -366,10 +396,30 @@ def main():
         ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
         try:
             with ctx:
+                if phase_counters is not None:
+                    # phase lock of the two caller streams: this episode starts when the previous one (on the other
+                    # stream) has passed its mark; its own mark releases the next one
+                    k_ = i % 2
+                    if phase_armed[0]:
+                        ops.phase_wait(phase_counters[1 - k_:2 - k_], phase_base[1 - k_] + phase_sent[1 - k_])
+                    model.phase_counter, model.phase_point = phase_counters[k_:k_ + 1], phase_point
+                    phase_sent[k_] += 1
                 dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
                                            e['img_shape'], support_code=e['code'], qry_isegmaps=e['qry_isegmaps'])
         finally:
             ops.PROFILE = None
+        if emulate_comm:
+            with ctx:
+                recs, cnts = fdist.pack_detections(dets, max_det)
+                packed = torch.cuda.current_stream().record_event()
+            comm_stream.wait_event(packed)
+            with torch.cuda.stream(comm_stream):
+                rccl_like.wait_stream(comm_stream)
+                with torch.cuda.stream(rccl_like):
+                    gathered_last['emulated'] = (recs.clone(), cnts.clone())
+                comm_stream.wait_stream(rccl_like)
+            recs.record_stream(rccl_like)
+            cnts.record_stream(rccl_like)
         if world > 1:
             # one RCCL all-gather of fixed-size padded records (boxes, scores, labels, mask probabilities) per step.
             # The records are packed on the CALLER stream - five small copies out of the episode's output buffers,
@@ -490,6 +540,10 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    if phase_counters is not None:
+        phase_base[:] = [int(v) for v in phase_counters.tolist()]
+        phase_sent[:] = [0, 0]
+        phase_armed[0] = not os.environ.get('FGN_BENCH_PHASE_NOWAIT')
     t0 = time.perf_counter()
     # in the instrumented steps every convolution kernel launch stamps a start/stop HIP event pair
     # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on)
@@ -618,7 +672,8 @@ def main():
                                                 'max': round(max(per_rank_dt) / args.steps * 1e3, 3),
                                                 'all': [round(v / args.steps * 1e3, 3) for v in per_rank_dt]},
                        'rank_placement': rank_info,
-                       'gather_stream': (None if world == 1 else 'caller' if gather_on_compute else 'communication'),
+                       'gather_stream': (('emulated (one rank)' if emulate_comm else None) if world == 1 else 'caller' if gather_on_compute else 'communication'),
+                       'phase_lock': phase_point or None,
                        'jitter_ms_rehearsal': jitter_ms or None,
                        'peak_memory_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        'reserved_memory_gib': round(torch.cuda.memory_reserved() / 2 ** 30, 2),

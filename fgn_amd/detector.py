@@ -707,9 +707,11 @@ class FGN(torch.nn.Module):
         x = _Pair((outs[0].shape[0],) + hw(outs[0]), (outs[1].shape[0],) + hw(outs[1]), outs[0].shape[3], outs[0].device)
         ops.maxpool3x3s2(outs[0], out=x.q)
         ops.maxpool3x3s2(outs[1], out=x.s)
-        for stage in P['stages']:
+        self._phase_mark('layer1')                   # (stem + max-pool done)
+        for si, stage in enumerate(P['stages']):
             for blk in stage:
                 x = _bottleneck_pair(blk, x)
+            self._phase_mark('layer%d' % (si + 2))     # 'layer2' = layer1 done, ..., the last stage's mark equals 'rpn'
         return x.q, x.s
 
     def _shared_head(self, x, n_img_dev=None, y1=None):
@@ -978,6 +980,21 @@ class FGN(torch.nn.Module):
         with ops.arena(dev):     # zero-initialised small outputs of this episode: one fill (caller's stream only)
             return self._detect_body(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev)
 
+    # Phase mark of a pipelined serving loop (bench.py): when two caller streams replay episodes side by
+    # side, their relative phase settles in one of several steady states that differ by ~4 % in throughput.  A caller may
+    # hand over a one-element int32 device counter (``phase_counter``) and the point of the episode at which to bump it
+    # (``phase_point``: 'layer1'..'layer3' inside the backbone, 'rpn' = backbone done, 'rpn_conv', 'proposals', 'mask'):
+    # ``ops.phase_signal`` is captured into the episode's
+    # graph like any kernel, and the OTHER caller stream runs ``ops.phase_wait`` on that counter before its next episode.
+    # (An event would be the natural tool; a captured graph cannot record one that another stream waits for on this
+    # stack - "External events are disallowed in rocm".)  None: no mark.
+    phase_counter = None
+    phase_point = None
+
+    def _phase_mark(self, name: str) -> None:
+        if self.phase_counter is not None and name == self.phase_point:
+            ops.phase_signal(self.phase_counter)
+
     def _detect_body(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev) -> list:
         P, cfg = self._P, self.cfg
         N, K = self.n_ways, self.k_shots
@@ -1058,6 +1075,7 @@ class FGN(torch.nn.Module):
         if not cached:
             main.wait_event(vec_ready)
         rpn_start = main.record_event()
+        self._phase_mark('rpn')
         # guidance multiply (fgn_ag_rpn_head.py:44): never materialised - it rides in the Winograd input transform,
         # or in the A-operand staging of the direct kernel where the layer is too small for the Winograd form
         if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout,
@@ -1066,6 +1084,7 @@ class FGN(torch.nn.Module):
             x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
         else:
             x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
+        self._phase_mark('rpn_conv')
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)
@@ -1098,6 +1117,7 @@ class FGN(torch.nn.Module):
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
                       n_props=n_props)
 
+        self._phase_mark('proposals')
         # ---- box head on the proposals of all B images at once (fgn_roi_head.py:531-616); a RoI carries its
         # image index in column 0 (bbox2roi), which selects the feature map in RoIAlign and the support set
         # in the relation head.  With one image the device-side proposal count bounds every launch; with
@@ -1134,6 +1154,7 @@ class FGN(torch.nn.Module):
         dets = [det_all[i * D:(i + 1) * D] for i in range(B)]
         labs = [lab_all[i * D:(i + 1) * D] for i in range(B)]
         n_dets = [n_det_all[i:i + 1] for i in range(B)]
+        self._phase_mark('mask')
         # ---- mask head on the detections of all images at once (fgn_roi_head.py:704-718, 360-382)
         nd_all = n_dets[0] if B == 1 else None
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)

@@ -19,6 +19,8 @@ _f = C.c_float
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
     'fgn_profile_next_launch': (_i, [_p, _p]),
+    'fgn_phase_signal': (_i, [_p, _p]),
+    'fgn_phase_wait': (_i, [_p, _i, _i, _p]),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
     'fgn_conv2d_kernel_id': (_i, [_i] * 14),
     'fgn_conv2d_tune': (_i, [_i, _i]),
@@ -92,7 +94,7 @@ SIGNATURES = {
     'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 _lib = None
 
 

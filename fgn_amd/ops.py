@@ -166,6 +166,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def phase_signal(counter: torch.Tensor) -> None:
+    """Bump the int32 device counter from the current stream (inside a captured graph: on every replay)."""
+    _chk(counter, 'counter', torch.int32)
+    _lib.check(_lib.load().fgn_phase_signal(_ptr(counter), _stream()), 'fgn_phase_signal')
+
+
+def phase_wait(counter: torch.Tensor, target: int, timeout_us: int = 50000) -> None:
+    """Hold the current stream until the counter has reached ``target`` (or the timeout has passed)."""
+    _chk(counter, 'counter', torch.int32)
+    _lib.check(_lib.load().fgn_phase_wait(_ptr(counter), int(target), int(timeout_us), _stream()), 'fgn_phase_wait')
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 

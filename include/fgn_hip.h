@@ -37,6 +37,11 @@ int fgn_abi_version(void);
  * launches stamps the two HIP events (hipEvent_t, created by the caller) with that kernel's own start and end -
  * the duration a rocprofv3 kernel trace reports.  NULL, NULL disarms. */
 int fgn_profile_next_launch(void* start_event, void* stop_event);
+/* Phase marks between streams that replay captured graphs (no reference counterpart; the pipelined serving loop of
+ * INTEGRATION.md): fgn_phase_signal bumps *counter (device memory, int32) from inside an episode - captured into its
+ * graph like any kernel; fgn_phase_wait holds `stream` until *counter - target >= 0 or timeout_us (<= 1 s) have passed. */
+int fgn_phase_signal(int32_t* counter, void* stream);
+int fgn_phase_wait(const int32_t* counter, int32_t target, int timeout_us, void* stream);
 
 /* Implicit-GEMM convolution on the fp32 MFMA pipe with fused epilogue
  *   y = conv(x * in_scale?, w) * scale[c] + shift[c] (+ residual) (ReLU)

@@ -402,3 +402,33 @@ def test_det_post_matches_reference_golden_cls_mod(golden_dir):
                                     torch.from_numpy(z['reg_raw']).cuda(), 3, 400, 400, (0, 0, 0, 0),
                                     (.1, .1, .2, .2), 0.05, 0.5, 100, debug_scores=True)
     assert np.array_equal(dbg.cpu().numpy(), O.softmax32(z['cls_n3']))
+
+
+@pytest.mark.gpu
+def test_phase_signal_and_wait_between_streams():
+    """The counter marks of the pipelined serving loop: a wait passes once the counter has reached its target, gives up
+    after its timeout when it never does, and a signal captured into a hipGraph bumps the counter on every replay."""
+    import time
+    from fgn_amd import ops
+    c = torch.zeros(1, dtype=torch.int32, device='cuda')
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(b):
+        ops.phase_wait(c, 2, timeout_us=500000)              # queued first: sleeps until two signals have arrived
+        done = torch.ones(1, device='cuda')
+    with torch.cuda.stream(a):
+        ops.phase_signal(c)
+        ops.phase_signal(c)
+    torch.cuda.synchronize()
+    assert int(c) == 2 and float(done) == 1.0
+    t = time.perf_counter()
+    ops.phase_wait(c, 5, timeout_us=3000)                    # never reached: returns after ~3 ms
+    torch.cuda.synchronize()
+    assert 0.002 < time.perf_counter() - t < 0.2
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(a):
+        with torch.cuda.graph(g, stream=a):
+            ops.phase_signal(c)
+        for _ in range(3):
+            g.replay()
+    torch.cuda.synchronize()
+    assert int(c) == 5
