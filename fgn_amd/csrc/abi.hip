@@ -22,12 +22,14 @@ extern "C" int fgn_profile_next_launch(void* start_event, void* stop_event) {
 // the process).  The waiting wave holds one wave slot of one CU and issues `s_sleep` between polls.
 // ------------------------------------------------------------------------------------------------
 __global__ void phase_signal_kernel(int32_t* counter) {
-    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // relaxed on purpose: the mark is a timing gate, nobody consumes data through it - a release at agent scope would
+    // write back the XCD's L2 in the middle of the episode
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void phase_wait_kernel(const int32_t* counter, int32_t target, unsigned timeout_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) break;
         __builtin_amdgcn_s_sleep(64);
     }
