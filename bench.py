@@ -544,8 +544,7 @@ def main():
         phase_base[:] = [int(v) for v in phase_counters.tolist()]
         phase_sent[:] = [0, 0]
         phase_armed[0] = not os.environ.get('FGN_BENCH_PHASE_NOWAIT')
-        # the steps queued behind the isolated instrumented step (they wait on the GPU for it) carry no phase wait: with
-        # wait kernels parked behind it the isolated step's kernels measured ~3 % longer
+        # the steps queued behind the isolated instrumented step (they wait on the GPU for it) carry no phase wait
         phase_first_wait[0] = (max(alone_steps) + 1 + args.inflight) if alone_steps else 0
     t0 = time.perf_counter()
     # in the instrumented steps every convolution kernel launch stamps a start/stop HIP event pair
