@@ -543,7 +543,7 @@ def main():
     if phase_counters is not None:
         phase_base[:] = [int(v) for v in phase_counters.tolist()]
         phase_sent[:] = [0, 0]
-        phase_armed[0] = not os.environ.get('FGN_BENCH_PHASE_NOWAIT')
+        phase_armed[0] = not os.environ.get('FGN_BENCH_PHASE_NOWAIT')      # (=1: the marks are sent, nobody waits: A/B aid)
         # the steps queued behind the isolated instrumented step (they wait on the GPU for it) carry no phase wait
         phase_first_wait[0] = (max(alone_steps) + 1 + args.inflight) if alone_steps else 0
     t0 = time.perf_counter()
