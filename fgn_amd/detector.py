@@ -309,7 +309,13 @@ class _GraphedEpisode:
         args = lambda: (self.static['qry_img'], self.static.get('spp_imgs'), self.static.get('spp_bboxes'),
                         self.static.get('spp_isegmaps'), self.img_shape, self.code)
         # eager pass first: packs the weights, sets kernel attributes, sizes the allocator pools
-        model._detect_eager(*args())
+        # (the eager run that precedes the capture sends no phase mark: every ``detect_device`` call bumps the caller's
+        # counter exactly once - here through the replay that follows the capture)
+        mark, model.phase_counter = model.phase_counter, None
+        try:
+            model._detect_eager(*args())
+        finally:
+            model.phase_counter = mark
         torch.cuda.current_stream().synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: only this thread's calls are checked against the capture, so nothing another

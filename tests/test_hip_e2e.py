@@ -395,8 +395,9 @@ def test_hip_graph_replay_is_identical():
     assert len(model._graphs) == 3
 
 
-@pytest.mark.parametrize('in_flight,xfer_mode', [(2, 0), (3, 0), (5, 0), (3, 3), (5, 3), (3, 2), (3, 1)])
-def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager(in_flight, xfer_mode):
+@pytest.mark.parametrize('in_flight,xfer_mode,lock', [(2, 0, ''), (3, 0, ''), (5, 0, ''), (3, 3, ''), (5, 3, ''), (3, 2, ''), (3, 1, ''),
+                                                    (3, 3, 'rpn'), (3, 3, 'layer2'), (2, 0, 'proposals')])
+def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_eager(in_flight, xfer_mode, lock):
     """bench.py's execution mode (round 3): hipGraph replay, steps alternating between two caller streams, two to five
     episodes queued before the first is packed (three is bench.py's default: a caller stream then holds two replays of
     its graph, the second waiting on the GPU for the download of the first) - one captured graph, one set of static
@@ -404,7 +405,9 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
     five distinct episodes must give, step by step, the bytes of a serial eager run (boxes, scores, labels, detection
     RLE, ground-truth RLE).  ``xfer_mode``: the transfer arrangements of ``FGN.transfer_stream`` - 3 (bench.py's choice
     at one episode per step, round 4): uploads and result copies ride on the caller stream itself, no upload / copy
-    streams; 2: copies on the caller stream, one upload stream for all; 1: one stream for both."""
+    streams; 2: copies on the caller stream, one upload stream for all; 1: one stream for both.  ``lock``: the phase
+    lock of INTEGRATION.md's serving loop (a counter mark inside every captured episode, the other stream waits for
+    it before its next episode): same bytes, and every episode has sent exactly one mark."""
     from fgn_amd.config import tiny_config
     from fgn_amd.detector import FGN
     from fgn_amd.episodes import make_batch
@@ -421,13 +424,24 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
         model.transfer_stream(xfer_mode)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     pending, got = [], []
+    from fgn_amd import ops
+    marks = torch.zeros(2, dtype=torch.int32, device='cuda')
+    sent = [0, 0]
+    if lock:
+        model.phase_point = lock
 
     def finish(item):
         e, dets = item
         return model.pack_results(dets, 1, qry_isegmaps=e['qry_isegmaps'], img_shape=e['img_shape'])
     for i in range(12):
         e = eps[i % 5]
-        with torch.cuda.stream(streams[i % 2]):
+        k = i % 2
+        with torch.cuda.stream(streams[k]):
+            if lock:
+                if sent[1 - k]:
+                    ops.phase_wait(marks[1 - k:2 - k], sent[1 - k])
+                model.phase_counter = marks[k:k + 1]
+                sent[k] += 1
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'],
                                        qry_isegmaps=e['qry_isegmaps'])
         pending.append((e, dets))
@@ -436,6 +450,8 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
     while pending:
         got.append(finish(pending.pop(0)))
     assert len(model._graphs) == 2                                 # one graph per caller stream
+    torch.cuda.synchronize()
+    assert marks.tolist() == (sent if lock else [0, 0])             # one mark per episode, captured graphs included
     for i, g in enumerate(got):
         w = want[i % 5]
         for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
