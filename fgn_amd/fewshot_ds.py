@@ -297,3 +297,173 @@ class ClutteredCharsFewShotISEG(Dataset):
         }
 
     evaluate = SyntheticFewShotISEG.evaluate
+
+
+# ------------------------------------------------------------------------------------------------
+# Episodic sampling on a databag (which instances form an episode): the index half of
+# BaseFewShotISEG.load_dataset / reshuffle / __getitem__ / get_query / get_support
+# ------------------------------------------------------------------------------------------------
+class Databag:
+    """The lookup tables ``load_dataset`` collects or reads (base_fst.py:328-432): parent queries (one per image, with
+    ``cats_dict`` category -> instance ids in insertion order and the ids of their child queries), child queries
+    ``[parent, category]`` (one per image and category on it), per-class instance lists, per-instance parent / category
+    / box.  Built from the reference's pickle (``from_pickle``: the tuple ``(qrys_parents_, qrys_children,
+    cats_insts_list, insts)``; the older files hold SETS as class lists - kept in their iteration order, which is what
+    the reference's list comprehensions see) or from flat arrays (``from_arrays``: tests/golden/databag_sampler.npz)."""
+
+    def __init__(self, parents_cats, parents_children, children, class_lists, inst_parent, inst_cat, inst_bbox):
+        self.parents_cats = parents_cats            # list of [(cat_id, [inst ids])] per parent, insertion order
+        self.parents_children = parents_children    # list of [child ids] per parent
+        self.children = children                    # [n_children, 2] (parent, category)
+        self.class_lists = class_lists              # list of [inst ids] per category
+        self.inst_parent, self.inst_cat, self.inst_bbox = inst_parent, inst_cat, inst_bbox
+
+    @classmethod
+    def from_pickle(cls, path: str) -> 'Databag':
+        with open(path, 'rb') as fh:
+            parents, children, class_lists, insts = pickle.load(fh)
+        return cls([[(int(c), [int(i) for i in v]) for c, v in p['cats_dict'].items()] for p in parents],
+                   [[int(c) for c in p['nums_children_qrys']] for p in parents],
+                   np.asarray(children, np.int64).reshape(-1, 2), [[int(i) for i in lst] for lst in class_lists],
+                   np.array([int(i.get('num_parent_qry', -1)) for i in insts]),
+                   np.array([int(i['cat_id']) for i in insts]),
+                   np.array([np.asarray(i['bbox'], np.float32) for i in insts], np.float32).reshape(-1, 4))
+
+    @classmethod
+    def from_arrays(cls, z, prefix: str = 'bag__') -> 'Databag':
+        g = lambda k: np.asarray(z[prefix + k])
+        pp, pc, pi = g('parent_ptr'), g('parent_cat'), g('parent_inst')
+        parents_cats = []
+        for a, b in zip(pp[:-1], pp[1:]):
+            d = {}
+            for c, i in zip(pc[a:b], pi[a:b]):
+                d.setdefault(int(c), []).append(int(i))
+            parents_cats.append(list(d.items()))
+        cp, ch = g('parent_children_ptr'), g('parent_children')
+        lp, li = g('class_ptr'), g('class_inst')
+        return cls(parents_cats, [[int(c) for c in ch[a:b]] for a, b in zip(cp[:-1], cp[1:])], g('children'),
+                   [[int(i) for i in li[a:b]] for a, b in zip(lp[:-1], lp[1:])], g('inst_parent'), g('inst_cat'),
+                   g('inst_bbox'))
+
+
+class DatabagEpisodeSampler:
+    """Index producer of the reference's episodic dataset on a ``Databag``: ``len`` / ``order`` as ``load_dataset``
+    builds them, ``sample_indices(idx)`` = everything ``__getitem__`` decides before it touches a pixel.  Draws come
+    from Python's ``random`` module in the reference's call order (``random.choice`` of the child under 'parents',
+    ``random.sample`` of the other categories, ``random.shuffle`` of the N, ``random.sample`` of K instances per
+    category), so a seeded run replays the reference's episodes exactly (tests/golden/databag_sampler.npz)."""
+
+    def __init__(self, bag: Databag, n_ways: int, k_shots: int, cats_novel, cats_total_amount: int,
+                 sampling_cats: str = 'base_', sampling_scenario: str = 'parents', shuffle: bool = False, repeats: int = 1,
+                 first_parents__only: int = 0, first_children_only: int = 0, qry_cats_choice_remove: bool = False,
+                 qry_cats_choice_random: bool = False, qry_cats_order_shuffle: bool = True,
+                 delete_qry_insts_in_spp_insts_on_train: bool = True, spp_random: bool = True, rng=None):
+        self.bag, self.n_ways, self.k_shots = bag, int(n_ways), int(k_shots)
+        self.sampling_scenario = sampling_scenario
+        self.shuffle = shuffle
+        self.qry_cats_choice_remove, self.qry_cats_choice_random = qry_cats_choice_remove, qry_cats_choice_random
+        self.qry_cats_order_shuffle = qry_cats_order_shuffle
+        self.delete_qry_insts = delete_qry_insts_in_spp_insts_on_train
+        self.spp_random = spp_random
+        self.random = rng if rng is not None else random          # the module itself: the reference's global stream
+        # ---- cats_selection (base_fst.py:267-300)
+        novel = np.array([] if sampling_cats == 'all' else cats_novel, dtype=np.int32)
+        is_base = np.ones(cats_total_amount, bool)
+        is_base[novel] = False
+        base = np.where(is_base)[0]
+        if sampling_cats == 'base_':
+            self.cats_to_save = base
+        elif sampling_cats == 'novel':
+            self.cats_to_save = novel
+        elif sampling_cats == 'all':
+            self.cats_to_save = np.arange(cats_total_amount).astype(np.int32)
+        else:
+            raise ValueError(f'sampling_cats {sampling_cats!r}')
+        self.cats_to_save_bool = np.zeros(cats_total_amount, bool)
+        self.cats_to_save_bool[self.cats_to_save] = True
+        # ---- order (base_fst.py:438-474)
+        n_par, n_chi = len(bag.parents_cats), len(bag.children)
+        if sampling_scenario not in ('parents', 'children'):
+            raise ValueError(f'sampling_scenario {sampling_scenario!r}')
+        order = np.arange(n_par if sampling_scenario == 'parents' else n_chi)
+        if 0 < first_parents__only <= n_par:
+            if sampling_scenario == 'parents':
+                order = order[:first_parents__only]
+            else:
+                order = order[:bag.parents_children[first_parents__only - 1][-1] + 1]
+        if 0 < first_children_only <= n_chi:
+            if sampling_scenario == 'parents':
+                order = order[:int(bag.children[first_children_only - 1][0]) + 1]
+            else:
+                order = order[:first_children_only]
+        if not 1 <= repeats <= 100:
+            repeats = 1
+        self.order_initial = np.tile(order, reps=repeats)
+        self.reshuffle()
+
+    def reshuffle(self, e: int = 8) -> None:
+        """``reshuffle`` of a batch-1 / synthetic-dataset run (base_fst.py:611-625): a fixed permutation per epoch seed."""
+        self.order = self.order_initial.copy()
+        if self.shuffle:
+            order = list(self.order)
+            random.Random((2 ** e) % 1000).shuffle(order)
+            self.order = np.array(order, dtype=np.int32)
+
+    def __len__(self) -> int:
+        return len(self.order)
+
+    def sample_indices(self, idx: int) -> dict:
+        bag, R = self.bag, self.random
+        real_idx = int(self.order[idx])
+        # __getitem__ (base_fst.py:1197-1210)
+        child = R.choice(bag.parents_children[real_idx]) if self.sampling_scenario == 'parents' else real_idx
+        parent, cat_main = int(bag.children[child][0]), int(bag.children[child][1])
+        cats_dict = dict(bag.parents_cats[parent])
+        cats_on_img = list(cats_dict)
+        # get_query (base_fst.py:793-824): the N - 1 other categories
+        cats = [cat_main]
+        keep = self.cats_to_save_bool.copy()
+        keep[cat_main] = False
+        if self.qry_cats_choice_remove:
+            keep[cats_on_img] = False
+        pool = [int(c) for c in np.nonzero(keep)[0]]
+        if self.qry_cats_choice_random:
+            if len(pool) < self.n_ways - 1:
+                raise NotImplementedError(f'could not select {self.n_ways} categories')
+            other = R.sample(pool, self.n_ways - 1)
+        else:
+            other = pool[:self.n_ways - 1]
+        cats.extend(other)
+        if self.qry_cats_order_shuffle:
+            R.shuffle(cats)
+        cats_real = np.array(cats, dtype=np.int32)
+        # ... the query's instances (base_fst.py:826-846)
+        qry_insts, qry_cats = [], []
+        for c in cats_real:
+            if int(c) not in cats_dict:
+                continue
+            qry_insts.extend(cats_dict[int(c)])
+            qry_cats.extend([int(c)] * len(cats_dict[int(c)]))
+        # get_support (base_fst.py:1052-1080): K instances per category
+        spp = []
+        for c in cats_real:
+            lst = bag.class_lists[int(c)]
+            pool_i = [v for v in lst if v not in qry_insts] if self.delete_qry_insts else lst
+            if self.spp_random:
+                if len(pool_i) < self.k_shots:
+                    raise NotImplementedError(f'could not sample {self.k_shots} instances of category {int(c)}')
+                spp.extend(R.sample(pool_i, self.k_shots))
+            else:
+                spp.extend(pool_i[:self.k_shots])
+        # remap to 0..N-1 (base_fst.py:1243-1246)
+        mapping = np.zeros(int(cats_real.max()) + 1, dtype=np.int32)
+        mapping[cats_real] = np.arange(len(cats_real))
+        qry_cats = np.array(qry_cats, dtype=np.int32)
+        qry_insts = np.array(qry_insts, dtype=np.int32)
+        return dict(idx=idx, qry_child_idx=int(child), idx_parent=parent, cat_id_main=cat_main,
+                    cats_ids_to_sample_real=cats_real.astype(np.int64),
+                    cats_ids_to_sample=mapping[cats_real].astype(np.int64),
+                    qry_insts_ids=qry_insts, qry_cat_ids_real=qry_cats.astype(np.int64),
+                    qry_cat_ids=mapping[qry_cats].astype(np.int64) if len(qry_cats) else np.zeros(0, np.int64),
+                    qry_bboxes=bag.inst_bbox[qry_insts].astype(np.float32).reshape(-1, 4),
+                    spp_insts_ids=np.array(spp).astype(np.int64))
