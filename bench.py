@@ -109,6 +109,12 @@ def parse_args():
                     help='output tile edge of the Winograd form: 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3)')
     ap.add_argument('--resident-inputs', action='store_true',
                     help='not the headline: park the inputs in HBM before timing (no host->device copy in the step)')
+    ap.add_argument('--isolated-steps', default='last',
+                    help="timed steps whose convolution launches are stamped with HIP events while they have the GPU to "
+                         "themselves (queued behind the episodes in flight ON THE GPU, no host drain, the following steps "
+                         "wait for them): 'last' (default: the final step, whose tail runs alone anyway), 'none', or a "
+                         "comma list such as 5,20,35 (profiles/: three spread steps of a 60-step run; each costs the window "
+                         "~1.5 ms of lost overlap)")
     ap.add_argument('--cache-supports', action='store_true',
                     help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
     args = ap.parse_args()
@@ -265,10 +271,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # a bounded collective timeout: a rank that died (or never arrived) must end the job with an error, not leave the
+        # others inside an all-gather for the default 10-30 minutes (tests/test_host_cpu.py::test_a_failing_rank_...)
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get('FGN_BENCH_PG_TIMEOUT', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from fgn_amd import dist as fdist
     from fgn_amd import ops
@@ -319,18 +329,7 @@ def main():
     xfer_mode = int(os.environ.get('FGN_XFER_MODE', '3' if args.batch <= 2 else '0'))
     if args.graphs and xfer_mode:
         model.transfer_stream(xfer_mode)
-    # FGN_BENCH_EMULATE_COMM=1 (one rank, no process group): the stream arrangement of a multi-rank run on ONE GPU - a
-    # communication stream and a second stream standing in for RCCL's internal one are created and used BEFORE the caller
-    # streams, and every step packs its records and copies them on the communication stream behind an event, as the
-    # all-gather's local part would.  What a rank pays for the arrangement itself, without peers (profiles/).
-    emulate_comm = world == 1 and bool(os.environ.get('FGN_BENCH_EMULATE_COMM'))
-    comm_stream = torch.cuda.Stream() if (world > 1 or emulate_comm) else None
-    if emulate_comm:
-        rccl_like = torch.cuda.Stream()
-        for s_ in (comm_stream, rccl_like):
-            with torch.cuda.stream(s_):
-                torch.zeros(1, device=dev).add_(1)
-            s_.synchronize()
+    comm_stream = torch.cuda.Stream() if world > 1 else None
     if world > 1 and backend == 'nccl':
         # RCCL runs a collective on an internal stream of its own, which takes the next hardware queue when it is first
         # used.  One warm-up collective HERE - after the communication stream, before the caller streams exist - gives
@@ -359,7 +358,9 @@ def main():
     # (armed after the warm-up: the counters' values are read once, behind a synchronisation, and counted on the host
     # from there - every launch bumps its stream's counter exactly once)
     phase_counters = torch.zeros(2, device=dev, dtype=torch.int32) if (phase_point and len(ep_streams) == 2) else None
-    phase_armed, phase_base, phase_sent, phase_first_wait = [False], [0, 0], [0, 0], [0]
+    if phase_counters is not None:
+        model.phase_point = phase_point          # which point of the episode sends the mark; the counter travels per call
+    phase_armed, phase_base, phase_sent, phase_skip = [False], [0, 0], [0, 0], set()
     gathered_last = {}
     gather_on_compute = bool(os.environ.get('FGN_BENCH_GATHER_ON_COMPUTE'))
     gather_pool = None
@@ -384,6 +385,7 @@ def main():
                 return fdist.gather_detections(recs, cnts)
         return gather_pool.submit(work)
 
+    gather_events, gather_timed = [], []      # timing events of the collectives (created before the timed region)
     jitter_ms = float(os.environ.get('FGN_BENCH_JITTER_MS', '0'))     # rehearsal: rank r is late once every `world` steps
 
     def launch(i, profile=None):
@@ -396,30 +398,20 @@ def main():
         ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
         try:
             with ctx:
+                mark = None
                 if phase_counters is not None:
                     # phase lock of the two caller streams: this episode starts when the previous one (on the other
                     # stream) has passed its mark; its own mark releases the next one
                     k_ = i % 2
-                    if phase_armed[0] and i >= phase_first_wait[0]:
+                    if phase_armed[0] and i not in phase_skip:
                         ops.phase_wait(phase_counters[1 - k_:2 - k_], phase_base[1 - k_] + phase_sent[1 - k_])
-                    model.phase_counter, model.phase_point = phase_counters[k_:k_ + 1], phase_point
+                    mark = phase_counters[k_:k_ + 1]
                     phase_sent[k_] += 1
                 dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'],
-                                           e['img_shape'], support_code=e['code'], qry_isegmaps=e['qry_isegmaps'])
+                                           e['img_shape'], support_code=e['code'], qry_isegmaps=e['qry_isegmaps'],
+                                           phase_counter=mark)
         finally:
             ops.PROFILE = None
-        if emulate_comm:
-            with ctx:
-                recs, cnts = fdist.pack_detections(dets, max_det)
-                packed = torch.cuda.current_stream().record_event()
-            comm_stream.wait_event(packed)
-            with torch.cuda.stream(comm_stream):
-                rccl_like.wait_stream(comm_stream)
-                with torch.cuda.stream(rccl_like):
-                    gathered_last['emulated'] = (recs.clone(), cnts.clone())
-                comm_stream.wait_stream(rccl_like)
-            recs.record_stream(rccl_like)
-            cnts.record_stream(rccl_like)
         if world > 1:
             # one RCCL all-gather of fixed-size padded records (boxes, scores, labels, mask probabilities) per step.
             # The records are packed on the CALLER stream - five small copies out of the episode's output buffers,
@@ -437,7 +429,15 @@ def main():
             else:
                 comm_stream.wait_event(packed)
                 with torch.cuda.stream(comm_stream):
+                    # the collective's own duration on the communication stream (gather_ms_p50 / p99 of the line: a rank
+                    # that waits for a late peer shows here, not in its compute)
+                    ev = (gather_events.pop(), gather_events.pop()) if len(gather_events) >= 2 else None
+                    if ev is not None:
+                        ev[0].record()
                     gathered_last['g'] = gather(recs, cnts)
+                    if ev is not None and gather_pool is None:
+                        ev[1].record()
+                        gather_timed.append(ev)
                 recs.record_stream(comm_stream)
                 cnts.record_stream(comm_stream)
         return e, dets
@@ -452,39 +452,36 @@ def main():
             latencies.append(time.perf_counter() - pending[2])
         return out
 
-    def run(n_steps, prof=None, prof_steps=(), alone=None, alone_steps=()):
+    def run(n_steps, prof=None, prof_steps=(), alone=None):
         """Software-pipelined: episode i+1 is queued before the results of episode i are packed,
         so host-side result packing overlaps device work.  Every result is still delivered.
         ``prof`` / ``prof_steps``: steps whose conv launches are event-stamped while the pipeline runs as usual;
-        ``alone`` / ``alone_steps``: steps that are event-stamped after the episodes in flight have been packed, so
-        their kernels share the GPU with nothing but their own side stream."""
+        ``alone``: {step: ConvProfile} - steps that are event-stamped while they have the GPU to themselves: the step
+        is queued behind every episode in flight ON THE GPU (its caller stream waits for their completion events; the
+        host does not drain, so the GPU never idles in front of it and its clocks are those of the running pipeline)
+        and the compute of the following steps waits for it; its kernels share the chip with nothing but their own
+        side stream."""
         n_det = n_gt = 0
         pending = []
         last = None
-        stamps = [] if os.environ.get('FGN_BENCH_STEPTIMES') else None
+        alone = alone or {}
         for i in range(n_steps):
             t_a = time.perf_counter()
-            if alone is not None and i in alone_steps:
-                while pending:                      # (nothing is pending when the isolated step is step 0)
-                    last = finish(pending.pop(0))
-                    n_det += sum(len(r['dt_scores']) for r in last)
-                    n_gt += sum(len(r['qry_isegmaps_rle']) for r in last)
-                pending.append(launch(i, alone) + (t_a,))
-                # the following steps are queued at once (no host wait), but their compute waits on the GPU for this
-                # episode: its kernels share the chip with nothing but their own side stream
+            if i in alone:
+                st_i = ep_streams[i % len(ep_streams)]
+                st_i = st_i if st_i is not None else torch.cuda.current_stream()
+                for pe in pending:
+                    st_i.wait_event(pe[1][0]['host_ready'])
+                phase_skip.update(range(i, i + 1 + args.inflight))     # no phase wait in or right behind an isolated step
+                pending.append(launch(i, alone[i]) + (t_a,))
                 for st in ep_streams:
                     (st if st is not None else torch.cuda.current_stream()).wait_event(pending[-1][1][0]['host_ready'])
             else:
                 pending.append(launch(i, prof if (prof is not None and i in prof_steps) else None) + (t_a,))
-            t_b = time.perf_counter()
             if len(pending) > args.inflight:
                 last = finish(pending.pop(0))
                 n_det += sum(len(r['dt_scores']) for r in last)
                 n_gt += sum(len(r['qry_isegmaps_rle']) for r in last)
-            if stamps is not None:
-                stamps.append((round((t_b - t_a) * 1e3, 2), round((time.perf_counter() - t_b) * 1e3, 2)))
-        if stamps:
-            print('step (launch ms, finish ms):', stamps, file=sys.stderr, flush=True)
         while pending:
             last = finish(pending.pop(0))
             n_det += sum(len(r['dt_scores']) for r in last)
@@ -495,38 +492,40 @@ def main():
     # pin the host slots and let every kernel set its LDS attribute once
     prime = ops.ConvProfile()
     n_setup = 2 * len(ep_streams)         # every caller stream captures its hipGraph here, not in a warm-up / timed step
+    model.stamp_capacity = 256            # the captured graphs carry launch records of the dominant kernel (ops.read_stamps)
     run(n_setup + 1, prof=prime, prof_steps=(n_setup,))   # also creates the first timing events (a one-time ~40 ms in HIP)
-    # timing events for the instrumented steps are created here, outside the timed region (HIP grows
-    # its event pool in bursts that cost tens of ms)
-    # Two timed steps are instrumented.  The FIRST one runs alone (the pipeline is empty after the warm-up barrier, and
-    # the compute of the following steps waits on the GPU for it): its kernel durations are those of a kernel that has
-    # the GPU to itself and its own side stream - what `roofline` reports and what a rocprofv3 kernel trace (which
-    # serialises dispatches) shows.  One step in the middle is instrumented while
-    # two episodes overlap on the two caller streams, the way every other step runs: kernels of different episodes
-    # then share the CUs, each launch takes longer and the step takes less (`roofline.overlapped`).
-    alone_steps = [0]
-    # the overlapped instrumented step (informational: `roofline.overlapped`) runs in the WARM-UP when there is room for it
-    # (two episodes overlap from the second warm-up step on): measured r04, an eagerly launched, event-stamped step in the
-    # middle of a 20-step window costs it ~1.5 % (187.6 -> 190.4 img/s over three alternating runs); the isolated step, which
-    # `roofline` itself comes from, stays inside the timed region where the number is defined
-    overlapped_in_warmup = args.warmup >= 3
-    prof_steps = [] if overlapped_in_warmup else ([args.steps // 2] if args.steps >= 4 else [])
-    if os.environ.get('FGN_BENCH_NO_ISOLATED'):      # tuning aid: what the isolated instrumented step costs
+    # Instrumentation (timing events are created here, outside the timed region: HIP grows its event pool in bursts that
+    # cost tens of ms):
+    #  * every launch of the dominant kernel in EVERY timed step adds its span to a launch record inside the kernel
+    #    (in-kernel 100 MHz stamps, first workgroup start -> last workgroup end: works inside the replayed graphs at two
+    #    atomics per workgroup) -> `roofline.timed_window`, the regime a rocprofv3 kernel trace of this command sees;
+    #  * `--isolated-steps` (default: the last timed step) are launched eagerly with a start / stop HIP event pair per
+    #    convolution launch while they have the GPU to themselves -> `roofline.achieved / frac / by_kernel /
+    #    launch_classes`.  Rounds 1-4 instrumented step 0 - the first work after the barrier's device synchronisation, on
+    #    an idle chip: its launches read 5 % longer than the same launches anywhere else;
+    #  * one warm-up step is event-stamped while episodes overlap (`roofline.overlapped`, informational).
+    if args.isolated_steps == 'none':
         alone_steps = []
-    if os.environ.get('FGN_BENCH_NO_OVERLAPPED'):    # tuning aid: what the overlapped instrumented step costs
-        prof_steps = []
+    elif args.isolated_steps == 'last':
+        alone_steps = [args.steps - 1]
+    else:
+        alone_steps = sorted({int(t) for t in args.isolated_steps.split(',') if t.strip() != '' and 0 <= int(t) < args.steps})
+    overlapped_in_warmup = args.warmup >= 3
+    prof_steps = [] if overlapped_in_warmup else ([args.steps // 2] if args.steps >= 4 and (args.steps // 2) not in alone_steps else [])
     prof = ops.ConvProfile().reserve(2 * len(prime) + 16)            # overlapped step
-    prof_alone = ops.ConvProfile().reserve(2 * len(prime) + 16)      # isolated step -> roofline
-    for ev in prof.pool + prof_alone.pool:
-        ev.record()
+    prof_alone = {i: ops.ConvProfile().reserve(2 * len(prime) + 16) for i in alone_steps}      # isolated steps -> roofline
+    for pr in [prof] + list(prof_alone.values()):
+        for ev in pr.pool:
+            ev.record()
+    if world > 1:
+        gather_events.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 2)))
+        for ev in gather_events:
+            ev.record()
     # (Measured, r03: a Python garbage collection never fell into the 20-step window - collector on / off 185.5 / 184.4
     # img/s -, but an IDLE GPU right before it does cost: a gc.collect() of ~50 ms placed between the warm-up and the timed
     # region took 2.5 % off the 20 steps, the first of which then ran at a lower clock.  Nothing sits between the warm-up
     # steps and the timed region but the barrier.)
-    preheat = int(os.environ.get('FGN_BENCH_PREHEAT', '0'))        # tuning aid: extra untimed steps in front of the warm-up
-    if preheat:
-        run(preheat)
-    if overlapped_in_warmup and not os.environ.get('FGN_BENCH_NO_OVERLAPPED'):
+    if overlapped_in_warmup:
         run(args.warmup, prof, prof_steps=[max(1, args.warmup - 3)])     # two more steps queue up behind it
     else:
         run(args.warmup)
@@ -543,14 +542,19 @@ def main():
     if phase_counters is not None:
         phase_base[:] = [int(v) for v in phase_counters.tolist()]
         phase_sent[:] = [0, 0]
-        phase_armed[0] = not os.environ.get('FGN_BENCH_PHASE_NOWAIT')      # (=1: the marks are sent, nobody waits: A/B aid)
-        # the steps queued behind the isolated instrumented step (they wait on the GPU for it) carry no phase wait
-        phase_first_wait[0] = (max(alone_steps) + 1 + args.inflight) if alone_steps else 0
+        phase_armed[0] = True
+        phase_skip.clear()
+    graphs = list(model._graphs.values())
+    for ge in graphs:                      # launch records: forget the set-up and warm-up replays
+        if ge.stamps is not None:
+            ops.reset_stamps(ge.stamps)
+    gather_timed.clear()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     # in the instrumented steps every convolution kernel launch stamps a start/stop HIP event pair
     # (hipExtLaunchKernelGGL: the kernel's own duration, on the stream it runs on)
     latencies.clear()
-    n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps, alone=prof_alone, alone_steps=alone_steps)
+    n_d, n_gt, last_results = run(args.steps, prof, prof_steps=prof_steps, alone=prof_alone)
     timed_latencies = sorted(latencies)
     barrier()
     dt = time.perf_counter() - t0
@@ -612,13 +616,66 @@ def main():
                           'frac_of_hbm_peak': round(c['bytes'] / c['ms'] / 1e9 / 8.0, 4)}
         return res
     by_kernel_overlapped = per_kernel(prof)
-    by_kernel = per_kernel(prof_alone) if len(prof_alone) else by_kernel_overlapped
+    # the isolated steps: the dominant kernel is the one with the largest summed duration; `roofline` reports the MEDIAN
+    # isolated step (by the dominant kernel's time), the others as min / max
+    iso = {i: per_kernel(pr) for i, pr in prof_alone.items() if len(pr)}
+    dom_votes = [max(bk, key=lambda n: bk[n]['ms']) for bk in iso.values()]
+    dom_name = max(set(dom_votes), key=dom_votes.count) if dom_votes else \
+        (max(by_kernel_overlapped, key=lambda n: by_kernel_overlapped[n]['ms']) if by_kernel_overlapped else 'none')
+    iso_order = sorted(iso, key=lambda i: iso[i].get(dom_name, {'ms': 0.0})['ms'])
+    med_step = iso_order[len(iso_order) // 2] if iso_order else None
+    by_kernel = iso[med_step] if med_step is not None else by_kernel_overlapped
+    records_med = prof_alone[med_step] if med_step is not None else prof
     tot = dict(ms=sum(k['ms'] for k in by_kernel.values()), launches=sum(k['launches'] for k in by_kernel.values()),
                issued=sum(k['issued'] for k in by_kernel.values()), direct=sum(k['direct'] for k in by_kernel.values()))
-    dom_name = max(by_kernel, key=lambda n: by_kernel[n]['ms']) if by_kernel else 'none'
     dom = by_kernel.get(dom_name, dict(ms=0.0, launches=0, issued=0.0, direct=0.0))
     tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     achieved = tf(dom['issued'], dom['ms'])
+    iso_table = [dict(step=i, kernel_ms=round(iso[i][dom_name]['ms'], 4), launches=iso[i][dom_name]['launches'],
+                      avg_launch_us=round(iso[i][dom_name]['ms'] * 1e3 / max(iso[i][dom_name]['launches'], 1), 2),
+                      frac=round(tf(iso[i][dom_name]['issued'], iso[i][dom_name]['ms']) / PEAK_FP32_MFMA_TFLOPS, 4),
+                      all_conv_ms=round(sum(k['ms'] for k in iso[i].values()), 3))
+                 for i in sorted(iso) if dom_name in iso[i]]
+
+    # ---- the dominant kernel over the WHOLE timed window: the launch records inside the captured graphs --------------
+    window = None
+    sites = [rec for rec in records_med if rec['kernel'] == dom_name]
+    if model.use_graphs and sites and dom_name == 'conv_pw_persist_kernel':
+        per_site = [dict(executions=0, total_us=0.0, min_us=None, max_us=None) for _ in sites]
+        # (a graph whose captured launch sequence does not have the isolated step's launch sites cannot be matched)
+        ok = bool(graphs) and all(ge.stamps is not None and ge.stamp_count == len(sites) for ge in graphs)
+        for ge in graphs if ok else []:
+            for a, b in zip(per_site, ops.read_stamps(ge.stamps, ge.stamp_count)):
+                a['executions'] += b['executions']
+                a['total_us'] += b['total_us']
+                if b['executions']:
+                    a['min_us'] = b['min_us'] if a['min_us'] is None else min(a['min_us'], b['min_us'])
+                    a['max_us'] = b['max_us'] if a['max_us'] is None else max(a['max_us'], b['max_us'])
+        n_exec = sum(a['executions'] for a in per_site)
+        if ok and n_exec:
+            flop_of = []
+            for rec in sites:
+                n = rec['n_img'] if rec['n_img_dev'] is None else min(rec['n_img'], int(rec['n_img_dev'].item()))
+                flop_of.append(rec['flop_issued'] * n)
+            w_us = sum(a['total_us'] for a in per_site)
+            w_flop = sum(f * a['executions'] for f, a in zip(flop_of, per_site))
+            ratios = sorted(a['total_us'] / a['executions'] / (1e3 * r['e0'].elapsed_time(r['e1']))
+                            for a, r in zip(per_site, sites) if a['executions'] and r['e0'].elapsed_time(r['e1']) > 0)
+            window = {'what': 'EVERY launch of the kernel in the timed region (all steps, both caller streams, inside the '
+                              'replayed hipGraphs): span first workgroup start -> last workgroup end on the 100 MHz '
+                              'in-kernel clock, folded into a launch record by the kernel itself (fgn_profile_stamps); the '
+                              'regime a rocprofv3 kernel trace of this command reports',
+                      'launches': n_exec, 'launch_sites_per_step': len(sites),
+                      'executions_per_site': sorted({a['executions'] for a in per_site}),
+                      'avg_launch_us': round(w_us / n_exec, 2),
+                      'achieved': round(w_flop / w_us / 1e6, 2),
+                      'frac': round(w_flop / w_us / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
+                      'site_us_over_isolated_event_us': ({'p10': round(ratios[len(ratios) // 10], 3), 'p50': round(ratios[len(ratios) // 2], 3),
+                                                          'p90': round(ratios[(len(ratios) * 9) // 10], 3)} if ratios else None),
+                      'largest_site': (lambda k: {'avg_us': round(per_site[k]['total_us'] / per_site[k]['executions'], 1),
+                                                  'min_us': per_site[k]['min_us'], 'max_us': per_site[k]['max_us'],
+                                                  'isolated_event_us': round(1e3 * sites[k]['e0'].elapsed_time(sites[k]['e1']), 1)})(
+                          max(range(len(sites)), key=lambda k: flop_of[k]))}
 
     # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh), corrected per MI355X_MICROARCH.md; PMC collection serialises kernels, so it is
@@ -674,7 +731,14 @@ def main():
                                                 'max': round(max(per_rank_dt) / args.steps * 1e3, 3),
                                                 'all': [round(v / args.steps * 1e3, 3) for v in per_rank_dt]},
                        'rank_placement': rank_info,
-                       'gather_stream': (('emulated (one rank)' if emulate_comm else None) if world == 1 else 'caller' if gather_on_compute else 'communication'),
+                       # the collective's own duration on the communication stream, per timed step (HIP events around it)
+                       'gather_ms': ((lambda v: {'p50': round(v[len(v) // 2], 3), 'p99': round(v[min(len(v) - 1, int(len(v) * 0.99))], 3),
+                                                 'max': round(v[-1], 3), 'steps': len(v)})(
+                           sorted(a.elapsed_time(b) for a, b in gather_timed)) if gather_timed else None),
+                       # with one rank there is no process group, no communication stream and no collective: `python bench.py`
+                       # and `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` run the same code
+                       'single_rank_path': 'no process group / communication stream / collective' if world == 1 else None,
+                       'gather_stream': (None if world == 1 else 'caller' if gather_on_compute else 'communication'),
                        'phase_lock': phase_point or None,
                        'jitter_ms_rehearsal': jitter_ms or None,
                        'peak_memory_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
@@ -703,12 +767,16 @@ def main():
                          # `frac` is the average over ALL launches of the kernel; split by the bound a launch has on
                          # paper (arithmetic intensity against 157.3 TF/s / 8 TB/s): the MFMA-bound ones against the
                          # MFMA peak, the output-bound 1x1 convolutions of layer1 / layer2 against the HBM peak
-                         'launch_classes': launch_classes(prof_alone if len(prof_alone) else prof, dom_name),
+                         'launch_classes': launch_classes(records_med, dom_name),
                          'profiled_steps': n_prof_steps,
                          'timing': 'start/stop HIP events stamped by each launch of the kernel itself (hipExtLaunchKernelGGL) on '
-                                   'its own stream, in the first step of the timed region, which runs with no other episode '
-                                   'beside it (its own side stream only; the next steps are queued behind it on the GPU): '
-                                   'the duration a rocprofv3 kernel trace reports',
+                                   'its own stream, in the isolated timed step(s) below: queued behind the episodes in flight '
+                                   'on the GPU (no idle chip in front of them), no other episode beside them (their own side '
+                                   'stream only).  With several isolated steps this is the MEDIAN one',
+                         'isolated_steps': iso_table,
+                         'frac_min_max_over_isolated_steps': ([min(r_['frac'] for r_ in iso_table), max(r_['frac'] for r_ in iso_table)]
+                                                              if iso_table else None),
+                         'timed_window': window,
                          # the same kernel in a mid-run step, while two episodes overlap on the two caller streams (the
                          # way the other steps run): launches share the CUs with another episode's kernels
                          'overlapped': (lambda k: None if not k or not k['ms'] else {

@@ -78,7 +78,9 @@ def fgn_r50_c4_scratch_config(n_ways: int = 3, k_shots: int = 3) -> dict:
     """The from-scratch backbone variant (fgn_r50_c4_scratch.py:5-30): 3-conv deep stem, average-pool
     shortcuts, GroupNorm(32) instead of frozen BatchNorm.  Heads and test_cfg are the same."""
     cfg = fgn_r50_c4_config(n_ways, k_shots)
-    cfg['backbone'].update(deep_stem=True, avg_down=True, norm='GN', gn_groups=32)
+    # ref_num_stages: fgn_r50_c4_scratch.py:12 builds THREE stages (no layer4 module at all); the DenseCL config builds four
+    # and main.py:402-405 only stops walking the last one (fgn_amd.train.reference_param_order)
+    cfg['backbone'].update(deep_stem=True, avg_down=True, norm='GN', gn_groups=32, ref_num_stages=3)
     return cfg
 
 

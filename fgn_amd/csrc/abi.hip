@@ -1,6 +1,6 @@
 // ABI version of libfgn_hip.so (bumped whenever include/fgn_hip.h changes incompatibly) and the profiler hook.
 #include "common.h"
-extern "C" int fgn_abi_version(void) { return 25; }
+extern "C" int fgn_abi_version(void) { return 26; }
 
 thread_local hipEvent_t fgn_prof_start = nullptr;
 thread_local hipEvent_t fgn_prof_stop = nullptr;
@@ -12,6 +12,20 @@ extern "C" int fgn_profile_next_launch(void* start_event, void* stop_event) {
     fgn_prof_start = reinterpret_cast<hipEvent_t>(start_event);
     fgn_prof_stop = reinterpret_cast<hipEvent_t>(stop_event);
     return FGN_OK;
+}
+
+thread_local unsigned long long* fgn_stamp_base = nullptr;
+thread_local int fgn_stamp_next = 0, fgn_stamp_cap = 0;
+// Arm (records != NULL) / disarm the calling thread for launch records (common.h).  `records`: device memory, `capacity`
+// records of 8 x uint64, initialised by the caller to {~0, 0, 0, 0, ~0, 0, 0, 0} = {first start of the execution in
+// flight, sum of durations, workgroups arrived, executions, shortest, longest, -, -} in 10 ns ticks.  Returns the number
+// of records handed out since the last arming (the launches recorded, in launch order).
+extern "C" int fgn_profile_stamps(void* records, int capacity) {
+    const int used = fgn_stamp_next;
+    fgn_stamp_base = reinterpret_cast<unsigned long long*>(records);
+    fgn_stamp_cap = records ? capacity : 0;
+    fgn_stamp_next = 0;
+    return used;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,6 +33,17 @@ extern thread_local hipEvent_t fgn_prof_stop;
         }                                                                                                  \
     } while (0)
 
+// Launch records of the dominant kernel that work INSIDE a replayed hipGraph (fgn_profile_stamps): while the calling
+// thread is armed, every launch of conv_pw_persist_kernel is handed the next 64-byte record of the caller's device
+// buffer; the kernel folds each of its executions into that record (first workgroup start -> last workgroup end on the
+// 100 MHz s_memrealtime clock: count, sum, min, max).  nullptr: the kernel executes no stamp instruction.
+extern thread_local unsigned long long* fgn_stamp_base;
+extern thread_local int fgn_stamp_next, fgn_stamp_cap;
+static inline unsigned long long* fgn_next_stamp_record() {
+    if (!fgn_stamp_base || fgn_stamp_next >= fgn_stamp_cap) return nullptr;
+    return fgn_stamp_base + 8 * (size_t)fgn_stamp_next++;
+}
+
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the
 // function object of the CURRENT device (a process may drive several GPUs): set once per (call site, device);
 // `done_mask` is a static of the call site, bit d = device d done.

@@ -22,10 +22,14 @@
 //     kernel only): the mask-head support-vector multiply (fgn_roi_head.py:379); `a_img_div` lets several
 //     output images read one input image (AG-RPN guidance, fgn_ag_rpn_head.py:44, when the direct form is
 //     used; the Winograd form applies it in its input transform).
-//   Kernels   :  conv_igemm_dma_kernel (64x64 tile, optional split-K; modes generic / point-wise + grouped
-//     Winograd GEMM / stem), conv_igemm_kernel (register-staged loader, [rows][32 + 4 pad] LDS layout, for the
-//     fused input scale when a layer does not take the Winograd form); the dispatcher at the bottom of the
-//     file picks one per launch.
+//   Kernels   :  conv_pw_persist_kernel (point-wise launches with more output tiles than resident workgroups: the
+//     dominant kernel of an episode), conv_igemm_dma_kernel (64x64 / 128x128 tile, optional split-K; modes generic /
+//     point-wise + grouped Winograd GEMM / stem), conv_igemm_dma_pair_kernel (one layer on two tensors),
+//     conv_igemm_kernel (register-staged loader, [rows][32 + 4 pad] LDS layout, for the fused input scale when a
+//     layer does not take the Winograd form); the dispatcher at the bottom of the file picks one per launch.
+//   Everything here is on the default path.  The kernels that were built, measured and NOT adopted (Stream-K, the
+//   generalised persistent kernel in eight tile shapes, their tuning entry point) live in
+//   tools/micro/conv_pw_experiments.inc and are compiled only with -DFGN_EXPERIMENTS (tools/micro/build_experiments.sh).
 #include "common.h"
 #include <cstdlib>
 
@@ -54,20 +58,11 @@ struct ConvParams {
     // the slabs in a fixed order (deterministic) and applies the epilogue.
     float* ws;
     int splits, kt_per_split;
-    // last-arriver reduce (LDS-DMA kernel): one zero-initialised int32 per output tile.  Every split of a tile publishes
-    // its partial tile to its slab with write-through stores and takes a ticket; the workgroup that draws the last
-    // ticket sums the slabs in slab order (the order splitk_epilogue_kernel uses: bit-identical results), applies the
-    // epilogue and returns the ticket to zero.  nullptr: the reduce runs as splitk_epilogue_kernel.
-    int32_t* tickets;
-    // tile scheduler of conv_pw_persist2_kernel: FGN_SCHED_WORDS zero-initialised int32 (one counter per XCD share of the
-    // tiles, 64 bytes apart), zero again when the launch has run.  Workgroups take their first tile by index and pull
-    // every further one from the counter of their share, so the last tiles of a launch go to whichever workgroups are
-    // free first instead of to a fixed 1/3 of them.  nullptr: fixed tile order (tile, tile + grid, ...).
-    int32_t* sched;
-    // Stream-K launch (conv_pw_streamk_kernel; 0 = off): tiles [0, sk_dp) are walked whole, the rest is shared out in
-    // ranges of sk_U K-tiles; `ws` holds the pieces (2 slabs of 64x64 floats per workgroup), `tickets` one word per
-    // remaining tile (the words of `sched` behind the scheduler's: FGN_SCHED_WORDS covers both).
-    int sk_U, sk_dp;
+#ifdef FGN_EXPERIMENTS      // tools/micro/conv_pw_experiments.inc (not part of libfgn_hip.so)
+    int32_t* tickets;        // Stream-K: one zero-initialised word per remaining tile
+    int32_t* sched;          // tile scheduler of conv_pw_persist2_kernel: zero-initialised counters
+    int sk_U, sk_dp;         // Stream-K launch: tiles [0, sk_dp) whole, the rest in ranges of sk_U K-tiles
+#endif
     unsigned x_bytes, w_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
     // grouped GEMM (Winograd; 64x64 kernel, point-wise mode): rows [g*grp_rows, (g+1)*grp_rows) use the weight
     // matrix at w + g*grp_w_stride floats; within a group only the first `valid` rows are computed, valid =
@@ -75,15 +70,14 @@ struct ConvParams {
     // device.  grp_rows == 0: plain convolution.
     int grp_rows, grp_valid, grp_items, grp_rows_per_item, grp_w_stride;
     const int32_t* grp_count_dev;
+    // launch record (conv_pw_persist_kernel; fgn_profile_stamps): 8 x uint64 in device memory or nullptr
+    unsigned long long* stamp;
 };
 
 #ifndef CONV_DMA_STAGES
 #define CONV_DMA_STAGES 2
 #endif
 constexpr int BK = 32;
-constexpr int FGN_TILE_SCHED_WORDS = 8 * 16;         // conv_pw_persist2_kernel's counters
-constexpr int FGN_STREAMK_MAX_GRID = 1280;           // tickets of conv_pw_streamk_kernel: one per remaining tile < grid
-constexpr int FGN_SCHED_WORDS = FGN_TILE_SCHED_WORDS + FGN_STREAMK_MAX_GRID;
 constexpr int LDS_STRIDE = 36;  // floats
 
 // Diagnostic build only (-DCONV_CLOCK_STAMPS, tools/micro/gemm_clock.hip; the product library never defines it): one
@@ -115,17 +109,6 @@ __device__ unsigned long long g_clock_stamps[16384 * 6];
 #else
 #define CLOCK_STAMP_BEGIN() do { } while (0)
 #define CLOCK_STAMP_END(slot) do { } while (0)
-#endif
-// Diagnostic build only (-DCONV_PW_EXP=<bits>, tools/micro/gemm_clock.hip; WRONG results, timing only): take one
-// ingredient at a time out of the K loop of conv_pw_persist_kernel to see what its saturated rate is made of.
-// 1: no LDS-DMA inside the K loop (the loop re-reads the tile's first K-tile), 2: no s_barrier in the K loop,
-// 4: the wait before the barrier does not wait for the DMA (lgkmcnt only), 8: operand fragments are read from LDS once
-// per output tile instead of once per 16-deep step, 16: the epilogue does not store to global memory, 32: the first
-// K-tile of the next output tile is not fetched, 64: no epilogue at all, 256: one M0 write per K-tile instead of four.
-#ifdef CONV_PW_EXP
-#define PW_EXP(bit) ((CONV_PW_EXP) & (bit))
-#else
-#define PW_EXP(bit) 0
 #endif
 
 // Per-thread staging state, fixed for the whole K loop: for each A row this thread loads, the
@@ -453,27 +436,6 @@ __device__ __forceinline__ void lds_dma16_s(const i32x4& rs, unsigned lds_base, 
         : "v"(voff), "s"(lds_base), "s"(rs), "s"(soff)
         : "memory", "m0");
 }
-// (diagnostic builds only: the same without the M0 write - the data lands where the previous load's did)
-__device__ __forceinline__ void lds_dma16_s_nom0(const i32x4& rs, unsigned voff, unsigned soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-// 16-byte store that writes through the XCD's L2 to device-coherent memory (sc1 = agent scope): how a workgroup publishes
-// a split-K partial tile that a workgroup on another XCD will read (the L2s of the eight XCDs are not coherent with each
-// other for plain stores; a release fence instead would write back the whole L2).
-__device__ __forceinline__ void store_wt16(float* ptr, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
-}
-// 16-byte load at agent scope (sc1): reads what store_wt16 of a workgroup on another XCD published, without the
-// acquire fence's invalidation of this XCD's L2 (which holds the operands every other workgroup is streaming).  The
-// caller waits with wait_loads() before it uses the value.
-__device__ __forceinline__ f32x4 load_agent16(const float* ptr) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
 __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
     i32x4 r;
@@ -713,11 +675,15 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            // stem (MODE 2): a 16-byte chunk is one PIXEL of the NHWC4 image and .w its fourth channel, which is zero in the
+            // image and in the packed weights alike - a quarter of the MFMAs of the 7x7 stem would multiply zeros
+            if (!STEM) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
         }
         // tile t+1 must have landed (own DMAs counted; the barrier covers the other waves');
         // with NSTAGE == 3 the DMAs of tile t+2 stay in flight across the barrier.
@@ -754,63 +720,6 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
         constexpr int RPP = 256 / C4;                 // rows per pass
         const int c4 = t % C4, rr = t / C4;
         const int n = n0 + c4 * 4;
-        if (BM == 64 && BN == 64 && p.splits > 1 && p.tickets) {      // (only the 64x64 tile is ever split)
-            // ---- split-K with the reduce inside the launch (see ConvParams::tickets)
-            const size_t slab = (size_t)p.n_img * HoWo * p.Cout;
-            if (n < p.Cout) {
-                float* dst = p.ws + (size_t)by * slab;
-#pragma unroll
-                for (int k = 0; k < BM / RPP; ++k) {
-                    const int row = rr + RPP * k;
-                    const int m = m0 + row;
-                    if (m >= M) continue;
-                    const float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
-                    store_wt16(dst + (size_t)m * p.Cout + n, f32x4{v.x, v.y, v.z, v.w});
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's slab stores are acknowledged
-            // flag word behind the C tile (a static __shared__ variable would push dynamic + static LDS past the
-            // 160 KB the launcher allows the function)
-            volatile int* const s_last = reinterpret_cast<volatile int*>(smem + BM * PITCH);
-            __syncthreads();                                        // ... and every thread's
-            if (t == 0) {
-                int32_t* tk = p.tickets + (tile_m * p.n_tiles_n + tile_n);
-                const int got = atomicAdd(tk, 1);
-                *s_last = got == p.splits - 1;
-                if (got == p.splits - 1) *tk = 0;                   // ready for the next launch
-            }
-            __syncthreads();
-            if (!*s_last) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale lines: the other slabs come from memory
-            if (n < p.Cout) {
-                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
-                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
-#pragma unroll 2
-                for (int k = 0; k < BM / RPP; ++k) {
-                    const int m = m0 + rr + RPP * k;
-                    if (m >= M) continue;
-                    const size_t o = (size_t)m * p.Cout + n;
-                    float4 a = *reinterpret_cast<const float4*>(p.ws + o);
-                    for (int z = 1; z < p.splits; ++z) {
-                        const float4 b = *reinterpret_cast<const float4*>(p.ws + (size_t)z * slab + o);
-                        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                    }
-                    // same operation order as splitk_epilogue_kernel: scale, shift, residual, ReLU
-                    if (p.scale) { a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w; }
-                    if (p.shift) { a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w; }
-                    if (p.residual) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
-                        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
-                    }
-                    if (p.relu) {
-                        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                    }
-                    *reinterpret_cast<float4*>(p.y + o) = a;
-                }
-            }
-            return;
-        }
         if (n < p.Cout) {
             const bool raw = p.splits > 1;
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -915,18 +824,18 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_pair_kernel(con
 // ------------------------------------------------------------------------------------------------
 // Persistent point-wise kernel: the 64x64 LDS-DMA kernel in MODE 1 (1x1 / stride 1 convolutions and the grouped
 // Winograd GEMM) with a workgroup that walks several output tiles (tile, tile + grid, ...).  These launches have
-// K of 256..1024, i.e. 8..32 K-tiles per output tile: in the one-tile-per-workgroup kernel every workgroup of a
+// K of 64..1024, i.e. 2..32 K-tiles per output tile: in the one-tile-per-workgroup kernel every workgroup of a
 // round runs its prologue (index math, first DMA, its latency) and its epilogue (accumulators -> LDS -> 16 B
 // stores) at the same time as its neighbours, so the matrix pipe idles ~20 % of a launch.  Here the first K-tile of
 // the NEXT output tile is in flight (LDS stage 0) while the epilogue of the current one drains through stage 1, and
 // workgroups drift out of phase after their first tile.
 // LDS: [stage 0: 16 KB][stage 1: 16 KB]; the C tile of the epilogue (64 x 64 floats) lives in stage 1: 32 KB per
-// workgroup, five workgroups per CU.
+// workgroup, four workgroups per CU (1024 persistent workgroups: measured best against 512 / 768 / 1280, r03).
+// Wave tile 32x32 as 2x2 tiles of v_mfma_f32_16x16x4_f32: lane group g = lane >> 4 reads the 16-byte chunk 4*kk + g
+// of its row, MFMA j contracts k in {j, 4+j, 8+j, 12+j} of the 16-deep step (same cycles per FLOP as the 32x32x2 form,
+// +3..5 % on the large GEMMs: a different power / clock point of the chip, MI355X_MICROARCH.md "DVFS give-back" 7).
+// Where its rate goes (r04: in-kernel stamps, Stream-K, decomposition by diagnostic builds): DESIGN.md 4.1.
 // ------------------------------------------------------------------------------------------------
-// M16: the 32x32 wave tile as 2x2 tiles of v_mfma_f32_16x16x4_f32 (lane group g = lane>>4 reads the 16-byte chunk
-// 4*kk+g of its row: MFMA j contracts k in {j, 4+j, 8+j, 12+j} of the 16-deep step) instead of one
-// v_mfma_f32_32x32x2_f32 tile - same cycles per FLOP, a different power / clock point of the chip.
-template <bool M16>
 __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
     constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
     constexpr int A_LD = 2, B_LD = 2;
@@ -952,19 +861,6 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
     // tile -> (m0, n0): XCD-contiguous runs of logical tiles (the grid is a multiple of 8), optional banded raster
     const int nq = total_tiles >> 3, nr = total_tiles & 7;
     auto coords = [&](int tile, int& m0, int& n0) -> bool {
-        if (p.band_nt < 0) {
-            // experiment (FGN_WG_POS_INNER=1, tools/gemm_time.py): the raster a GEMM with a FUSED Winograd output
-            // transform would be forced into - one workgroup per (row block, channel block) walking the 36 tile
-            // positions; the grid is band_mt * n_tiles_n workgroups and `tile` advances by the grid, i.e. by one position
-            const int per_pos = p.band_mt * p.n_tiles_n;
-            const int g = tile / per_pos, rest = tile - g * per_pos;
-            const int mi = rest / p.n_tiles_n;
-            m0 = (g * p.band_mt + mi) * BM;
-            n0 = (rest - mi * p.n_tiles_n) * BN;
-            if (m0 >= M) return false;
-            if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
-            return true;
-        }
         const int xcd = tile & 7, idx = tile >> 3;
         const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
         int tile_m = bid / p.n_tiles_n;
@@ -1010,13 +906,6 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         const unsigned ko = (unsigned)(kt * BK * 4);
         // the K-tile's byte offset rides in the instruction's scalar offset: no vector arithmetic per K-tile (round 4:
         // +1..2.5 % on the large GEMMs against `voff + ko` with its select for out-of-range rows and M0 save / restore)
-        if (PW_EXP(256)) {          // one M0 write per K-tile instead of four (what a per-wave contiguous LDS layout would issue)
-            lds_dma16_s(x_rs, sa, a_voff[0], ko);
-            lds_dma16_s_nom0(x_rs, a_voff[1], ko);
-            lds_dma16_s_nom0(w_rs, b_voff[0], ko);
-            lds_dma16_s_nom0(w_rs, b_voff[1], ko);
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
         const unsigned sb = sa + BM * 128;
@@ -1024,24 +913,35 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * 32 * 128, b_voff[i], ko);
     };
 
-    const int frag_row = lane & 31, half = lane >> 5;
-    const int rswz = (frag_row >> 1) & 7;
-    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const float* const rd_a = smem + (wm * WM + r16) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
     float* const cbase = smem + STAGE;              // stage 1
 
+    // launch record (fgn_profile_stamps): this execution's span = first workgroup start -> the arrival of the last
+    // workgroup, folded into the record by that workgroup - works inside a replayed hipGraph, where no HIP event can be
+    // placed around one kernel.  Two atomics per workgroup; nothing at all when the launch carries no record.
+    if (p.stamp && t == 0) atomicMin(p.stamp, __builtin_amdgcn_s_memrealtime());
+    auto leave = [&]() {
+        if (!p.stamp || t != 0) return;
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (atomicAdd(p.stamp + 2, 1ull) != (unsigned long long)gridDim.x - 1) return;
+        const unsigned long long d = t1 - atomicExch(p.stamp, ~0ull);      // (re-armed for the next replay)
+        atomicExch(p.stamp + 2, 0ull);
+        atomicAdd(p.stamp + 1, d);
+        atomicAdd(p.stamp + 3, 1ull);
+        atomicMin(p.stamp + 4, d);
+        atomicMax(p.stamp + 5, d);
+    };
     int m0, n0;
     int tile = next_active(blockIdx.x, m0, n0);
-    if (tile < 0) return;
+    if (tile < 0) { leave(); return; }
     CLOCK_STAMP_BEGIN();
     set_offsets(m0, n0);
     issue_tile(0, 0);
 
     while (true) {
-        f32x16 acc;
         f32x4 acc4[2][2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1051,73 +951,34 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
-        float4 af_x[2][2], bf_x[2][2];                  // PW_EXP(8) only
-        if (PW_EXP(8)) {
-            const int r16 = lane & 15, g16 = lane >> 4;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            const float* As = rd_a + cur * STAGE;
+            const float* Bs = rd_b + cur * STAGE;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                float4 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int row = r16 + 16 * i;
+                    const int row = r16 + 16 * i;                       // row within the wave's 32
                     const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
-                    af_x[kk][i] = *reinterpret_cast<const float4*>(rd_a + (row - frag_row) * BK + pc);
-                    bf_x[kk][i] = *reinterpret_cast<const float4*>(rd_b + (row - frag_row) * BK + pc);
+                    af[i] = *reinterpret_cast<const float4*>(As + 16 * i * BK + pc);
+                    bf[i] = *reinterpret_cast<const float4*>(Bs + 16 * i * BK + pc);
                 }
-        }
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT && !PW_EXP(1)) issue_tile(kt + 1, cur ^ 1);
-            asm volatile("" ::: "memory");
-            const float* As = rd_a + (PW_EXP(1) ? 0 : cur) * STAGE;
-            const float* Bs = rd_b + (PW_EXP(1) ? 0 : cur) * STAGE;
-            if (M16) {
-                const int r16 = lane & 15, g16 = lane >> 4;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    float4 af[2], bf[2];
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int row = r16 + 16 * i;                       // row within the wave's 32
-                        const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
-                        if (PW_EXP(8)) {
-                            af[i] = af_x[kk][i]; bf[i] = bf_x[kk][i];
-                            asm volatile("" : "+v"(af[i].x), "+v"(bf[i].x));      // keep the loop's MFMAs in the loop
-                            continue;
-                        }
-                        af[i] = *reinterpret_cast<const float4*>(As + (row - frag_row) * BK + pc);
-                        bf[i] = *reinterpret_cast<const float4*>(Bs + (row - frag_row) * BK + pc);
+                    for (int j = 0; j < 2; ++j) {
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
                     }
-#ifdef CONV_PERSIST_SETPRIO       // measured (r03, -DCONV_PERSIST_SETPRIO): isolated-step fraction 0.69 -> 0.67, step time equal
-                    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc4[i][j], 0, 0, 0);
-                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc4[i][j], 0, 0, 0);
-                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc4[i][j], 0, 0, 0);
-                            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
-                        }
-#ifdef CONV_PERSIST_SETPRIO
-                    __builtin_amdgcn_s_setprio(0);
-#endif
-                }
-            } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int pc = ((kk * 2 + half) ^ rswz) * 4;
-                const float4 af = *reinterpret_cast<const float4*>(As + pc);
-                const float4 bf = *reinterpret_cast<const float4*>(Bs + pc);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
-            }
             }
             // see conv_igemm_dma_kernel: reads of stage `cur` must have returned before the barrier is signalled
-            if (PW_EXP(4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (!PW_EXP(2)) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
         // both stages are free now.  Next output tile: its first K-tile goes to stage 0 while the epilogue below
@@ -1127,33 +988,17 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         const int next = next_active(tile + gridDim.x, nm0, nn0);
         if (next >= 0) {
             set_offsets(nm0, nn0);
-            if (!PW_EXP(32)) issue_tile(0, 0);
+            issue_tile(0, 0);
         }
-        if (PW_EXP(64)) {           // no epilogue at all: the accumulators are only kept alive
+        // 16x16 C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc4[i][j]));
-            if (next < 0) break;
-            tile = next; m0 = nm0; n0 = nn0;
-            continue;
-        }
-        if (M16) {
-            // 16x16 C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-            const int r16 = lane & 15, g16 = lane >> 4;
+            for (int j = 0; j < 2; ++j) {
+                float* cw = cbase + (wm * WM + 16 * i + 4 * g16) * PITCH + wn * WN + 16 * j + r16;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float* cw = cbase + (wm * WM + 16 * i + 4 * g16) * PITCH + wn * WN + 16 * j + r16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
-                }
-        } else {
-            float* cw = cbase + (wm * WM + 4 * half) * PITCH + wn * WN + frag_row;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
-        }
+                for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
+            }
         __syncthreads();
         {
             constexpr int C4 = BN / 4, RPP = 256 / C4;       // 16 float4 per row, 16 rows per pass
@@ -1181,8 +1026,7 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
                     if (p.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    if (PW_EXP(16)) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                    else *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+                    *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
                 }
             }
         }
@@ -1190,547 +1034,15 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         tile = next; m0 = nm0; n0 = nn0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    leave();
     CLOCK_STAMP_END(blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Stream-K form of the persistent point-wise kernel (round 4): the work of a launch is tiles x K-tiles, and what
-// conv_pw_persist_kernel and the one-tile-per-workgroup kernel lose is the LAST round of whole tiles - 7.31 rounds take
-// 7.75 tile times on the AG-RPN GEMM, 408 tiles on 1024 resident slots leave 104 CUs with one workgroup and 152 with two.
-// Here the tiles beyond the last full round of the grid (all tiles, when there are fewer than workgroups) are shared out by
-// K-TILE: the workgroups of an XCD split the K-tiles of that XCD's remaining tiles into equal contiguous ranges of
-// U <= KT K-tiles (a range touches at most two tiles).  A workgroup first runs its range, then its whole tiles
-// (tile = blockIdx, + grid, ...) exactly as conv_pw_persist_kernel does.
-//   * A range that covers a tile from K-tile 0 to KT - 1 ends in the normal epilogue.
-//   * Any other range is a PIECE: the raw 64x64 partial sums go to the workgroup's private slab (ws + (2 * blockIdx +
-//     seg) * 4096 floats, seg = 0 if the workgroup's range starts inside this tile, 1 if it started in the tile before)
-//     with write-through stores, then one ticket per tile (tickets[remaining tile], zero before the launch and again
-//     after it).  The workgroup that draws the last ticket of a tile sums the pieces IN K ORDER (its own from LDS, the
-//     others from their slabs: a fixed order whoever comes last - deterministic results), applies the epilogue and
-//     stores.  Nobody waits for anybody: no workgroup depends on another one being resident.
-// Remaining tiles keep the XCD-contiguous numbering of the whole-tile walk: tile = dp_tiles + 8 * rl + xcd is the rl-th
-// remaining tile of XCD xcd's run, and only that XCD's workgroups (blockIdx & 7 == xcd) work on it, so its operands stay
-// in one L2.  Per output element the K order is that of the other kernels; the grouping of the partial sums differs
-// (pieces are summed after the fact), so results agree with conv_pw_persist_kernel to rounding, not bitwise.
-// LDS: the two stages + one flag word.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void conv_pw_streamk_kernel(const ConvParams p, const int total_tiles,
-                                                                 const int dp_tiles, const int U, const int dbg) {
-    constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
-    constexpr int A_LD = 2, B_LD = 2;
-    constexpr int STAGE = (BM + BN) * BK;          // floats
-    constexpr int PITCH = BN;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
-    int grp_valid = p.grp_valid;
-    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
-
-    const int col4 = t & 7, row0 = t >> 3;
-    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
-    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
-    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
-    const int KT = p.K / BK;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
-    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
-    constexpr unsigned OOB = 0x7ffffff0u;
-
-    const int nq = total_tiles >> 3, nr = total_tiles & 7;
-    auto coords = [&](int tile, int& m0, int& n0) -> bool {
-        const int xcd = tile & 7, idx = tile >> 3;
-        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
-        int tile_m = bid / p.n_tiles_n;
-        int tile_n = bid - tile_m * p.n_tiles_n;
-        if (p.band_nt > 0) {
-            const int per_grp = p.band_mt * p.n_tiles_n;
-            const int grp = bid / per_grp;
-            int r = bid - grp * per_grp;
-            const int per_band = p.band_mt * p.band_nt;
-            const int band = r / per_band;
-            r -= band * per_band;
-            const int mi = r / p.band_nt;
-            tile_m = grp * p.band_mt + mi;
-            tile_n = band * p.band_nt + (r - mi * p.band_nt);
-        }
-        m0 = tile_m * BM;
-        n0 = tile_n * BN;
-        if (m0 >= M) return false;
-        if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
-        return true;
-    };
-
-    // this workgroup's share of the remaining tiles' K-tiles: units [u, u_end) of its XCD's run, unit = rl * KT + kt
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int rem_x = nq + (xcd < nr ? 1 : 0) - (dp_tiles >> 3);
-    const int units_x = rem_x * KT;
-    int u = min(li * U, units_x);
-    const int u_end = min(u + U, units_x);
-    int dp_cur = blockIdx.x;
-    struct Item { int m0, n0, k0, k1, rl; };            // rl < 0: a whole tile of the fixed walk
-    auto next_item = [&](Item& it) -> bool {
-        while (u < u_end) {
-            const int rl = u / KT, k0 = u - rl * KT, k1 = min(KT, k0 + (u_end - u));
-            u += k1 - k0;
-            if (coords(dp_tiles + rl * 8 + xcd, it.m0, it.n0)) {
-                it.k0 = k0; it.k1 = k1; it.rl = rl;
-                return true;
-            }
-        }
-        for (; dp_cur < dp_tiles; dp_cur += gridDim.x)
-            if (coords(dp_cur, it.m0, it.n0)) {
-                it.k0 = 0; it.k1 = KT; it.rl = -1;
-                dp_cur += gridDim.x;
-                return true;
-            }
-        return false;
-    };
-
-    unsigned a_voff[A_LD], b_voff[B_LD];
-    auto set_offsets = [&](int m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int m = m0 + row0 + 32 * i;
-            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
-        }
-        int b0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
-        if (p.grp_rows) b0 += (m0 / p.grp_rows) * p.grp_w_stride * 4;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * 32 * p.K * 4);
-    };
-    auto issue_tile = [&](int kt, int stage) {
-        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
-        const unsigned ko = (unsigned)(kt * BK * 4);
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
-        const unsigned sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * 32 * 128, b_voff[i], ko);
-    };
-
-    const int frag_row = lane & 31;
-    const float* const rd_a = smem + (wm * WM + frag_row) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + frag_row) * BK;
-    float* const cbase = smem + STAGE;              // stage 1
-    volatile int* const s_last = reinterpret_cast<volatile int*>(smem + 2 * STAGE);
-    const int r16 = lane & 15, g16 = lane >> 4;
-    constexpr int C4 = BN / 4, RPP = 256 / C4;       // 16 float4 per row, 16 rows per pass
-    const int c4 = t % C4, rr = t / C4;
-
-    Item it;
-    if (!next_item(it)) return;
-    CLOCK_STAMP_BEGIN();
-    set_offsets(it.m0, it.n0);
-    issue_tile(it.k0, 0);
-
-    while (true) {
-        f32x4 acc4[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
-        for (int kt = it.k0; kt < it.k1; ++kt) {
-            if (kt + 1 < it.k1) issue_tile(kt + 1, cur ^ 1);
-            asm volatile("" ::: "memory");
-            const float* As = rd_a + cur * STAGE;
-            const float* Bs = rd_b + cur * STAGE;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                float4 af[2], bf[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = r16 + 16 * i;
-                    const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
-                    af[i] = *reinterpret_cast<const float4*>(As + (row - frag_row) * BK + pc);
-                    bf[i] = *reinterpret_cast<const float4*>(Bs + (row - frag_row) * BK + pc);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc4[i][j], 0, 0, 0);
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc4[i][j], 0, 0, 0);
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc4[i][j], 0, 0, 0);
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
-                    }
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
-        }
-        // both stages are free: the first K-tile of the next item goes to stage 0 while this one drains through stage 1
-        Item nx;
-        const bool more = next_item(nx);
-        if (more) {
-            set_offsets(nx.m0, nx.n0);
-            issue_tile(nx.k0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float* cw = cbase + (wm * WM + 16 * i + 4 * g16) * PITCH + wn * WN + 16 * j + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
-            }
-        __syncthreads();
-        const int n = it.n0 + c4 * 4;
-        // rl0 / rl1: first and last workgroup (index within the XCD) with K-tiles of this remaining tile
-        const bool piece = it.rl >= 0 && (it.k0 != 0 || it.k1 != KT);
-        bool reduce = false;
-        int i0 = 0, i1 = 0;
-        if (piece && dbg == 1) {
-            // timing experiment (tuning knob 5): pieces are dropped - WRONG results, the cost of the exchange by difference
-        } else if (piece) {
-            float* slab = p.ws + ((size_t)blockIdx.x * 2 + ((li * U) / KT == it.rl ? 0 : 1)) * (BM * BN);
-#pragma unroll
-            for (int k = 0; k < BM / RPP; ++k) {
-                const int row = rr + RPP * k;
-                const float4 v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
-                store_wt16(slab + row * BN + c4 * 4, f32x4{v.x, v.y, v.z, v.w});
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's slab stores are acknowledged
-            __syncthreads();                                        // ... and every thread's
-            i0 = (it.rl * KT) / U;
-            i1 = (it.rl * KT + KT - 1) / U;
-            if (t == 0) {
-                int32_t* tk = p.tickets + (it.rl * 8 + xcd);
-                const int got = atomicAdd(tk, 1);
-                *s_last = got == i1 - i0;
-                if (got == i1 - i0) *tk = 0;                        // ready for the next launch
-            }
-            __syncthreads();
-            reduce = *s_last != 0;
-        }
-        if ((!piece || reduce) && n < p.Cout) {
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
-            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
-            float4 res[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int m = it.m0 + rr + RPP * k;
-                res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.residual && m < M) res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
-            }
-            f32x4 sum[4];
-            if (reduce) {
-                // pieces in K order, whoever came last: the own one from LDS, the others from their slabs (agent-scope loads)
-                for (int i = i0; i <= i1; ++i) {
-                    f32x4 b[4];
-                    if (i == li) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const f32x4*>(cbase + (rr + RPP * k) * PITCH + c4 * 4);
-                    } else {
-                        const float* src = p.ws + ((size_t)(i * 8 + xcd) * 2 + ((i * U) / KT == it.rl ? 0 : 1)) * (BM * BN) + c4 * 4;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) b[k] = load_agent16(src + (rr + RPP * k) * BN);
-                        wait_loads(b[0], b[1], b[2], b[3]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (i == i0) sum[k] = b[k];
-                        else sum[k] += b[k];
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = rr + RPP * k;
-                const int m = it.m0 + row;
-                if (m >= M) continue;
-                float4 v;
-                if (reduce)
-                    v = make_float4(sum[k][0], sum[k][1], sum[k][2], sum[k][3]);
-                else
-                    v = *reinterpret_cast<const float4*>(cbase + row * PITCH + c4 * 4);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
-                if (p.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
-            }
-        }
-        if (!more) break;
-        it = nx;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CLOCK_STAMP_END(blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent point-wise kernel, second form (round 4): any workgroup tile BM x BN out of wave tiles WM x WN
-// (NW = (BM/WM)*(BN/WN) waves), v_mfma_f32_16x16x4_f32 only, and NO LDS round trip in the epilogue.
-//   * The MFMA is issued with its operands SWAPPED (B fragment as "A", A fragment as "B"): the 16x16 result tile is then
-//     C^T, i.e. lane (c = lane & 15, g = lane >> 4) holds C[m = c][n = 4g .. 4g+3] in its four accumulator registers -
-//     four CONSECUTIVE output channels of one row.  The epilogue is one 16-byte global store (and one 16-byte residual
-//     load, one 16-byte scale / shift load) per 16x16 tile straight from the accumulators: no C tile in LDS, no
-//     epilogue barriers, and the LDS the C tile took is free for a larger operand tile.  (Same products in the same k
-//     order as the unswapped form: bit-identical sums.)
-//   * Larger tiles: a 64x64 wave tile reads half the LDS bytes per MFMA of the 32x32 one and a 128x128 workgroup tile
-//     takes half the L2 -> LDS bytes per MFMA of the 64x64 one - the two largest levers on the clock the chip holds in
-//     an MFMA-dense loop (cdna_hip_programming.md 5.4 rule 28) - and runs one barrier per 4096 MFMA cycles of a wave
-//     instead of one per 1024.
-//   * Fragments of the next 16-deep step are read while the current step's MFMAs issue (two register sets).
-//   * Grouped GEMM with any BM: a row tile never straddles two groups (tiles are numbered per group, the last one of a
-//     group is cut at the group's valid rows), so t_pad stays a multiple of 64.
-// Tile order: XCD-contiguous runs of logical tiles; inside a group band-major ([band][row tile][channel tile of the
-// band]) so that a band's weights stay in the XCD's L2 while the group's rows stream past.
-// ------------------------------------------------------------------------------------------------
-struct Persist2Geom {
-    int mt;          // row tiles per group (grouped GEMM) or of the whole launch
-    int band_nt;     // channel tiles per band (divides n_tiles_n; n_tiles_n = no banding)
-    int n_groups;    // 1 for a plain convolution
-};
-
-template <int BM, int BN, int WM, int WN, int NST, int MINW>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void conv_pw_persist2_kernel(const ConvParams p,
-                                                                                          const Persist2Geom gm,
-                                                                                          const int total_tiles) {
-    constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
-    constexpr int RPP = NW * 8;                        // tile rows one DMA pass of the workgroup covers
-    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
-    constexpr int TI = WM / 16, TJ = WN / 16;
-    constexpr int STAGE = (BM + BN) * BK;              // floats
-    constexpr int LOADS = A_LD + B_LD;                 // LDS-DMA wave-instructions per K-tile and wave
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
-    static_assert(NST >= 2 && NST <= 4 && (NST - 2) * LOADS <= 63, "stages");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv / NWN, wn = wv - wm * NWN;
-    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
-    int grp_valid = p.grp_valid;
-    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
-    grp_valid = min(grp_valid, p.grp_rows);
-
-    const int col4 = t & 7, row0 = t >> 3;
-    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
-    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
-    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
-    const int KT = p.K / BK;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
-    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
-    constexpr unsigned OOB = 0x7ffffff0u;
-
-    // Tiles are cut into 8 contiguous shares (one per value of blockIdx & 7: workgroups b and b + 8 sit on one XCD, so a
-    // share's operands stay in that XCD's L2); `idx` counts inside this workgroup's share.
-    const int nq = total_tiles >> 3, nr = total_tiles & 7;
-    const int xk = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
-    const int size_x = nq + (xk < nr ? 1 : 0);
-    const int start_x = xk < nr ? xk * (nq + 1) : nr * (nq + 1) + (xk - nr) * nq;
-    const int per_grp = gm.mt * p.n_tiles_n, per_band = gm.mt * gm.band_nt;
-    // tile of the share -> (first row, row limit, first channel, weight offset of the group); false: nothing to compute
-    auto coords = [&](int idx, int& m0, int& mend, int& n0, int& wofs) -> bool {
-        const int bid = start_x + idx;
-        const int grp = bid / per_grp;
-        int r = bid - grp * per_grp;
-        const int band = r / per_band;
-        r -= band * per_band;
-        const int mi = r / gm.band_nt;
-        n0 = (band * gm.band_nt + (r - mi * gm.band_nt)) * BN;
-        if (p.grp_rows) {
-            m0 = grp * p.grp_rows + mi * BM;
-            mend = min(M, grp * p.grp_rows + grp_valid);
-            wofs = grp * p.grp_w_stride;
-        } else {
-            m0 = mi * BM;
-            mend = M;
-            wofs = 0;
-        }
-        return m0 < mend;
-    };
-    // ---- tile scheduler.  The first tile of a workgroup is idx = blockIdx >> 3 (no atomic in front of the first DMA);
-    // every further one is nwg_x + (old value of the share's counter).  Every workgroup ends on exactly one pull past
-    // the end of its share, so a share sees max(size_x - nwg_x, 0) + nwg_x pulls in all and the workgroup that draws
-    // the last of them returns the counter to zero for the next launch (kernel boundaries order it).  One lane pulls;
-    // the value reaches the other waves through one LDS word behind a workgroup barrier.
-    int* const s_next = reinterpret_cast<int*>(smem + NST * STAGE);
-    int32_t* const counter = p.sched ? p.sched + xk * 16 : nullptr;
-    const int pulls_x = max(size_x - nwg_x, 0) + nwg_x;
-    int pulled = 0;                                    // lane 0 of the workgroup: the value its pending pull returned
-    auto pull_issue = [&]() {
-        if (t == 0) pulled = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto pull_publish = [&]() {                        // lane 0: hand the pulled index to the workgroup (LDS word)
-        if (t == 0) {
-            if (pulled == pulls_x - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_next[0] = nwg_x + pulled;
-        }
-    };
-    // blocking form (start of a workgroup whose own first tile is empty, or a pulled tile without valid rows - a launch
-    // cut short by a device-side count): pull until a tile with work or the end of the share
-    auto pull_blocking = [&](int& m0, int& mend, int& n0, int& wofs) -> int {
-        int idx;
-        do {
-            pull_issue();
-            pull_publish();
-            __syncthreads();
-            idx = __builtin_amdgcn_readfirstlane(s_next[0]);
-            __syncthreads();
-        } while (idx < size_x && !coords(idx, m0, mend, n0, wofs));
-        return idx;
-    };
-
-    unsigned a_voff[A_LD], b_voff[B_LD];
-    auto set_offsets = [&](int m0, int mend, int n0, int wofs) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int m = m0 + row0 + RPP * i;
-            a_voff[i] = m < mend ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
-        }
-        const int b0 = (wofs + (n0 + row0) * p.K + src_c4 * 4) * 4;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * RPP * p.K * 4);
-    };
-    auto issue_tile = [&](int kt, int stage) {
-        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
-        const unsigned ko = (unsigned)(kt * BK * 4);
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * RPP * 128, a_voff[i], ko);
-        const unsigned sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * RPP * 128, b_voff[i], ko);
-    };
-
-    const int r16 = lane & 15, g16 = lane >> 4;
-    // fragment read: row (base + 16 i + r16), 16-byte chunk (4 kk + g16) ^ swizzle(row); the swizzle of row r is
-    // (r >> 1) & 7 and the bases are multiples of 16, so it depends on r16 alone
-    const int fswz = (r16 >> 1) & 7;
-    const float* const rd_a = smem + (wm * WM + r16) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
-
-    int m0 = 0, mend = 0, n0 = 0, wofs = 0;
-    int idx = blockIdx.x >> 3;
-    if (counter) {
-        if (!(idx < size_x && coords(idx, m0, mend, n0, wofs))) idx = pull_blocking(m0, mend, n0, wofs);
-    } else {
-        while (idx < size_x && !coords(idx, m0, mend, n0, wofs)) idx += nwg_x;
-    }
-    if (idx >= size_x) return;
-    CLOCK_STAMP_BEGIN();
-    set_offsets(m0, mend, n0, wofs);
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < KT) issue_tile(s, s);
-
-    while (true) {
-        f32x4 acc[TI][TJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // NST LDS stages: K-tiles kt + 1 .. kt + NST - 2 are in flight while tile kt is multiplied and tile kt + NST - 1
-        // is issued.  One barrier per K-tile, at its top: behind it tile kt has landed for every wave (own DMAs by the
-        // counted vmcnt - completion is in issue order, so "at most (NST - 2) * LOADS outstanding" means tile kt is in;
-        // stores of the previous epilogue and the scheduler's atomic only make that wait longer, never shorter) and
-        // every wave has finished reading the stage of tile kt - 1, which tile kt + NST - 1 overwrites.  With one or
-        // two workgroups on a CU (launches of few tiles, and the last round of every launch) a K-tile is ~1100
-        // MFMA cycles against a DMA latency of 2000-3000: two stages leave the pipe idle two thirds of the time
-        // (measured r04: a lone workgroup needs ~3300 cycles per K-tile), the deeper ring covers it.
-        int cur = 0;
-        for (int kt = 0; kt < KT; ++kt) {
-            if (NST > 2 && kt + NST - 2 < KT) {
-                if (NST == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LOADS) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kt == 0 && counter) pull_issue();        // the next tile's index arrives under this tile's K loop
-            if (kt + NST - 1 < KT) {
-                int st = cur + NST - 1;
-                if (st >= NST) st -= NST;
-                issue_tile(kt + NST - 1, st);
-            }
-            if (kt == KT - 1 && counter) pull_publish(); // ... and is handed to the workgroup behind the barrier after the loop
-            asm volatile("" ::: "memory");
-            const float* As = rd_a + cur * STAGE;
-            const float* Bs = rd_b + cur * STAGE;
-            f32x4 af[2][TI], bf[2][TJ];
-            const int pc0 = ((0 * 4 + g16) ^ fswz) * 4, pc1 = ((1 * 4 + g16) ^ fswz) * 4;
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(As + 16 * i * BK + pc0);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bs + 16 * j * BK + pc0);
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[1][i] = *reinterpret_cast<const f32x4*>(As + 16 * i * BK + pc1);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[1][j] = *reinterpret_cast<const f32x4*>(Bs + 16 * j * BK + pc1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                // k-slot e of the 16-deep step over ALL accumulators before slot e + 1: an accumulator sees its next
-                // MFMA TI*TJ issues later (dependent latency 40 cycles, issue 32); operands swapped: the accumulator
-                // holds C^T (see the header of this kernel)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
-            }
-            cur = cur + 1 == NST ? 0 : cur + 1;
-        }
-        // every wave is done with the last stage (and lane 0's hand-off word is visible) before the next tile's first
-        // K-tiles are issued: they fly while this tile's accumulators are stored
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int em0 = m0, emend = mend, en0 = n0;
-        int nm0 = 0, nmend = 0, nn0 = 0, nwofs = 0;
-        int next;
-        if (counter) {
-            next = __builtin_amdgcn_readfirstlane(s_next[0]);
-            if (next < size_x && !coords(next, nm0, nmend, nn0, nwofs)) next = pull_blocking(nm0, nmend, nn0, nwofs);
-        } else {
-            next = idx + nwg_x;
-            while (next < size_x && !coords(next, nm0, nmend, nn0, nwofs)) next += nwg_x;
-        }
-        if (next < size_x) {
-            set_offsets(nm0, nmend, nn0, nwofs);
-#pragma unroll
-            for (int s = 0; s < NST - 1; ++s)
-                if (s < KT) issue_tile(s, s);
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int n = en0 + wn * WN + 16 * j + 4 * g16;
-            if (n >= p.Cout) continue;                                   // Cout % 4 == 0 (checked by the launcher)
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
-            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
-            // all residual rows of this channel block first (TI independent 16-byte loads in flight), then the arithmetic
-            float4 res[TI];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int m = em0 + wm * WM + 16 * i + r16;
-                res[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.residual && m < emend) res[i] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int m = em0 + wm * WM + 16 * i + r16;
-                if (m >= emend) continue;
-                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w;
-                if (p.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
-            }
-        }
-        if (next >= size_x) break;
-        idx = next; m0 = nm0; mend = nmend; n0 = nn0; wofs = nwofs;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CLOCK_STAMP_END(blockIdx.x);
-}
+#ifdef FGN_EXPERIMENTS
+#define FGN_EXP_PART 1       // kernels and tuning state
+#include "../../tools/micro/conv_pw_experiments.inc"
+#undef FGN_EXP_PART
+#endif
 
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
@@ -1766,48 +1078,19 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
     }
 }
 
-// persistent grid of conv_pw_persist_kernel: 4 workgroups per CU (measured best: 768 / 1024 / 1280 below), a multiple of 8 (XCDs);
-// FGN_PW_PERSIST=0 turns the persistent kernel off (tuning aid, tools/)
-static int persist_blocks() {
-    static const int n = getenv("FGN_PW_PERSIST") ? atoi(getenv("FGN_PW_PERSIST")) : 1024;
-    return n / 8 * 8;
-}
+// persistent grid of conv_pw_persist_kernel: 4 workgroups per CU (measured best, r03: 512 / 768 / 1280 workgroups lose
+// 7 / 3 / 3 % of the pipelined step), a multiple of 8 (XCDs)
+static constexpr int persist_blocks() { return 1024; }
 
-// Stream-K plan (conv_pw_streamk_kernel) for a point-wise launch of `tiles` 64x64 output tiles with KT K-tiles each.
-// g_sk_mode 0: never; 1: launches with more tiles than resident workgroups whose last round is at most g_sk_fill_pct
-// per cent full; 2: also launches of g_sk_min_tiles .. grid tiles (today's one-tile-per-workgroup launches); 3: every
-// eligible launch.  Tuning knobs 2..4 of fgn_conv2d_tune.
-static int g_sk_mode = getenv("FGN_STREAMK") ? atoi(getenv("FGN_STREAMK")) : 0;
-static int g_sk_fill_pct = getenv("FGN_STREAMK_FILL") ? atoi(getenv("FGN_STREAMK_FILL")) : 85;
-static int g_sk_debug = 0;
-static int g_sk_min_tiles = getenv("FGN_STREAMK_MIN_TILES") ? atoi(getenv("FGN_STREAMK_MIN_TILES")) : 320;
-static size_t streamk_ws_bytes() { return (size_t)persist_blocks() * 2 * 64 * 64 * sizeof(float); }
-static bool plan_streamk(long long tiles, int KT, int* dp_tiles, int* U) {
-    const int G = persist_blocks();
-    if (g_sk_mode <= 0 || G <= 0 || G > FGN_STREAMK_MAX_GRID || KT < 4 || tiles <= 0 || tiles >= (1ll << 30)) return false;
-    const int dp = (int)(tiles / G) * G;
-    const int rem = (int)(tiles - dp);
-    if (rem == 0) return false;
-    if (g_sk_mode < 3) {
-        if (rem * 100ll > (long long)g_sk_fill_pct * G) return false;       // a nearly full round gains nothing
-        if (dp == 0 && (g_sk_mode < 2 || tiles < g_sk_min_tiles)) return false;
-    }
-    const int nq = (int)(tiles >> 3), nr = (int)(tiles & 7);
-    const int rem_max = nq + (nr ? 1 : 0) - dp / 8;                         // remaining tiles of the longest XCD run
-    const int per = cdiv(rem_max * KT, G / 8);
-    *U = std::max(per, std::min(KT, 4));                                    // <= KT: rem_max <= G / 8
-    *dp_tiles = dp;
-    return true;
-}
 
 // split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
 static int plan_splits(long long M, int Cout, int KT, int tile_hint, bool pw = false) {
     if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
     if (Cout % 4) return 1;
-    if (g_sk_mode == 3 && tile_hint == 0 && pw) return 1;   // Stream-K for every eligible 1x1 launch (tools/, tests)
+#ifdef FGN_EXPERIMENTS
+    if (g_sk_mode == 3 && tile_hint == 0 && pw) return 1;   // Stream-K for every eligible 1x1 launch (tools/)
+#endif
     const long long blocks = ((M + 63) / 64) * cdiv(Cout, 64);
-    static const int forced = getenv("FGN_CONV_SPLITS") ? atoi(getenv("FGN_CONV_SPLITS")) : 0;   // tuning aid (tools/)
-    if (forced > 0) return std::max(1, std::min(forced, KT / 2));
     // Measured on the point-wise layers of a cfg3 episode (tools/split_time.py, r03): a 16-deep K loop (Cin 512) never
     // repays the slabs and the reduce launch (support layer2 conv1 22.3 us unsplit / 26.9 split 4, the 9-RoI shared
     // head's conv3 14.1 / 15.2); with 32 K-tiles a split pays only below ~320 workgroups (query layer3 conv1, 264
@@ -1826,7 +1109,7 @@ static int plan_splits(long long M, int Cout, int KT, int tile_hint, bool pw = f
 
 // banded raster when the launch's weights exceed the L2 budget (see ConvParams::band_nt)
 static void set_band(ConvParams& p, int BM, int BN, int m_tiles) {
-    static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
+    constexpr long long budget = 2048 * 1024;       // bytes of weights per band: half an XCD's L2
     const long long per_nt = (long long)BN * (p.K / p.splits) * 4;
     p.band_nt = 0; p.band_mt = 0;
     if (budget > 0 && per_nt * p.n_tiles_n > budget) {
@@ -1837,6 +1120,12 @@ static void set_band(ConvParams& p, int BM, int BN, int m_tiles) {
     }
 }
 
+#ifdef FGN_EXPERIMENTS
+#define FGN_EXP_PART 2       // launchers and the hooks the dispatcher below calls
+#include "../../tools/micro/conv_pw_experiments.inc"
+#undef FGN_EXP_PART
+#endif
+
 template <int BM, int BN, int WM, int WN, int MW>
 static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t stream) {
     ConvParams p = p0;
@@ -1844,8 +1133,6 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     const int m_tiles = cdiv(M_max, BM);
     const dim3 grid(m_tiles * p.n_tiles_n, p.splits);
     set_band(p, BM, BN, m_tiles);
-    // the in-launch reduce lives in the LDS-DMA kernel's 16-byte epilogue
-    if (p.in_scale || p.x_bytes == 0 || cin4 || (p.Cout & 3) != 0 || (p.splits <= 1 && p.sk_U == 0)) p.tickets = nullptr;
     const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static unsigned long long lds_ok[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, true, MW>), &lds_ok[0]);
@@ -1864,36 +1151,20 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         const bool pw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.a_img_div == 1;
         if (cin4)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 2>), grid, dim3(256), dlds, stream, p);
+#ifdef FGN_EXPERIMENTS
         else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && p.sk_U > 0 && p.ws && p.tickets) {
-            static unsigned long long sk_ok = 0ull;
-            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_streamk_kernel), &sk_ok);
-            if (attr != hipSuccess) return (int)attr;
-            const size_t sklds = (size_t)2 * (64 + 64) * BK * sizeof(float) + 16;
-            FGN_LAUNCH_TIMED(conv_pw_streamk_kernel, dim3(persist_blocks()), dim3(256), sklds, stream, p, (int)grid.x,
-                             p.sk_dp, p.sk_U, g_sk_debug);
-        } else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && persist_blocks() > 0 &&
-                 (int)grid.x > persist_blocks()) {
+            const int rc = fgn_exp_launch_streamk(p, (int)grid.x, stream);
+            if (rc != FGN_OK) return rc;
+        }
+#endif
+        else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && (int)grid.x > persist_blocks()) {
             // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel)
             static unsigned long long pk_ok = 0ull;
-            static unsigned long long pk16_ok = 0ull;
-            static const int m16 = getenv("FGN_PW_M16") ? atoi(getenv("FGN_PW_M16")) : 1;   // measured: +3..5 % on the large GEMMs
-            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel<false>), &pk_ok);
-            if (attr == hipSuccess) attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel<true>), &pk16_ok);
+            attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
             if (attr != hipSuccess) return (int)attr;
             const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float);
-            static const int pos_inner = getenv("FGN_WG_POS_INNER") ? atoi(getenv("FGN_WG_POS_INNER")) : 0;
-            if (pos_inner && p.grp_rows) {
-                p.band_nt = -1;
-                p.band_mt = p.grp_rows / 64;
-                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<true>, dim3(p.band_mt * p.n_tiles_n), dim3(256), plds, stream, p,
-                                 (int)grid.x);
-                FGN_LAUNCH_CHECK();
-                return FGN_OK;
-            }
-            if (m16)
-                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<true>, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
-            else
-                FGN_LAUNCH_TIMED(conv_pw_persist_kernel<false>, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
+            p.stamp = fgn_next_stamp_record();
+            FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
         } else if (pw)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
@@ -1905,7 +1176,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     else
         FGN_LAUNCH_TIMED((conv_igemm_kernel<BM, BN, WM, WN, false, MW>), grid, dim3(256), lds, stream, p);
     FGN_LAUNCH_CHECK();
-    if (p.splits > 1 && !p.tickets) {
+    if (p.splits > 1) {
         const size_t total4 = (size_t)M_max * p.Cout / 4;
         const int eg = (int)std::min<size_t>((total4 + 255) / 256, 2048);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(eg), dim3(256), 0, stream, p);
@@ -1914,114 +1185,6 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
     return FGN_OK;
 }
 
-// tuning knobs (fgn_conv2d_tune): forced tile code (-1 = heuristic) and workgroups per CU (0 = the tile's default)
-static int g_pw2_force = getenv("FGN_PW2") ? atoi(getenv("FGN_PW2")) : -1;      // -1: the heuristic below
-static int g_pw2_wgs = getenv("FGN_PW2_WGS") ? atoi(getenv("FGN_PW2_WGS")) : 0;   // 0: the tile's own workgroups per CU
-// ---- conv_pw_persist2_kernel: launch -------------------------------------------------------------------------
-// tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 64x128 (32x64), 3 = 128x64 (64x32), 4 = 64x64 (32x32),
-// 5 = 128x128 with 8 waves of 32x64, 6 = 64x64 with 8 waves of 32x16, 7 = 64x128 with 8 waves of 32x32, 8 = 32x64 (16x32)
-template <int BM, int BN, int WM, int WN, int NST, int WG_MAX>
-static int launch_persist2_t(const ConvParams& p0, int M_max, hipStream_t stream) {
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    constexpr size_t LDS = (size_t)NST * (BM + BN) * BK * sizeof(float) + 16;      // + the scheduler's hand-off word
-    // workgroups per CU: what LDS and the 2048-thread limit admit, at most the tile's own bound
-    constexpr int BY_LDS = (int)(160 * 1024 / LDS), BY_THREADS = 2048 / NT;
-    constexpr int WG_PER_CU = BY_LDS < BY_THREADS ? (BY_LDS < WG_MAX ? BY_LDS : WG_MAX) : (BY_THREADS < WG_MAX ? BY_THREADS : WG_MAX);
-    constexpr int MINW = WG_PER_CU * NT / 256;           // __launch_bounds__: waves per SIMD the grid needs
-    static_assert(WG_PER_CU >= 1, "tile does not fit");
-    ConvParams p = p0;
-    p.n_tiles_n = cdiv(p.Cout, BN);
-    Persist2Geom gm;
-    gm.n_groups = p.grp_rows ? M_max / p.grp_rows : 1;
-    gm.mt = p.grp_rows ? cdiv(p.grp_rows, BM) : cdiv(M_max, BM);
-    static const long long budget = getenv("FGN_BAND_KB") ? atoll(getenv("FGN_BAND_KB")) * 1024 : 2048 * 1024;
-    const long long per_nt = (long long)BN * p.K * 4;
-    gm.band_nt = p.n_tiles_n;
-    if (budget > 0 && per_nt * p.n_tiles_n > budget) {
-        int nb = (int)std::max<long long>(1, budget / per_nt);
-        while (nb > 1 && p.n_tiles_n % nb) --nb;
-        gm.band_nt = nb;
-    }
-    const long long total = (long long)gm.n_groups * gm.mt * p.n_tiles_n;
-    if (total <= 0 || total >= (1ll << 30)) return FGN_ERR_SHAPE;
-    const int per_cu = g_pw2_wgs > 0 ? std::min(g_pw2_wgs, WG_PER_CU) : WG_PER_CU;
-    const int cap = 256 * per_cu;
-    const int grid = (int)std::min<long long>((total + 7) / 8 * 8, cap);
-    static unsigned long long ok = 0ull;
-    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist2_kernel<BM, BN, WM, WN, NST, MINW>), &ok);
-    if (attr != hipSuccess) return (int)attr;
-    FGN_LAUNCH_TIMED((conv_pw_persist2_kernel<BM, BN, WM, WN, NST, MINW>), dim3(grid), dim3(NT), LDS, stream, p, gm, (int)total);
-    FGN_LAUNCH_CHECK();
-    return FGN_OK;
-}
-
-template <int BM, int BN, int WM, int WN, int WG_MAX>
-static int launch_persist2_st(int nst, const ConvParams& p, int M_max, hipStream_t stream) {
-    switch (nst) {
-        case 3: return launch_persist2_t<BM, BN, WM, WN, 3, WG_MAX>(p, M_max, stream);
-        case 4: return launch_persist2_t<BM, BN, WM, WN, 4, WG_MAX>(p, M_max, stream);
-        default: return launch_persist2_t<BM, BN, WM, WN, 2, WG_MAX>(p, M_max, stream);
-    }
-}
-
-// code = tile + 10 * (LDS stages, 0 = 2)
-static int launch_persist2(int code, const ConvParams& p, int M_max, hipStream_t stream) {
-    const int nst = code / 10 ? code / 10 : 2;
-    switch (code % 10) {
-        case 1: return launch_persist2_t<128, 128, 64, 64, 2, 2>(p, M_max, stream);
-        case 2: return launch_persist2_st<64, 128, 32, 64, 3>(nst, p, M_max, stream);
-        case 3: return launch_persist2_t<128, 64, 64, 32, 2, 3>(p, M_max, stream);
-        case 4: return launch_persist2_st<64, 64, 32, 32, 4>(nst, p, M_max, stream);
-        case 5: return launch_persist2_t<128, 128, 32, 64, 2, 2>(p, M_max, stream);
-        case 6: return launch_persist2_st<64, 64, 32, 16, 4>(nst, p, M_max, stream);       // 8 waves on a 64x64 tile
-        case 7: return launch_persist2_st<64, 128, 32, 32, 3>(nst, p, M_max, stream);      // 8 waves on a 64x128 tile
-        case 8: return launch_persist2_st<32, 64, 16, 32, 5>(nst, p, M_max, stream);       // 4 waves on a 32x64 tile
-        default: return FGN_ERR_ARG;
-    }
-}
-
-// Which point-wise launches take conv_pw_persist2_kernel, and with which tile (0: none).  FGN_PW2 forces a code for
-// every eligible launch (tools/gemm_time.py A/B); eligible = 1x1 / stride 1 on the LDS-DMA path, no split-K, no fused
-// input scale, Cout % 4 == 0.
-
-static int pick_persist2(long long M, int Cout, int K, bool grouped, int grp_rows = 0, bool has_residual = false) {
-    if (g_pw2_force >= 0) return g_pw2_force;
-    if (has_residual) return 0;
-    // Measured on MI355X against the round-3 kernels, interleaved in one process (tools/gemm_variants.py;
-    // profiles/r04_gemm_variants_*.txt, four boxes):
-    //  * the large grouped Winograd GEMMs (AG-RPN 36 x 819 x 1024 x 1024, shared head on 300 RoIs 36 x 1200 x 512 x 512)
-    //    on 64x128 tiles, three workgroups per CU: 466-472 us against 476-485, 178-182 against 182-187 (the row
-    //    count of a launch over 768 slots leaves a shorter last round, and half the L2 -> LDS bytes per MFMA of the
-    //    64x64 tile); the smaller grouped GEMMs are equal or slower -> round-3 kernel;
-    //  * plain 1x1 convolutions of 500..1000 64x64-tile equivalents and K >= 512 (first shared-head conv on the
-    //    feature map 4200 x 1024 > 512, on 100 RoIs 4900 x 1024 > 512, layer2 conv1 26016 x 512 > 128) on 32x64 tiles:
-    //    49-51 us against 55-56, 50-51 against 55-57, 38-39 against 40-42 - twice the workgroups of a grid that fills
-    //    two to four slots per CU unevenly;
-    //  * everything else (residual epilogues: the 16-byte stores from the accumulators touch 16 rows x 64 B per
-    //    instruction, the LDS round trip 4 rows x 256 B; small K; full grids of 64x64 tiles): round-3 kernels.
-    // In the pipelined step (two caller streams, three episodes in flight) the other episode's kernels fill a GEMM's
-    // last round, and none of this shows: same-box A/B of bench.py with these choices on / off, r04: B = 1 188.6-190.9
-    // vs 190.1-190.8 img/s, B = 4 212.3-212.5 vs 209.2-211.0, B = 8 213.2 vs 215.5.  The choices stay behind
-    // FGN_PW2_AUTO=1 (and the per-launch knob); the default keeps every launch on the round-3 kernels.
-    static const bool automatic = getenv("FGN_PW2_AUTO") && atoi(getenv("FGN_PW2_AUTO")) != 0;
-    if (!automatic) return 0;
-    const long long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
-    if (grouped) return (grp_rows >= 800 && Cout >= 512 && K >= 512) ? 2 : 0;
-    if (K >= 512 && tiles64 >= 500 && tiles64 <= 1000) return 8;
-    return 0;
-}
-
-// Tuning knobs at run time (tools/: interleaved A/B of kernel variants inside ONE process, cdna_hip_programming.md 5.4
-// rule 24).  knob 0: tile code of conv_pw_persist2_kernel for every eligible point-wise launch (-1 = heuristic,
-// 0 = never); knob 1: its workgroups per CU (0 = the tile's default).  Returns the previous value.
-extern "C" int fgn_conv2d_tune(int knob, int value) {
-    int* k = knob == 0 ? &g_pw2_force : knob == 1 ? &g_pw2_wgs : knob == 2 ? &g_sk_mode : knob == 3 ? &g_sk_fill_pct :
-             knob == 4 ? &g_sk_min_tiles : knob == 5 ? &g_sk_debug : nullptr;
-    if (!k) return FGN_ERR_ARG;
-    const int prev = *k;
-    *k = value;
-    return prev;
-}
 
 // tile choice (measured on MI355X, tools/conv_bench.py): 64x64 everywhere, except when the 128x128 grid is one nearly
 // full round of 2 workgroups per CU (the 1024 -> 512 conv on 300 RoIs: 460 tiles), where half the L2 traffic per
@@ -2054,20 +1217,14 @@ extern "C" int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, 
     int mode = 3;
     if (use_dma && !has_in_scale)
         mode = cin4 ? 2 : (KH == 1 && KW == 1 && stride == 1 && pad == 0 && a_img_div == 1) ? 1 : 0;
-    // conv_pw_persist2_kernel: tile code * 10 + 5 (the grouped Winograd GEMM asks with tile_hint 4)
-    if (mode == 1 && (Cout & 3) == 0 && (tile_hint == 0 || tile_hint == 4) &&
-        (tile_hint == 4 || plan_splits(M, Cout, K / BK, tile_hint, true) == 1)) {
-        // (asked per group: M / 36 rows; F(2x2) launches have 16 groups and never reach the row threshold)
-        const int code = pick_persist2(M, Cout, K, tile_hint == 4, tile_hint == 4 ? (int)(M / 36) : 0, has_residual != 0);
-        if (code) return (code % 10) * 10 + 5;
+#ifdef FGN_EXPERIMENTS
+    {   // conv_pw_persist2_kernel: tile code * 10 + 5; Stream-K launches: tile * 10 + 6
+        const int id = fgn_exp_kernel_id(mode, tile, M, Cout, K, tile_hint, has_residual);
+        if (id) return id;
     }
-    // Stream-K launches: mode 6 (conv_pw_streamk_kernel)
-    if (mode == 1 && tile == 4 && (Cout & 3) == 0 && tile_hint == 0 && plan_splits(M, Cout, K / BK, tile_hint, true) == 1) {
-        int dp = 0, U = 0;
-        if (plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), K / BK, &dp, &U)) return tile * 10 + 6;
-    }
+#endif
     // point-wise launches with more 64x64 output tiles than resident workgroups run on conv_pw_persist_kernel
-    if (mode == 1 && tile == 4 && (Cout & 3) == 0 && persist_blocks() > 0 &&
+    if (mode == 1 && tile == 4 && (Cout & 3) == 0 &&
         ((M + 63) / 64) * cdiv(Cout, 64) > persist_blocks() && plan_splits(M, Cout, K / BK, tile_hint, true) == 1)
         mode = 4;
     return tile * 10 + mode;
@@ -2084,25 +1241,7 @@ extern "C" size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, i
     const bool pw = KH == 1 && KW == 1 && stride == 1 && pad == 0;
     const int s = plan_splits(M, Cout, KT, tile_hint, pw);
     if (s > 1) return (size_t)s * M * Cout * sizeof(float);
-    // Stream-K pieces (conv_pw_streamk_kernel).  Asked without the residual / input-scale flags of the launch, so a
-    // launch that ends up on another kernel may be given a workspace it does not use.
-    int dp = 0, U = 0;
-    if (tile_hint == 0 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && (Cout & 3) == 0 && Cin % BK == 0 &&
-        plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), KT, &dp, &U))
-        return streamk_ws_bytes();
     return 0;
-}
-
-// int32 tickets the in-launch split-K reduce of this layer needs (one per 64x64 output tile; 0: the layer is not split)
-extern "C" int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                                         int pad, int tile_hint) {
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho <= 0 || Wo <= 0 || n_img <= 0) return 0;
-    const long long M = (long long)n_img * Ho * Wo;
-    if (tile_hint >= 100) tile_hint -= 100;
-    if (tile_hint > 0 && tile_hint != 4) return 0;
-    if (plan_splits(M, Cout, cdiv(KH * KW * Cin, BK), tile_hint, KH == 1 && KW == 1 && stride == 1 && pad == 0) <= 1) return 0;
-    return (int)(((M + 63) / 64) * cdiv(Cout, 64));
 }
 
 extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
@@ -2110,7 +1249,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
                                    const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                                    int cout_pad, int KH, int KW, int stride, int pad, int a_img_div,
                                    int relu, int tile_hint, float* splitk_ws, size_t splitk_ws_bytes,
-                                   int32_t* splitk_tickets, int32_t* sched, hipStream_t stream) {
+                                   hipStream_t stream) {
     if (!x || !w_packed || !y) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     const bool cin4 = (Cin == 4);
@@ -2119,8 +1258,10 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (a_img_div < 1 || stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.tickets = splitk_tickets; p.sched = sched;
-    p.sk_U = 0; p.sk_dp = 0;
+    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.stamp = nullptr;
+#ifdef FGN_EXPERIMENTS
+    p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
     p.n_img = n_img; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.a_img_div = a_img_div; p.relu = relu;
     p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -2161,16 +1302,13 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
             p.splits = cdiv(KT, p.kt_per_split);
         }
     }
+#ifdef FGN_EXPERIMENTS
     if (p.splits == 1 && !in_scale && p.x_bytes != 0 && !cin4 && KH == 1 && KW == 1 && stride == 1 && pad == 0 &&
         a_img_div == 1 && (Cout & 3) == 0 && tile_hint == 0) {
-        const int code = pick_persist2(M, Cout, p.K, false, 0, residual != nullptr);
-        if (code) return launch_persist2(code, p, (int)M, stream);
-        int dp = 0, U = 0;
-        if (tile == 4 && splitk_ws && sched && splitk_ws_bytes >= streamk_ws_bytes() &&
-            plan_streamk(((M + 63) / 64) * cdiv(Cout, 64), p.K / BK, &dp, &U)) {
-            p.ws = splitk_ws; p.tickets = sched + FGN_TILE_SCHED_WORDS; p.sk_U = U; p.sk_dp = dp;
-        }
+        int rc = FGN_OK;
+        if (fgn_exp_pointwise(p, M, tile, false, 0, stream, &rc)) return rc;
     }
+#endif
     switch (tile) {
         case 1: return launch_cfg<128, 128, 64, 64, 2>(p, (int)M, cin4, stream);
         case 2: return launch_cfg<64, 128, 32, 64, 3>(p, (int)M, cin4, stream);
@@ -2202,8 +1340,10 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
     for (int i = 0; i < 2; ++i) {
         ConvParams& p = ps[i];
         p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
-        p.in_scale = nullptr; p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = nullptr;
-        p.sk_U = 0; p.sk_dp = 0;
+        p.in_scale = nullptr; p.n_img_dev = nullptr; p.stamp = nullptr;
+#ifdef FGN_EXPERIMENTS
+        p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
         p.n_img = ns[i]; p.H = Hs[i]; p.W = Ws[i]; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
         p.stride = stride; p.pad = pad; p.a_img_div = 1; p.relu = relu;
         p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0;
@@ -2250,19 +1390,9 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
 
-// int32 words of the tile scheduler workspace (`sched` of fgn_conv2d_nhwc_f32 / fgn_winograd_gemm_f32)
-extern "C" int fgn_gemm_sched_words(void) { return FGN_SCHED_WORDS; }
-
-// bytes of the Stream-K workspace `ws` of fgn_winograd_gemm_f32 for this shape (0: the launch does not use one)
-extern "C" size_t fgn_winograd_gemm_workspace_bytes(int t_pad, int Cin, int Cout, int n_groups) {
-    if (t_pad <= 0 || t_pad % 64 || Cin % BK || (Cout & 3)) return 0;
-    int dp = 0, U = 0;
-    return plan_streamk((long long)n_groups * (t_pad / 64) * cdiv(Cout, 64), Cin / BK, &dp, &U) ? streamk_ws_bytes() : 0;
-}
-
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                                      int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
-                                     int32_t* sched, float* ws, size_t ws_bytes, hipStream_t stream) {
+                                     hipStream_t stream) {
     if (!V || !U || !Mo) return FGN_ERR_ARG;
     if (n_img <= 0) return FGN_OK;
     if (Cin % BK != 0 || Cout % 4 != 0 || cout_pad % 128 != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
@@ -2273,8 +1403,10 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
-    p.n_img_dev = nullptr; p.tickets = nullptr; p.sched = sched;
-    p.sk_U = 0; p.sk_dp = 0;
+    p.n_img_dev = nullptr; p.stamp = nullptr;
+#ifdef FGN_EXPERIMENTS
+    p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
     p.n_img = (int)rows; p.H = 1; p.W = 1; p.Cin = Cin; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0; p.K = Cin;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = Cin / BK;
@@ -2282,14 +1414,11 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
     p.grp_rows_per_item = tiles_per_img; p.grp_w_stride = cout_pad * Cin; p.grp_count_dev = n_img_dev;
     p.n_tiles_n = 0;
+#ifdef FGN_EXPERIMENTS
     {
-        const int code = pick_persist2(rows, Cout, p.K, true, t_pad);
-        if (code) return launch_persist2(code, p, (int)rows, stream);
-        int dp = 0, Uk = 0;
-        if (ws && sched && ws_bytes >= streamk_ws_bytes() &&
-            plan_streamk((rows / 64) * cdiv(Cout, 64), p.K / BK, &dp, &Uk)) {
-            p.ws = ws; p.tickets = sched + FGN_TILE_SCHED_WORDS; p.sk_U = Uk; p.sk_dp = dp;
-        }
+        int rc = FGN_OK;
+        if (fgn_exp_pointwise(p, rows, 4, true, t_pad, stream, &rc)) return rc;
     }
+#endif
     return launch_cfg<64, 64, 32, 32, 4>(p, (int)rows, false, stream);
 }

@@ -759,11 +759,15 @@ extern "C" int fgn_adagrad_multi_f32(float* const* params, const float* const* g
                                      const long long* n, const float* lr, int count, float weight_decay, float eps,
                                      hipStream_t stream) {
     if (count < 0 || (count > 0 && (!params || !grads || !state_sums || !n || !lr))) return FGN_ERR_ARG;
-    for (int c0 = 0; c0 < count; c0 += FGN_ADAGRAD_MAX_TENSORS) {
+    // `i` walks the caller's list ONCE across the tables: empty tensors are skipped without taking a slot, so a table may
+    // cover more than FGN_ADAGRAD_MAX_TENSORS list entries - the next table starts where this one stopped (a fixed
+    // stride would hand the entries beyond it to two tables: two updates in one step)
+    int i = 0;
+    while (i < count) {
         AdagradTable t;
         t.count = 0;
         int chunks = 0;
-        for (int i = c0; i < count && t.count < FGN_ADAGRAD_MAX_TENSORS; ++i) {
+        for (; i < count && t.count < FGN_ADAGRAD_MAX_TENSORS; ++i) {
             if (n[i] <= 0) continue;
             if (!params[i] || !grads[i] || !state_sums[i]) return FGN_ERR_ARG;
             const int k = t.count++;

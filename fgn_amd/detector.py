@@ -62,7 +62,8 @@ def normalise_config(n_ways, k_shots, backbone=None, rpn_head=None, roi_head=Non
                                    # fgn_r50_c4_scratch.py:16-23
                                    deep_stem=bool(backbone.get('deep_stem', False)),
                                    avg_down=bool(backbone.get('avg_down', False)),
-                                   norm=norm.get('type', 'BN'), gn_groups=norm.get('num_groups', 32))
+                                   norm=norm.get('type', 'BN'), gn_groups=norm.get('num_groups', 32),
+                                   ref_num_stages=int(backbone.get('num_stages', 4)))
     if rpn_head:
         r = cfg['rpn_head']
         if 'anchor_generator' in rpn_head:
@@ -259,6 +260,11 @@ class _BottleneckGN:
         if self.pooled and stride != 2:
             raise NotImplementedError('avg_down shortcut: only stride 2')
         i = 1 if self.pooled else 0
+        # (mmdet's ResLayer may put the AvgPool2d in front of a stride-1 shortcut too - kernel 1, the identity - which
+        # shifts the conv / norm to downsample.1 / .2 in layer1 as well: unverifiable here (mmdet 2.18 is absent), so a
+        # checkpoint in either key layout loads)
+        if f'{prefix}.downsample.{i}.weight' not in sd and f'{prefix}.downsample.{1 - i}.weight' in sd:
+            i = 1 - i
         self.down = None
         if f'{prefix}.downsample.{i}.weight' in sd:
             self.down = ops.pack_conv(sd[f'{prefix}.downsample.{i}.weight'], stride=1 if avg_down else stride)
@@ -295,7 +301,7 @@ class _GraphedEpisode:
     for the previous download, and the two tensors the rare RLE-overflow fallback reads are cloned."""
     CODE_KEYS = ('vec', 'S', 'cat_mean_mp')
 
-    def __init__(self, model, ins: dict, img_shape, support_code, dev):
+    def __init__(self, model, ins: dict, img_shape, support_code, dev, phase_counter=None):
         self.static = {k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in ins.items()}
         self.img_shape = torch.as_tensor(img_shape).cpu().clone()
         self.code = None
@@ -311,18 +317,25 @@ class _GraphedEpisode:
         # eager pass first: packs the weights, sets kernel attributes, sizes the allocator pools
         # (the eager run that precedes the capture sends no phase mark: every ``detect_device`` call bumps the caller's
         # counter exactly once - here through the replay that follows the capture)
-        mark, model.phase_counter = model.phase_counter, None
-        try:
-            model._detect_eager(*args())
-        finally:
-            model.phase_counter = mark
+        model._detect_eager(*args(), phase_counter=None)
         torch.cuda.current_stream().synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        # launch records of the dominant kernel (``FGN.stamp_capacity``; bench.py's roofline over the whole timed window):
+        # the record of every conv_pw_persist_kernel launch is baked into the captured launch, each replay adds its span
+        self.stamps, self.stamp_count = None, 0
+        if model.stamp_capacity:
+            self.stamps = ops.new_stamp_records(int(model.stamp_capacity), dev)
+            torch.cuda.current_stream().synchronize()
+            ops.arm_stamps(self.stamps)
         # thread-local capture mode: only this thread's calls are checked against the capture, so nothing another
         # thread does (the watchdog of an RCCL process group polling the all-gather of the previous step) can
         # invalidate it.  (The global mode passed the same test on this torch build; FGN_GRAPH_CAPTURE_MODE selects.)
-        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get('FGN_GRAPH_CAPTURE_MODE', 'thread_local')):
-            self.outs = model._detect_eager(*args())
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get('FGN_GRAPH_CAPTURE_MODE', 'thread_local')):
+                self.outs = model._detect_eager(*args(), phase_counter=phase_counter)
+        finally:
+            if self.stamps is not None:
+                self.stamp_count = ops.arm_stamps(None)
 
     def run(self, model, ins: dict, support_code, main) -> list:
         for k, v in ins.items():
@@ -399,7 +412,11 @@ class FGN(torch.nn.Module):
         # r04: B = 1 189.9-191.3 vs 188.6-190.9 img/s, B = 4 211.1-211.8 vs 209.2-211.0, B = 8 214.6 vs 215.5): on since
         # round 4 for the launch count.  False = the separate pass, byte-identical to `encode_supports`.
         self.use_merged_support_head = True
+        # stem 7x7/2 + BN + ReLU with the 3x3/2 max-pool in its epilogue (csrc/stem_pool.hip): the 64-channel stem map
+        # (106 MB at cfg3) is never written; False = the two launches of rounds 1-4 (identical bytes)
+        self.use_stem_pool_fusion = ops.STEM_POOL_FUSION
         self.transfer_mode = 0                    # 0: upload + copy stream per caller; 1 / 2: see transfer_stream()
+        self.stamp_capacity = 0                   # > 0: captured graphs carry launch records of the dominant kernel (ops.read_stamps)
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
         self._pinned: dict = {}                   # (batch, max_det, byte cap) -> list of pinned host slots
@@ -698,7 +715,7 @@ class FGN(torch.nn.Module):
                 x = blk(x)
         return x
 
-    def extract_feat_pair(self, qry_nchw: torch.Tensor, spp_nchw: torch.Tensor):
+    def extract_feat_pair(self, qry_nchw: torch.Tensor, spp_nchw: torch.Tensor, phase_counter=None):
         """Both backbone passes of an episode (fgn.py:212-215) through SHARED launches wherever a layer does not look at
         the spatial structure (``use_merged_backbone``; frozen-BN bottleneck backbones only)."""
         P = self._P
@@ -713,11 +730,11 @@ class FGN(torch.nn.Module):
         x = _Pair((outs[0].shape[0],) + hw(outs[0]), (outs[1].shape[0],) + hw(outs[1]), outs[0].shape[3], outs[0].device)
         ops.maxpool3x3s2(outs[0], out=x.q)
         ops.maxpool3x3s2(outs[1], out=x.s)
-        self._phase_mark('layer1')                   # (stem + max-pool done)
+        self._phase_mark('layer1', phase_counter)    # (stem + max-pool done)
         for si, stage in enumerate(P['stages']):
             for blk in stage:
                 x = _bottleneck_pair(blk, x)
-            self._phase_mark('layer%d' % (si + 2))     # 'layer2' = layer1 done, ..., the last stage's mark equals 'rpn'
+            self._phase_mark('layer%d' % (si + 2), phase_counter)     # 'layer2' = layer1 done, ..., the last stage's mark equals 'rpn'
         return x.q, x.s
 
     def _shared_head(self, x, n_img_dev=None, y1=None):
@@ -934,14 +951,17 @@ class FGN(torch.nn.Module):
 
     @torch.no_grad()
     def detect_device(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None,
-                      qry_isegmaps=None) -> list:
+                      qry_isegmaps=None, phase_counter=None) -> list:
         """Everything up to the host wait: queues the host->device copies, the whole path and the device->host
         copies of the results.  Returns, per image, a dict of device tensors (det_bboxes [D,5], det_labels [D],
         n_dets [1], mask_prob, RLE bytes) plus the pinned host slot ``pack_results`` reads.
         With ``support_code`` (from ``encode_supports``) the support branch is skipped.  ``qry_isegmaps`` (list of
         [n_i,H,W] bool): the ground-truth masks, RLE-encoded on the device for ``qry_isegmaps_rle``.  With
         ``use_graphs`` the launch sequence of one input geometry is captured once into a hipGraph and replayed
-        (same kernels, same results; ~0.2 ms of host time instead of ~2 ms)."""
+        (same kernels, same results; ~0.2 ms of host time instead of ~2 ms).  ``phase_counter``: the one-element int32
+        device counter THIS call's episode bumps at ``phase_point`` (see ``_phase_mark``); passed per call, so two
+        caller threads never see each other's counter (the attribute of the same name is the fallback for callers that
+        set it on the model)."""
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('FGN.simple_test needs a GPU: the HIP path has no CPU fallback')
         dev = torch.device('cuda', torch.cuda.current_device())
@@ -953,11 +973,13 @@ class FGN(torch.nn.Module):
         if uploaded is not None:
             main.wait_event(uploaded)
         graphed = self.use_graphs and self.debug_trace is None and ops.PROFILE is None
+        if phase_counter is None:
+            phase_counter = self.phase_counter
         if graphed:
-            ge, outs = self._detect_graphed(ins, img_shape, support_code)
+            ge, outs = self._detect_graphed(ins, img_shape, support_code, phase_counter)
         else:
             outs = self._detect_eager(ins['qry_img'], ins.get('spp_imgs'), ins.get('spp_bboxes'),
-                                      ins.get('spp_isegmaps'), img_shape, support_code)
+                                      ins.get('spp_isegmaps'), img_shape, support_code, phase_counter=phase_counter)
         if gt_rle is not None:
             for d, g in zip(outs, gt_rle):
                 d['gt_rle'] = g
@@ -966,25 +988,33 @@ class FGN(torch.nn.Module):
             ge.last_download = outs[0]['host_ready']
         return outs
 
-    def _detect_graphed(self, ins: dict, img_shape, support_code):
+    def _detect_graphed(self, ins: dict, img_shape, support_code, phase_counter=None):
         main = torch.cuda.current_stream()
         dev = torch.device('cuda', torch.cuda.current_device())
         hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
+        # everything the captured launch sequence depends on besides the weights (those drop ``_graphs`` when they
+        # change): the paste semantic is an argument of the captured RLE kernel, the transfer arrangement decides which
+        # streams the capture forks, and the phase mark is a captured kernel with the counter's address in its arguments
+        self._skip_empty()
+        mark = None if (phase_counter is None or not self.phase_point) else (phase_counter.data_ptr(), self.phase_point)
         key = (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone),
-               bool(self.use_merged_support_head)) + \
+               bool(self.use_merged_support_head), self.paste_semantics, int(self.transfer_mode), mark,
+               bool(self.use_side_stream), bool(self.use_stem_pool_fusion)) + \
             tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
         ge = self._graphs.get(key)
         if ge is None:
-            ge = self._graphs[key] = _GraphedEpisode(self, ins, img_shape, support_code, dev)
+            ge = self._graphs[key] = _GraphedEpisode(self, ins, img_shape, support_code, dev, phase_counter)
         return ge, ge.run(self, ins, support_code, main)
 
-    def _detect_eager(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None) -> list:
+    def _detect_eager(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code=None,
+                      phase_counter=None) -> list:
         dev = torch.device('cuda', torch.cuda.current_device())
         if self._packed_device != dev:
             self._pack(dev)
         self._sync_trained_shared()
         with ops.arena(dev):     # zero-initialised small outputs of this episode: one fill (caller's stream only)
-            return self._detect_body(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev)
+            return self._detect_body(qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev,
+                                     phase_counter)
 
     # Phase mark of a pipelined serving loop (bench.py): when two caller streams replay episodes side by
     # side, their relative phase settles in one of several steady states that differ by ~4 % in throughput.  A caller may
@@ -993,15 +1023,18 @@ class FGN(torch.nn.Module):
     # ``ops.phase_signal`` is captured into the episode's
     # graph like any kernel, and the OTHER caller stream runs ``ops.phase_wait`` on that counter before its next episode.
     # (An event would be the natural tool; a captured graph cannot record one that another stream waits for on this
-    # stack - "External events are disallowed in rocm".)  None: no mark.
+    # stack - "External events are disallowed in rocm".)  None: no mark.  The counter travels as an ARGUMENT of
+    # ``detect_device`` (and is part of the graph cache key: a replayed graph bumps the counter it was captured with);
+    # ``phase_counter`` on the model is the fallback for callers that set it there.
     phase_counter = None
     phase_point = None
 
-    def _phase_mark(self, name: str) -> None:
-        if self.phase_counter is not None and name == self.phase_point:
-            ops.phase_signal(self.phase_counter)
+    def _phase_mark(self, name: str, counter) -> None:
+        if counter is not None and name == self.phase_point:
+            ops.phase_signal(counter)
 
-    def _detect_body(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev) -> list:
+    def _detect_body(self, qry_img, spp_imgs, spp_bboxes, spp_isegmaps, img_shape, support_code, dev,
+                     phase_counter=None) -> list:
         P, cfg = self._P, self.cfg
         N, K = self.n_ways, self.k_shots
         tr = self.debug_trace
@@ -1051,7 +1084,7 @@ class FGN(torch.nn.Module):
             sc = support_code
         elif merged:
             sc = self._support_front(spp_imgs, spp_bboxes, spp_isegmaps, B, dev, main, defer_backbone=True)
-            qry_fmap, spp_fmaps = self.extract_feat_pair(qry, sc.pop('spp'))
+            qry_fmap, spp_fmaps = self.extract_feat_pair(qry, sc.pop('spp'), phase_counter)
             backbone_done = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(backbone_done)
@@ -1081,7 +1114,7 @@ class FGN(torch.nn.Module):
         if not cached:
             main.wait_event(vec_ready)
         rpn_start = main.record_event()
-        self._phase_mark('rpn')
+        self._phase_mark('rpn', phase_counter)
         # guidance multiply (fgn_ag_rpn_head.py:44): never materialised - it rides in the Winograd input transform,
         # or in the A-operand staging of the direct kernel where the layer is too small for the Winograd form
         if P['rpn_conv_wg'] is not None and ops.winograd_fits(B * N, fh, fw, C, P['rpn_conv_wg'].cout,
@@ -1090,7 +1123,7 @@ class FGN(torch.nn.Module):
             x = ops.conv3x3_winograd(qry_fmap, P['rpn_conv_wg'], in_scale=vec, a_img_div=N)
         else:
             x = ops.conv2d(ops.scale_channels(qry_fmap, vec, N), P['rpn_conv'])
-        self._phase_mark('rpn_conv')
+        self._phase_mark('rpn_conv', phase_counter)
         head = ops.conv2d(x, P['rpn_head'])                                     # [B*N,h,w,5A]
         A = P['anchors'].shape[0]
         logits, scores, deltas = ops.rpn_merge(head, B, N, A)
@@ -1123,7 +1156,7 @@ class FGN(torch.nn.Module):
             tr.update(class_vec=vec, rpn_logits=logits, rpn_scores=scores, rpn_deltas=deltas, proposals=props,
                       n_props=n_props)
 
-        self._phase_mark('proposals')
+        self._phase_mark('proposals', phase_counter)
         # ---- box head on the proposals of all B images at once (fgn_roi_head.py:531-616); a RoI carries its
         # image index in column 0 (bbox2roi), which selects the feature map in RoIAlign and the support set
         # in the relation head.  With one image the device-side proposal count bounds every launch; with
@@ -1160,7 +1193,7 @@ class FGN(torch.nn.Module):
         dets = [det_all[i * D:(i + 1) * D] for i in range(B)]
         labs = [lab_all[i * D:(i + 1) * D] for i in range(B)]
         n_dets = [n_det_all[i:i + 1] for i in range(B)]
-        self._phase_mark('mask')
+        self._phase_mark('mask', phase_counter)
         # ---- mask head on the detections of all images at once (fgn_roi_head.py:704-718, 360-382)
         nd_all = n_dets[0] if B == 1 else None
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)

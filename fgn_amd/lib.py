@@ -19,18 +19,15 @@ _f = C.c_float
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
     'fgn_profile_next_launch': (_i, [_p, _p]),
+    'fgn_profile_stamps': (_i, [_p, _i]),
     'fgn_phase_signal': (_i, [_p, _p]),
     'fgn_phase_wait': (_i, [_p, _i, _i, _p]),
     'fgn_conv2d_workspace_bytes': (C.c_size_t, [_i] * 10),
     'fgn_conv2d_kernel_id': (_i, [_i] * 14),
-    'fgn_conv2d_tune': (_i, [_i, _i]),
-    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p, _p, _p]),
-    'fgn_conv2d_splitk_tickets': (_i, [_i] * 10),
+    'fgn_conv2d_nhwc_f32': (_i, [_p] * 8 + [_i] * 13 + [_p, C.c_size_t, _p]),
     'fgn_winograd_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_t_pad': (_i, [_i]),
-    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, C.c_size_t, _p]),
-    'fgn_winograd_gemm_workspace_bytes': (C.c_size_t, [_i, _i, _i, _i]),
-    'fgn_gemm_sched_words': (_i, []),
+    'fgn_winograd_gemm_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_input_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd4_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_output_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -94,7 +91,7 @@ SIGNATURES = {
     'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 _lib = None
 
 

@@ -27,12 +27,8 @@ from . import lib as _lib
 #   flop_*      per image: direct-convolution FLOPs of the layer / MFMA FLOPs actually issued (0 for the transforms)
 PROFILE = None
 
-# Split-K reduce by the last-arriving workgroup inside the conv launch instead of a second kernel.  Built and parity-tested
-# (tests/test_hip_conv.py), measured and left OFF: on the cfg3 episode (26 split layers) the step takes 6.02-6.09 ms
-# with it against 5.88-5.98 ms with the separate reduce kernel (three alternating runs on one box, r03) - the separate
-# kernel reduces a layer with 2048 workgroups at once, the in-launch form leaves it to one workgroup per tile behind
-# write-through stores, a ticket and an acquire fence, on the tail of the conv kernel.
-SPLITK_IN_LAUNCH = os.environ.get('FGN_SPLITK_IN_LAUNCH', '0') != '0'
+# stem 7x7/2 + BN + ReLU + 3x3/2 max-pool as ONE kernel (csrc/stem_pool.hip; detector.FGN.use_stem_pool_fusion).  A/B knob.
+STEM_POOL_FUSION = os.environ.get('FGN_STEM_POOL', '0') != '0'
 
 _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
 
@@ -40,16 +36,9 @@ _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32
 def kernel_name(kid: int) -> str:
     """fgn_conv2d_kernel_id -> the kernel name in a rocprofv3 kernel trace."""
     mode = kid % 10
-    if mode == 5:      # conv_pw_persist2_kernel: tile code -> template arguments (csrc/conv_igemm.hip launch_persist2)
-        return 'conv_pw_persist2_kernel<%d, %d, %d, %d, %d>' % {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3),
-                                                               3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4),
-                                                               5: (128, 128, 32, 64, 4), 6: (64, 64, 32, 16, 8),
-                                                               7: (64, 128, 32, 32, 6), 8: (32, 64, 16, 32, 4)}[kid // 10]
-    if mode == 6:
-        return 'conv_pw_streamk_kernel'
     bm, bn, wm, wn, mw = _TILES[kid // 10]
-    if mode == 4:      # template argument = MFMA shape (16x16x4 unless the tuning knob FGN_PW_M16=0 selects 32x32x2)
-        return 'conv_pw_persist_kernel<%s>' % ('false' if os.environ.get('FGN_PW_M16') == '0' else 'true')
+    if mode == 4:
+        return 'conv_pw_persist_kernel'
     if mode == 3:
         return f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, *, {mw}>'
     return f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, 2, {mw}, {mode}>'
@@ -141,25 +130,39 @@ class ConvProfile(list):
         return pair
 
 
-# Workspace of the opt-in point-wise GEMM kernels (include/fgn_hip.h, `sched`: the tile scheduler's counters of
-# conv_pw_persist2_kernel and the tickets of conv_pw_streamk_kernel): fgn_gemm_sched_words() zero int32 per launch, returned
-# to zero by the launch.  Taken from the episode's zero arena (one private range per launch, so launches in flight never
-# share one); without an open arena a fresh torch.zeros (tests, tools).  The default kernels use neither, so no words are
-# taken unless one of those kernels is switched on (FGN_PW2 / FGN_PW2_AUTO / FGN_STREAMK) or FGN_GEMM_SCHED=1 asks.
-_OPT_IN_GEMM = any(os.environ.get(k, '0') not in ('', '0', '-1') for k in ('FGN_PW2', 'FGN_PW2_AUTO', 'FGN_STREAMK'))
-GEMM_SCHED = os.environ.get('FGN_GEMM_SCHED', '1' if _OPT_IN_GEMM else '0') != '0'
+# ---- launch records of the dominant kernel that work inside a replayed hipGraph (include/fgn_hip.h: fgn_profile_stamps) ----
+def new_stamp_records(capacity: int, device) -> torch.Tensor:
+    """``capacity`` records of 8 x uint64 (held as int64): {first start, sum, arrived, executions, shortest, longest, -, -}."""
+    t = torch.zeros((capacity, 8), dtype=torch.int64, device=device)
+    t[:, 0] = -1
+    t[:, 4] = -1
+    return t
 
 
-def _sched(device):
-    if not GEMM_SCHED:
-        return None
-    return zeros((_lib.load().fgn_gemm_sched_words(),), device, torch.int32)
+def arm_stamps(records: Optional[torch.Tensor]) -> int:
+    """Arm (or, with None, disarm) the calling thread: every launch of conv_pw_persist_kernel takes the next record.
+    Returns the number of records handed out since the previous call."""
+    if records is None:
+        return int(_lib.load().fgn_profile_stamps(None, 0))
+    _chk(records, 'records', torch.int64)
+    if records.dim() != 2 or records.shape[1] != 8:
+        raise _lib.FgnHipError('arm_stamps: records must be [capacity, 8] int64')
+    return int(_lib.load().fgn_profile_stamps(_ptr(records), records.shape[0]))
 
 
-def _gemm_ws(L, t_pad, cin, cout, groups, device):
-    """Stream-K workspace of a grouped Winograd GEMM launch (None when the launch does not take that kernel)."""
-    n = L.fgn_winograd_gemm_workspace_bytes(t_pad, cin, cout, groups)
-    return (torch.empty(n, device=device, dtype=torch.uint8), n) if n and GEMM_SCHED else (None, 0)
+def reset_stamps(records: torch.Tensor) -> None:
+    """Forget the executions recorded so far (call with no launch of the graph in flight)."""
+    records[:, 1] = 0
+    records[:, 3] = 0
+    records[:, 4] = -1
+    records[:, 5] = 0
+
+
+def read_stamps(records: torch.Tensor, n: int) -> list:
+    """[{executions, total_us, min_us, max_us}] of the first ``n`` records (10 ns ticks -> microseconds)."""
+    r = records[:n].cpu().numpy().view(np.uint64)
+    return [dict(executions=int(x[3]), total_us=float(x[1]) * 0.01,
+                 min_us=(float(x[4]) * 0.01 if x[3] else None), max_us=(float(x[5]) * 0.01 if x[3] else None)) for x in r]
 
 
 def _stream() -> int:
@@ -296,16 +299,10 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
                                             layer.pad, tile_hint)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
-    tickets = None
-    if ws_bytes and SPLITK_IN_LAUNCH:
-        # zero-initialised tickets of the in-launch split-K reduce (from the episode's zero arena when one is open)
-        tickets = zeros((L.fgn_conv2d_splitk_tickets(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
-                                                     layer.pad, tile_hint),), x.device, torch.int32)
     rc = L.fgn_conv2d_nhwc_f32(
         _ptr(x), _ptr(layer.w), _ptr(out), _ptr(layer.scale), _ptr(layer.shift), _ptr(residual),
         _ptr(in_scale), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
-        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _ptr(tickets),
-        _ptr(_sched(x.device) if layer.kh == 1 and layer.kw == 1 and layer.stride == 1 else None), _stream())
+        layer.stride, layer.pad, a_img_div, int(layer.relu), tile_hint, _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'fgn_conv2d_nhwc_f32')
     if prof is not None:
         kid = L.fgn_conv2d_kernel_id(n_img, H, W, cin, layer.cout, layer.cout_pad, layer.kh, layer.kw, layer.stride,
@@ -514,10 +511,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
-    gws, gws_n = _gemm_ws(L, t_pad, cin, layer.cout, G, x.device)
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, G, _ptr(_sched(x.device)), _ptr(gws), gws_n, st),
-               'fgn_winograd_gemm_f32')
+                                       layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_f32')
     if ev is not None:
         ev.append(prof.arm())
     _lib.check(f_out(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W, layer.cout, t_pad,
@@ -586,9 +581,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
-    gws, gws_n = _gemm_ws(L, t_pad, cin, cout, G, dev)
     _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
-                                       G, _ptr(_sched(dev)), _ptr(gws), gws_n, st), 'fgn_winograd_gemm_f32')
+                                       G, st), 'fgn_winograd_gemm_f32')
     if prof is not None:
         ev.append(prof.arm())
     if pair:

@@ -798,7 +798,8 @@ def _layer4_params(bb: dict) -> list:
     ``model.named_parameters()``, of every checkpoint and of the optimizer's index space.  This build holds no
     layer4; its shapes follow from the architecture (mmdet ResNet ``arch_settings``: Bottleneck x3 at depth 50,
     BasicBlock x2 at depth 18; planes = 2 x the third stage's)."""
-    if len(bb['stage_blocks']) != 3:
+    # (a reference config with ``num_stages=3`` - fgn_r50_c4_scratch.py:12 - registers no layer4 at all: nothing phantom)
+    if len(bb['stage_blocks']) != 3 or int(bb.get('ref_num_stages', 4)) != 4:
         return []
     planes = 2 * bb['stage_planes'][-1]
     bottleneck = bb.get('block', 'bottleneck') == 'bottleneck'
@@ -871,6 +872,10 @@ class Trainer:
         if not torch.cuda.is_available():
             raise ops._lib.FgnHipError('Trainer needs a GPU: the HIP path has no CPU fallback')
         self.model, self.lr, self.wd, self.mult, self.eps = model, lr, weight_decay, roi_head_lr_mult, eps
+        # `lr` is the CURRENT (scheduled) learning rate the next step applies - a caller's schedule (``step_lr``) writes it
+        # through ``set_lr``; `base_lr` is the schedule's base, what mmcv's LrUpdaterHook keeps as `initial_lr` in every
+        # param group of a checkpoint and restores its schedule from on resume
+        self.base_lr = lr
         self.bn_momentum = bn_momentum
         dev = torch.device('cuda', torch.cuda.current_device())
         if model._packed_device != dev:
@@ -891,6 +896,10 @@ class Trainer:
         import weakref
         model._trainer = weakref.ref(self)      # the model sources its weights from W / buffers while a trainer lives
         self.refresh()
+
+    def set_lr(self, lr: float) -> None:
+        """The scheduled learning rate of the next steps (``step_lr(self.base_lr, it, epoch)``); the base stays."""
+        self.lr = float(lr)
 
     def refresh(self) -> None:
         """Re-derive every packed head layer from the master weights (device-side torch ops)."""
@@ -964,19 +973,23 @@ class Trainer:
         parameter over ``reference_param_order`` - every parameter of the detector, the frozen backbone (and the unused
         layer4) included, because mmcv's constructor lists frozen parameters too and Adagrad creates state for all of
         them.  Frozen parameters never see a gradient: their state is torch's initial one (step 0, zero sum) at the
-        optimizer's default lr.  The reference's ``optimizer.load_state_dict`` accepts this dict as it is (same group
+        optimizer's default lr; every group carries mmcv's ``initial_lr`` (the schedule's base x the group's lr_mult)
+        next to the current ``lr``.  The reference's ``optimizer.load_state_dict`` accepts this dict as it is (same group
         count, one parameter per group); ``param_names`` (extra key, ignored by torch) spells the index space out."""
         order = reference_param_order(self.model._sd, self.model.cfg['backbone'])
         state, groups = {}, []
         for i, (k, shape) in enumerate(order):
             if k in self.W:
                 st = {'step': torch.tensor(float(self.n_steps)), 'sum': self.state[k].detach().cpu()}
-                lr = self.lr * (self.mult if k.startswith('roi_head') else 1.0)
+                mult = self.mult if k.startswith('roi_head') else 1.0
             else:
                 st = {'step': torch.tensor(0.0), 'sum': torch.zeros(shape)}
-                lr = self.lr
+                mult = 1.0
             state[i] = st
-            groups.append({'lr': lr, 'lr_decay': 0, 'eps': self.eps, 'weight_decay': self.wd,
+            # 'initial_lr': mmcv's LrUpdaterHook.before_run does `group.setdefault('initial_lr', group['lr'])` and derives
+            # every later lr from it - a checkpoint taken at a decayed / warm-up lr without the key would make the resumed
+            # schedule start from the decayed value (applied twice)
+            groups.append({'lr': self.lr * mult, 'initial_lr': self.base_lr * mult, 'lr_decay': 0, 'eps': self.eps, 'weight_decay': self.wd,
                            'initial_accumulator_value': 0, 'foreach': None, 'maximize': False, 'differentiable': False,
                            'fused': None, 'params': [i]})
         return {'state': state, 'param_groups': groups, 'param_names': [k for k, _ in order]}
@@ -1007,6 +1020,7 @@ class Trainer:
             if 'state_sum' in opt:                                    # this package's round-2 layout
                 sums = opt['state_sum']
                 self.lr, self.wd = opt.get('lr', self.lr), opt.get('weight_decay', self.wd)
+                self.base_lr = opt.get('initial_lr', self.lr)
             elif 'state' in opt and 'param_groups' in opt:
                 # index -> name: the dict's own `param_names`, else the reference's full parameter order (a checkpoint
                 # written by mmcv / torch itself), else - a torch optimizer built over the trainable heads alone -
@@ -1034,7 +1048,10 @@ class Trainer:
                 by_name = {name_of[int(i)]: g for g in opt['param_groups'] for i in g['params']}
                 rp = next((g for k, g in by_name.items() if k in self.W and not k.startswith('roi_head')), None)
                 if rp is not None:
+                    # `lr` of a group is the SCHEDULED lr at the time of the checkpoint; the schedule's base is mmcv's
+                    # `initial_lr` (absent in a checkpoint written before any LrUpdaterHook ran: then lr IS the base)
                     self.lr, self.wd = float(rp['lr']), float(rp['weight_decay'])
+                    self.base_lr = float(rp.get('initial_lr', rp['lr']))
             else:
                 raise ValueError("unknown 'optimizer' entry: expected torch.optim.Adagrad.state_dict() layout")
             for k, v in sums.items():

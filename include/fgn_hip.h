@@ -37,6 +37,13 @@ int fgn_abi_version(void);
  * launches stamps the two HIP events (hipEvent_t, created by the caller) with that kernel's own start and end -
  * the duration a rocprofv3 kernel trace reports.  NULL, NULL disarms. */
 int fgn_profile_next_launch(void* start_event, void* stop_event);
+/* Launch records that work inside a replayed hipGraph (no reference counterpart): while the calling thread is armed,
+ * every launch of the dominant kernel (conv_pw_persist_kernel) is handed the next record of `records` (device memory,
+ * `capacity` records of 8 x uint64, initialised to {~0, 0, 0, 0, ~0, 0, 0, 0}); each execution of such a launch - every
+ * replay of a graph it was captured into - adds its span (first workgroup start -> last workgroup end, 10 ns ticks of
+ * the constant 100 MHz clock) to the record: [1] sum, [3] executions, [4] shortest, [5] longest.  NULL disarms.
+ * Returns the number of records handed out since the previous call (= launches recorded, in launch order). */
+int fgn_profile_stamps(void* records, int capacity);
 /* Phase marks between streams that replay captured graphs (no reference counterpart; the pipelined serving loop of
  * INTEGRATION.md): fgn_phase_signal bumps *counter (device memory, int32) from inside an episode - captured into its
  * graph like any kernel; fgn_phase_wait holds `stream` until *counter - target >= 0 or timeout_us (<= 1 s) have passed. */
@@ -53,48 +60,26 @@ int fgn_phase_wait(const int32_t* counter, int32_t target, int timeout_us, void*
  *   x [n_img/a_img_div, H, W, Cin]   w_packed [cout_pad, KH, KW, Cin] (K padded to x32,
  *   cout_pad multiple of 128, zero rows)   y [n_img, Ho, Wo, Cout]
  *   scale/shift [Cout] or NULL; residual like y or NULL; in_scale [n_img, Cin] or NULL
- *   Cin must be a multiple of 32, or exactly 4 (stem, NHWC4 input)
+ *   Cin must be a multiple of 32, or exactly 4 = the stem's NHWC4 image: three channels and a ZERO fourth one, in x
+ *   (fgn_nchw3_to_nhwc4_f32) and in w_packed alike - the kernel does not multiply the fourth channel
  *   tile_hint 0 = auto, 1..4 = force a tile configuration, negative = no split-K,
  *   +100 = register-staged loader instead of LDS-DMA (tests)
  *   splitk_ws: optional workspace of fgn_conv2d_workspace_bytes() bytes; when given and the plain
  *   grid would under-fill the GPU, K is split over blockIdx.y into partial-tile slabs that are
  *   summed in slab order (bit-reproducible) before the epilogue.  NULL = never split.
- *   splitk_tickets: optional, fgn_conv2d_splitk_tickets() int32 values, ALL ZERO on entry (and
- *   zero again when the launch has run): the workgroup that publishes the last slab of an
- *   output tile reduces it inside the same launch.  NULL = the reduce runs as a second kernel.
- *   sched: optional, fgn_gemm_sched_words() int32 values, ALL ZERO on entry (and zero again when the launch has
- *   run): tile scheduler of the persistent point-wise kernel - its workgroups pull their next output tile from a
- *   counter instead of walking a fixed order, so the last tiles of a launch go to whichever workgroups are free.
- *   Used by 1x1 / stride 1 launches (and fgn_winograd_gemm_f32) that run on that kernel, ignored otherwise; one
- *   workspace per launch IN FLIGHT (launches that may overlap on the GPU must not share one).  NULL = fixed order.
- *   Results do not depend on it (each output tile is computed by one workgroup either way).
- *   Stream-K (conv_pw_streamk_kernel, tuning knob 2 of fgn_conv2d_tune / FGN_STREAMK): a 1x1 / stride 1 launch whose
- *   64x64 output tiles do not fill a whole number of rounds of the resident workgroups shares the K loop of the tiles of
- *   its last round among ALL workgroups; the partial tiles travel through `splitk_ws` (fgn_conv2d_workspace_bytes covers
- *   it), the tickets live in the words of `sched` behind the scheduler's.  Needs both; pieces are summed in K order
- *   whoever finishes last (bit-reproducible), results agree with the whole-tile kernels to rounding. */
-int fgn_gemm_sched_words(void);
+ *   (The kernels behind this entry point that were measured and not adopted - Stream-K, a tile scheduler, other
+ *   tile shapes - are not part of this library: tools/micro/conv_pw_experiments.inc.) */
 size_t fgn_conv2d_workspace_bytes(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                                   int pad, int tile_hint);
 /* Which kernel the dispatcher launches for a layer (tile*10 + mode; 41 = conv_igemm_dma_kernel<64,64,32,32,2,4,1>):
  * lets a profiler attribute a launch to the kernel name rocprofv3 reports.  No reference counterpart. */
 int fgn_conv2d_kernel_id(int n_img, int H, int W, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
                          int pad, int a_img_div, int has_in_scale, int has_residual, int tile_hint);
-/* Tuning knob (no reference counterpart; tools/ only): knob 0 = tile code of conv_pw_persist2_kernel forced for every
- * eligible point-wise launch (-1 heuristic, 0 never, 1 128x128, 2 64x128, 3 128x64, 4 64x64, 5 128x128 on 8 waves, 6 64x64 on 8 waves, 7 64x128 on 8 waves, 8 32x64; + 10 x LDS stages (3, 4) for tiles 2, 4, 6, 7, 8),
- * knob 1 = its workgroups per CU (0 = default); knob 2 = Stream-K mode (0 never, 1 launches of more tiles than resident
- * workgroups, 2 also smaller launches of at least knob-4 tiles, 3 every eligible launch), knob 3 = largest fill of the last
- * round in per cent that still takes Stream-K, knob 4 = smallest tile count for mode 2.  Returns the previous value,
- * FGN_ERR_ARG for an unknown knob. */
-int fgn_conv2d_tune(int knob, int value);
 int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const float* scale,
                         const float* shift, const float* residual, const float* in_scale,
                         const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
                         int cout_pad, int KH, int KW, int stride, int pad, int a_img_div, int relu,
-                        int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, int32_t* splitk_tickets,
-                        int32_t* sched, void* stream);
-int fgn_conv2d_splitk_tickets(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                              int tile_hint);
+                        int tile_hint, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* The same convolution (w_packed, scale, shift, relu as in fgn_conv2d_nhwc_f32) on TWO NHWC tensors of different
  * geometry in one launch: x0 [n_img0,H0,W0,Cin] -> y0, x1 [n_img1,H1,W1,Cin] -> y1.  For the backbone layers that
@@ -120,10 +105,7 @@ int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, cons
                            int a_img_div, int H, int W, int C, int t_pad, void* stream);
 int fgn_winograd_t_pad(int tiles_total);
 int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
-                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, int32_t* sched,
-                          float* ws, size_t ws_bytes, void* stream);
-/* ws / ws_bytes: optional Stream-K workspace (see fgn_conv2d_nhwc_f32's splitk_ws); size from this query, 0 = none. */
-size_t fgn_winograd_gemm_workspace_bytes(int t_pad, int Cin, int Cout, int n_groups);
+                          int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
 int fgn_winograd_output_f32(const float* Mo, float* y, const float* shift, const int32_t* n_img_dev, int n_img,
                             int H, int W, int C, int t_pad, int relu, void* stream);
 /* F(4x4,3x3) form of the same convolutions (the default): 36 tile positions (n_groups = 36 in

@@ -142,38 +142,6 @@ def test_split_k_is_reproducible_and_honours_the_device_count(shape):
         assert float((got[n - 3:] + 3.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('shape', [(1, 50, 84, 1024, 256, 1), (9, 7, 7, 1024, 512, 1), (9, 7, 7, 512, 512, 3),
-                                   (9, 16, 16, 1024, 256, 1), (1, 25, 42, 1024, 256, 1)])
-def test_split_k_reduce_inside_the_launch_equals_the_two_kernel_form(shape):
-    """The workgroup that publishes the last partial tile of an output tile reduces it inside the conv launch
-    (write-through slab stores, one ticket per tile, slabs summed in slab order): byte-identical to the separate reduce
-    kernel, on every one of 300 back-to-back launches that reuse the same slabs and tickets (layer shapes of the cfg3
-    episode that are split: layer3 1x1s on the query / support maps, the 9-RoI support shared head)."""
-    from fgn_amd import ops
-    n, h, w, cin, cout, k = shape
-    g = torch.Generator().manual_seed(cin + cout + k)
-    x = torch.randn(n, h, w, cin, generator=g).cuda()
-    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    res = torch.randn(n, h, w, cout, generator=g).cuda()
-    layer = ops.pack_conv(wt, bias=torch.randn(cout, generator=g), pad=k // 2, relu=True).to('cuda')
-    L = ops._lib.load()
-    assert L.fgn_conv2d_splitk_tickets(n, h, w, cin, cout, k, k, 1, k // 2, 0) > 0, 'shape is not split: test is vacuous'
-    keep = ops.SPLITK_IN_LAUNCH
-    try:
-        ops.SPLITK_IN_LAUNCH = False
-        two = ops.conv2d(x, layer, residual=res).clone()
-        ops.SPLITK_IN_LAUNCH = True
-        for i in range(300):
-            got = ops.conv2d(x, layer, residual=res)
-            assert torch.equal(got, two), f'launch {i} differs from the two-kernel reduce'
-    finally:
-        ops.SPLITK_IN_LAUNCH = keep
-    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double(),
-                                                layer.shift.double().cpu(), padding=k // 2)
-                     + res.permute(0, 3, 1, 2).double().cpu()).float()
-    assert (two.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
-
-
 def test_repeated_runs_are_bit_identical_at_full_occupancy():
     """Regression: a 1x1 conv with 1840 workgroups of the 64x64 kernel (4-5 per CU) gave, about once in
     40 launches, one wave a stale last k-slice of a K-tile: the loop barrier was signalled while that wave's
@@ -191,6 +159,47 @@ def test_repeated_runs_are_bit_identical_at_full_occupancy():
     assert (first.reshape(-1, 512).cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
     for i in range(200):
         assert torch.equal(ops.conv2d(xc, layer), first), f'launch {i} differs'
+
+
+@pytest.mark.parametrize('rows,cin,cout,res,relu', [(49 * 300, 512, 1024, True, True), (103664, 64, 256, True, True),
+                                                    (26016, 128, 512, False, True), (49 * 300 + 17, 1024, 1024, False, False),
+                                                    (4200 * 5, 96, 260, True, False)])
+def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, cin, cout, res, relu):
+    """conv_pw_persist_kernel (the dominant kernel of an episode: 1x1 / stride 1 launches with more 64x64 output tiles
+    than its 1024 persistent workgroups) at the episode's own shapes and at ragged ones (a last row tile of 17 rows, a
+    channel count that is not a multiple of 64), with residual / BN / ReLU epilogues: against fp64, and against the
+    one-tile-per-workgroup kernel of the same tile on pieces of the launch (fewer than 1024 tiles each, split-K off):
+    the two differ only in the order of the K sum inside a 16-deep step (16x16x4 vs 32x32x2 MFMA: 2e-6 of the range),
+    and every output element must be covered exactly once (a tile walked twice or skipped shows at once)."""
+    from fgn_amd import lib, ops
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    r = torch.randn(rows, cout, generator=g) if res else None
+    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
+    xc = x.cuda().view(1, rows, 1, cin)
+    rc = None if r is None else r.cuda().view(1, rows, 1, cout)
+    L = lib.load()
+    assert L.fgn_conv2d_kernel_id(1, rows, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, int(res), 0) % 10 == 4
+    y = ops.conv2d(xc, layer, residual=rc)
+    sc = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + 1e-5)
+    ref = (x.double() @ wt.reshape(cout, cin).double().T) * sc + (bn['bias'].double() - bn['running_mean'].double() * sc)
+    if r is not None:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    got = y.view(rows, cout).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # pieces of <= 60 row tiles x cout/64 channel tiles < 1024 tiles: conv_igemm_dma_kernel<64,64,...,1>
+    step = max(64, (1000 // ((cout + 63) // 64)) * 64)
+    for m0 in range(0, rows, step):
+        m1 = min(rows, m0 + step)
+        piece = ops.conv2d(xc[:, m0:m1].contiguous(), layer, residual=None if rc is None else rc[:, m0:m1].contiguous(),
+                           tile_hint=-4)
+        assert L.fgn_conv2d_kernel_id(1, m1 - m0, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, int(res), -4) % 10 == 1
+        assert (piece - y[:, m0:m1]).abs().max().item() <= 2e-6 * ref.abs().max().item(), (m0, m1)
 
 
 @pytest.mark.parametrize('cin,cout,k,stride', [(128, 128, 3, 2), (256, 512, 1, 2), (64, 64, 3, 1), (4, 64, 7, 2)])
@@ -225,208 +234,3 @@ def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
     oq, os_ = buf[:yq.numel()].view(yq.shape), buf[yq.numel():].view(ys.shape)
     ops.conv2d_pair(xq, xs, layer, oq, os_)
     assert torch.equal(oq, yq) and torch.equal(os_, ys)
-
-
-# ------------------------------------------------------------------------------------------------
-# conv_pw_persist2_kernel (round 4): every tile code through the tuning knob, against fp64 and against
-# the round-3 kernels on the same operands
-# ------------------------------------------------------------------------------------------------
-class _pw2:
-    """``with _pw2(code):`` forces tile code `code` of conv_pw_persist2_kernel for every eligible launch."""
-
-    def __init__(self, code):
-        self.code = code
-
-    def __enter__(self):
-        from fgn_amd import lib
-        self.prev = lib.load().fgn_conv2d_tune(0, self.code)
-
-    def __exit__(self, *a):
-        from fgn_amd import lib
-        lib.load().fgn_conv2d_tune(0, self.prev)
-
-
-@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8, 34, 44, 32, 42, 36, 47, 38, 48])   # tile + 10 * LDS stages
-@pytest.mark.parametrize('rows,cin,cout,res,relu', [(1000, 64, 72, True, True), (49 * 37, 96, 256, False, True),
-                                                     (130, 1024, 512, True, False), (64 * 9 + 1, 32, 4, False, False)])
-def test_persist2_pointwise_matches_fp64_and_round3_kernel(code, rows, cin, cout, res, relu):
-    """1x1 / stride 1 convolutions with BN epilogue (+ residual, ReLU): row counts that end inside a tile, Cout that
-    ends inside a 16-channel MFMA tile and inside a workgroup tile, K of 1..32 K-tiles; a device-side image count."""
-    from fgn_amd import ops
-    g = torch.Generator().manual_seed(rows + cin + cout)
-    x = torch.randn(rows, cin, 1, 1, generator=g)
-    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
-    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
-              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
-    r = torch.randn(rows, cout, 1, 1, generator=g) if res else None
-    ref = _ref(x, wt, None, bn, 1, 0, r, relu)
-    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
-    xc, rc = _nhwc(x).cuda(), None if r is None else _nhwc(r).cuda()
-    with _pw2(0):
-        old = ops.conv2d(xc, layer, residual=rc).clone()
-    with _pw2(code):
-        got = ops.conv2d(xc, layer, residual=rc).clone()
-        cnt = torch.tensor([rows - 77], dtype=torch.int32, device='cuda')
-        part = torch.full((rows, 1, 1, cout), -7.0, device='cuda')
-        ops.conv2d(xc, layer, residual=rc, n_img_dev=cnt, out=part)
-    scale = ref.abs().max().item() + 1e-6
-    assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * scale + 1e-6
-    # same products in the same k order as the round-3 kernels; the epilogue may contract differently (one ulp)
-    assert (got - old).abs().max().item() <= 2e-6 * scale
-    assert torch.equal(part[:rows - 77], got[:rows - 77]) and float((part[rows - 77:] + 7.0).abs().max()) == 0.0
-
-
-@pytest.mark.parametrize('code', [1, 2, 3, 4, 5, 6, 7, 8, 34, 44, 32, 42, 36, 47, 38, 48])   # tile + 10 * LDS stages
-@pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 64, 128), (5, 4, 512, 64), (100, 4, 32, 256)])
-def test_persist2_grouped_gemm_all_tiles_and_the_tile_scheduler(code, n, tiles, cin, cout):
-    """The grouped Winograd GEMM (36 groups, per-group weights): t_pad is a multiple of 64, so with 128-row tiles the
-    last row tile of every group is cut at the group's end; rows past n * tiles of a group and items past the device
-    count are never written.  No epilogue arithmetic -> the sums are the round-3 kernel's bit for bit."""
-    from fgn_amd import lib
-    L = lib.load()
-    g = torch.Generator().manual_seed(n * tiles + cin)
-    t_pad = L.fgn_winograd_t_pad(n * tiles)
-    V = torch.randn(36, t_pad, cin, generator=g).cuda()
-    U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) / cin ** 0.5).cuda()
-    st = torch.cuda.current_stream().cuda_stream
-
-    def run(force, cnt=None):
-        Mo = torch.full((36, t_pad, cout), -7.0, device='cuda')
-        with _pw2(force):
-            rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
-                                         n, tiles, t_pad, cin, cout, U.shape[1], 36,
-                                         None if sched is None else sched.data_ptr(), None, 0, st)
-        assert rc == 0
-        torch.cuda.synchronize()
-        if sched is not None:
-            assert int(sched.abs().max()) == 0            # the scheduler's counters are back at zero after the launch
-        return Mo
-    sched = None
-    old, got, p4 = run(0), run(code), run(4)
-    valid = n * tiles
-    ref = torch.einsum('gtc,gnc->gtn', V[:, :valid].double(), U[:, :cout].double()).float()
-    assert (got[:, :valid] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    # every tile shape accumulates a sum in the same k order: the tile codes agree bit for bit (and with the round-3
-    # persistent kernel; its non-persistent 32x32x2 form pairs the k's differently: last-bit differences)
-    assert torch.equal(got[:, :valid], p4[:, :valid])
-    assert (got[:, :valid] - old[:, :valid]).abs().max().item() <= 2e-6 * ref.abs().max().item()
-    # the tile scheduler (workgroups pull their next tile from a counter) changes who computes a tile, not the tile
-    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
-    for _ in range(3):                                       # back to back on the same counters: they reset themselves
-        assert torch.equal(run(code), got)
-    sched = None
-    # rows of a group past its valid rows: the round-3 kernel writes the padding rows of a started 64-row tile,
-    # this one writes none of them
-    assert float((got[:, valid:] + 7.0).abs().max()) == 0.0 if valid < t_pad else True
-    cnt = torch.tensor([n - 1], dtype=torch.int32, device='cuda')
-    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')     # pulled tiles without valid rows
-    part = run(code, cnt)
-    v2 = (n - 1) * tiles
-    assert torch.equal(part[:, :v2], got[:, :v2]) and float((part[:, v2:] + 7.0).abs().max()) == 0.0
-
-
-# ------------------------------------------------------------------------------------------------
-# conv_pw_streamk_kernel (round 4): the K loop of the last round's tiles shared among all workgroups
-# ------------------------------------------------------------------------------------------------
-class _streamk:
-    """``with _streamk(mode):`` sets the Stream-K mode (fgn_conv2d_tune knob 2; 3 = every eligible launch)."""
-
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        from fgn_amd import lib
-        L = lib.load()
-        self.prev = L.fgn_conv2d_tune(2, self.mode)
-        self.prev0 = L.fgn_conv2d_tune(0, 0)
-
-    def __exit__(self, *a):
-        from fgn_amd import lib
-        L = lib.load()
-        L.fgn_conv2d_tune(2, self.prev)
-        L.fgn_conv2d_tune(0, self.prev0)
-
-
-@pytest.mark.parametrize('rows,cin,cout,res,relu', [
-    (64 * 400 + 5, 128, 64, True, True),        # 401 tiles x 4 K-tiles: ranges of 4 = whole tiles only
-    (6504, 1024, 256, False, True),             # layer3 conv1 of a cfg3 episode: 408 tiles x 32 K-tiles, ranges of 13
-    (4900, 512, 1024, True, True),              # 1232 tiles: one whole round + 208 tiles in pieces, residual epilogue
-    (130, 1024, 512, True, False),              # 24 tiles: minimum range (4 K-tiles), most workgroups idle
-    (64 * 9 + 1, 256, 4, False, False),         # Cout inside one 16-byte vector, 10 tiles
-    (14700, 1024, 1024, False, True),           # 3680 tiles = 3 rounds + 608
-])
-def test_stream_k_pointwise_matches_fp64_and_the_whole_tile_kernels(rows, cin, cout, res, relu):
-    from fgn_amd import ops, lib
-    L = lib.load()
-    g = torch.Generator().manual_seed(rows + cin + cout)
-    x = torch.randn(rows, cin, 1, 1, generator=g)
-    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
-    bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
-              running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
-    r = torch.randn(rows, cout, 1, 1, generator=g) if res else None
-    ref = _ref(x, wt, None, bn, 1, 0, r, relu)
-    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
-    xc, rc = _nhwc(x).cuda(), None if r is None else _nhwc(r).cuda()
-    with _streamk(0):
-        old = ops.conv2d(xc, layer, residual=rc).clone()
-    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
-    keep, ops._sched = ops._sched, (lambda dev: sched)
-    try:
-        with _streamk(3):
-            assert L.fgn_conv2d_kernel_id(rows, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, int(res), 0) % 10 == 6
-            got = ops.conv2d(xc, layer, residual=rc).clone()
-            torch.cuda.synchronize()
-            assert int(sched.abs().max()) == 0            # every ticket is back at zero
-            for _ in range(3):                             # the order of arrival changes, the sums do not
-                assert torch.equal(ops.conv2d(xc, layer, residual=rc), got)
-            cnt = torch.tensor([rows - 77], dtype=torch.int32, device='cuda')
-            part = torch.full((rows, 1, 1, cout), -7.0, device='cuda')
-            ops.conv2d(xc, layer, residual=rc, n_img_dev=cnt, out=part)
-            torch.cuda.synchronize()
-            assert int(sched.abs().max()) == 0
-    finally:
-        ops._sched = keep
-    scale = ref.abs().max().item() + 1e-6
-    assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * scale + 1e-6
-    assert (got - old).abs().max().item() <= 4e-6 * scale          # pieces are summed after the fact: rounding only
-    assert torch.equal(part[:rows - 77], got[:rows - 77]) and float((part[rows - 77:] + 7.0).abs().max()) == 0.0
-
-
-@pytest.mark.parametrize('n,tiles,cin,cout', [(3, 273, 1024, 128), (5, 4, 512, 64), (100, 4, 256, 256), (300, 4, 128, 512)])
-def test_stream_k_grouped_gemm(n, tiles, cin, cout):
-    """The grouped Winograd GEMM on conv_pw_streamk_kernel: banded tile order, groups cut at their valid rows, a device-side
-    item count that empties some of the remaining tiles."""
-    from fgn_amd import lib
-    L = lib.load()
-    g = torch.Generator().manual_seed(n * tiles + cin)
-    t_pad = L.fgn_winograd_t_pad(n * tiles)
-    V = torch.randn(36, t_pad, cin, generator=g).cuda()
-    U = (torch.randn(36, (cout + 127) // 128 * 128, cin, generator=g) / cin ** 0.5).cuda()
-    st = torch.cuda.current_stream().cuda_stream
-    sched = torch.zeros(L.fgn_gemm_sched_words(), dtype=torch.int32, device='cuda')
-
-    def run(mode, cnt=None):
-        Mo = torch.full((36, t_pad, cout), -7.0, device='cuda')
-        with _streamk(mode):
-            nb = L.fgn_winograd_gemm_workspace_bytes(t_pad, cin, cout, 36)
-            assert (nb > 0) == (mode == 3)
-            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device='cuda')
-            rc = L.fgn_winograd_gemm_f32(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), None if cnt is None else cnt.data_ptr(),
-                                         n, tiles, t_pad, cin, cout, U.shape[1], 36, sched.data_ptr(), ws.data_ptr(), nb, st)
-        assert rc == 0
-        torch.cuda.synchronize()
-        assert int(sched.abs().max()) == 0
-        return Mo
-    old, got = run(0), run(3)
-    valid = n * tiles
-    ref = torch.einsum('gtc,gnc->gtn', V[:, :valid].double(), U[:, :cout].double()).float()
-    assert (got[:, :valid] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    assert (got[:, :valid] - old[:, :valid]).abs().max().item() <= 4e-6 * ref.abs().max().item()
-    for _ in range(3):
-        assert torch.equal(run(3), got)
-    cnt = torch.tensor([n - 1], dtype=torch.int32, device='cuda')
-    part = run(3, cnt)
-    v2 = (n - 1) * tiles
-    assert torch.equal(part[:, :v2], got[:, :v2])
-    lim = (v2 + 63) // 64 * 64                  # rows of a started 64-row tile are written, nothing beyond
-    assert float((part[:, lim:] + 7.0).abs().max()) == 0.0 if lim < t_pad else True

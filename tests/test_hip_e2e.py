@@ -7,22 +7,47 @@ from fgn_amd.agreement import episode_maxima, match_detections
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4      # BASELINE.json north_star: "masks/scores within 1e-4 fp32"; boxes/labels of matched pairs within 1e-2 px
+TOL = 1e-4      # BASELINE.json north_star: "masks/scores within 1e-4 fp32"
 
 
-BOX_TOL = 1e-2  # px: the matching radius of fgn_amd.agreement AND the asserted bound on matched pairs
+# Boxes: north_star asks for bit-exact boxes / labels.  Stage-wise they are (tests/test_hip_stages.py: identical head
+# outputs in -> identical boxes, scores, labels out, bit for bit); END TO END the two paths accumulate in different orders
+# (MFMA tiles vs MKL), so a decoded box moves by ~1e-3 px (measured maximum over 6400 detections 1.3e-3 px,
+# profiles/r04_accuracy_64.json).  The asserted bound is 3x that maximum; the matching radius of fgn_amd.agreement stays
+# 1e-2 px, so a pair that drifted past the bound fails as a box difference, not as a "flip".
+BOX_TOL = 4e-3
+CFG5_PROP_FLIPS = 8         # rows of the proposal symmetric difference tolerated at cfg5 (each with its printed reason)
+MASK_IOU_MIN = 0.999     # final binary masks (decoded dt_isegmaps_rle) of matched pairs: single pixels may sit on the 0.5 threshold
 
 
-def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0):
-    """Per image: match HIP detections to the oracle's (same label, box within 1e-2 px), assert
-    |d score| <= 1e-4, max |d mask probability| <= 1e-4 and |d box| <= 1e-2 px on EVERY matched pair, and count the
-    detections without a partner (an upstream selection flipped).  Every seeded episode of this file produces ZERO
-    flips (rounds 1-3, 6400 detections in profiles/r03_accuracy_64.json), so zero is what is asserted: one flipped
-    detection is a regression until someone shows the key that sat on a threshold.  A test that can genuinely flip
-    passes its own `max_flips` with a comment saying why."""
+def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0, cfg=None, max_prop_flips=0):
+    """Per image: (1) the PROPOSAL sets of the two paths (fgn.py:229-235) compared as sets - symmetric difference
+    printed with the reason each row can differ (fgn_amd.agreement.proposal_set_difference), ``max_prop_flips`` rows
+    tolerated (0 unless the caller says why), none of them unexplained; (2) HIP detections matched to the oracle's
+    (same label, box within 1e-2 px): |d score| <= 1e-4, max |d mask probability| <= 1e-4 and |d box| <= 4e-3 px on
+    EVERY matched pair, detections without a partner counted as selection flips - ZERO asserted (every seeded episode
+    of this file produced zero in rounds 1-4; a test that can genuinely flip passes its own ``max_flips`` with a
+    comment saying why); (3) the FINAL binary masks of every matched pair (decoded ``dt_isegmaps_rle``,
+    fgn_roi_head.py:668-671): IoU >= 0.999."""
+    from fgn_amd.agreement import mask_iou_of_pairs, match_detections, proposal_set_difference
     start = 0
     out = []
     for i in range(len(ref)):
+        if cfg is not None and 'proposals' in tr_ref and 'proposals' in tr:
+            rp = cfg['test_cfg']['rpn']
+            n_hip = int(tr['n_props'][i])
+            ps = proposal_set_difference(tr_ref['proposals'][i], tr['proposals'][i, :n_hip].cpu().numpy(),
+                                         rp['nms_iou_threshold'], rp['max_per_img'])
+            print(f'[parity {name} img {i}] proposals ref/hip {ps["n_ref"]}/{ps["n_got"]}, matched {ps["matched"]}, '
+                  f'only ref/hip {len(ps["only_ref"])}/{len(ps["only_got"])}; on matched: max|d box| {ps["max_dbox"]:.2e} px, '
+                  f'max|d score| {ps["max_dscore"]:.2e}')
+            for side in ('only_ref', 'only_got'):
+                for row in ps[side]:
+                    print(f'    {side} row {row["row"]} score {row["score"]:.7f} box {np.round(row["box"], 3).tolist()} '
+                          f'reason {row["reason"]} iou margin {row["iou_margin"]}')
+            assert ps['unexplained'] == 0, (name, i, ps)
+            assert len(ps['only_ref']) <= max_prop_flips and len(ps['only_got']) <= max_prop_flips, (name, i, ps)
+            assert ps['max_dscore'] <= TOL and ps['max_dbox'] <= BOX_TOL, (name, i, ps['max_dscore'], ps['max_dbox'])
         n_ref = len(ref[i]['dt_scores'])
         pi = tr['per_image'][i]
         n_got = int(pi['n_det'][0])
@@ -35,14 +60,20 @@ def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0):
                            pi['mask_prob'][:n_got].cpu().numpy(),
                            tr_ref['mask_logits'][start:start + n_ref].numpy(), pi['mask_logits'][:n_got].cpu().numpy())
         start += n_ref
+        pairs, _, _ = match_detections(ref[i]['dt_bboxes'], ref[i]['dt_cat_ids'], got[i]['dt_bboxes'], got[i]['dt_cat_ids'])
+        ious = mask_iou_of_pairs(ref[i]['dt_isegmaps_rle'], got[i]['dt_isegmaps_rle'], pairs)
+        m['min_mask_iou'] = float(ious.min()) if len(ious) else 1.0
+        m['masks_identical'] = int(sum(ref[i]['dt_isegmaps_rle'][a] == got[i]['dt_isegmaps_rle'][b] for a, b in pairs))
         print(f'[parity {name} img {i}] detections ref/hip {m["n_ref"]}/{m["n_got"]}, matched {m["matched"]}, '
               f'selection flips ref/hip {m["flips_ref"]}/{m["flips_got"]}; on matched pairs: max|d score| '
               f'{m["max_dscore"]:.2e}, max|d mask prob| {m["max_dprob"]:.2e}, max|d box| {m["max_dbox"]:.2e} px, '
-              f'max|d mask logit| {m["max_dlogit"]:.2e} (|logit| <= {m.get("max_abs_logit", 0):.1f})')
+              f'max|d mask logit| {m["max_dlogit"]:.2e} (|logit| <= {m.get("max_abs_logit", 0):.1f}); final masks: '
+              f'min IoU {m["min_mask_iou"]:.6f}, {m["masks_identical"]}/{m["matched"]} RLE strings byte-identical')
         assert m['matched'] > 0
         assert m['max_dscore'] <= TOL, (name, i, m)
         assert m['max_dprob'] <= TOL, (name, i, m)
         assert m['max_dbox'] <= BOX_TOL, (name, i, m)
+        assert m['min_mask_iou'] >= MASK_IOU_MIN, (name, i, m)
         assert m['flips_ref'] <= max_flips and m['flips_got'] <= max_flips, (name, i, m)
         out.append(m)
     return out
@@ -89,7 +120,7 @@ def test_e2e_half_width(n_ways, k_shots, hw):
     d = (tr['spp_cat_mean_mp'].cpu().reshape(-1) - tr_ref['spp_cat_mean_mp'].reshape(-1)).abs().max().item()
     assert d <= 1e-4 * tr_ref['spp_cat_mean_mp'].abs().max().item()
     # detections: every matched pair within north_star's tolerance; flips counted
-    _check_tolerance(ref, got, tr_ref, tr, f'half-width N{n_ways}K{k_shots}')
+    _check_tolerance(ref, got, tr_ref, tr, f'half-width N{n_ways}K{k_shots}', cfg=cfg)
     for i in range(2):
         rb, gb = ref[i]['dt_bboxes'], got[i]['dt_bboxes']
         assert got[i]['dt_bboxes'].dtype == np.float32 and got[i]['dt_cat_ids'].dtype == np.int64
@@ -135,7 +166,7 @@ def test_e2e_five_way_build_extension():
     cfg = with_caps(tiny_config(5, 2, width_div=2), rpn_max=1000)
     batch = make_batch(3, 1, 5, 2, 160, 160, 64)
     ref, tr_ref, got, tr = _run(cfg, batch)
-    _check_tolerance(ref, got, tr_ref, tr, 'five-way half-width R<=1000')
+    _check_tolerance(ref, got, tr_ref, tr, 'five-way half-width R<=1000', cfg=cfg)
     assert set(np.unique(got[0]['dt_cat_ids'])) <= set(range(5))
 
 
@@ -152,7 +183,7 @@ def test_e2e_full_width_reference_configs(name):
     ref, tr_ref, got, tr = _run(cfg, batch)
     r = tr_ref['qry_fmap']
     assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
-    _check_tolerance(ref, got, tr_ref, tr, name)
+    _check_tolerance(ref, got, tr_ref, tr, name, cfg=cfg)
     # HIP detections scored against the CPU path's detections as ground truth
     as_gt = dict(got[0])
     as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
@@ -174,7 +205,7 @@ def test_e2e_resnet18_extension_of_cfg2():
     r = tr_ref['qry_fmap']
     assert tuple(r.shape[1:]) == (256, 16, 16)
     assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
-    _check_tolerance(ref, got, tr_ref, tr, 'cfg2 ResNet-18')
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg2 ResNet-18', cfg=cfg)
 
 
 def test_rccl_gather_single_rank():
@@ -301,7 +332,7 @@ def test_cfg3_full_size_parity_and_invariants():
     ref = O.simple_test(sd, cfg, **batch, trace=tr_ref)
     r = tr_ref['qry_fmap']
     assert (_nchw(tr['qry_fmap']) - r).abs().max().item() <= 1e-4 * r.abs().max().item()
-    _check_tolerance(ref, got, tr_ref, tr, 'cfg3')
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg3', cfg=cfg)
     as_gt = dict(g)
     as_gt['qry_bboxes'], as_gt['qry_cat_ids'] = ref[0]['dt_bboxes'], ref[0]['dt_cat_ids']
     as_gt['qry_isegmaps_rle'] = ref[0]['dt_isegmaps_rle']
@@ -440,10 +471,9 @@ def test_two_caller_streams_with_two_episodes_in_flight_are_identical_to_serial_
             if lock:
                 if sent[1 - k]:
                     ops.phase_wait(marks[1 - k:2 - k], sent[1 - k])
-                model.phase_counter = marks[k:k + 1]
                 sent[k] += 1
             dets = model.detect_device(e['qry_img'], e['spp_imgs'], e['spp_bboxes'], e['spp_isegmaps'], e['img_shape'],
-                                       qry_isegmaps=e['qry_isegmaps'])
+                                       qry_isegmaps=e['qry_isegmaps'], phase_counter=marks[k:k + 1] if lock else None)
         pending.append((e, dets))
         if len(pending) > in_flight:
             got.append(finish(pending.pop(0)))
@@ -530,19 +560,27 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
     from fgn_amd.detector import FGN
     from fgn_amd.episodes import CONFIGS, RPN_MAX_PER_IMG, make_batch
     from fgn_amd.weights import init_state_dict
-    # ---- cfg4
+    # ---- cfg4: ONE batch of 8 (the per-GPU share) at 800x1328 against the ORACLE (8 x 1.1 TFLOP on the host cores, once;
+    # the reference's own evaluation call shape is the same code path at batch 4, fgn_test.py:49,108) - proposal sets,
+    # every matched pair, final masks - and against each episode run alone
     cfg = fgn_r50_c4_config(3, 3)
-    model = FGN(3, 3, state_dict=init_state_dict(cfg, 0))
     EPB = 8                                      # BASELINE.json cfg4: 8 episodes per GPU per step
     both = make_batch(40, EPB, **CONFIGS['cfg4'])
-    got2 = model.simple_test(**both, rescale=True)
-    assert len(got2) == EPB
+    ref, tr_ref, got2, tr = _run(cfg, both)
+    assert len(ref) == len(got2) == EPB
+    _check_tolerance(ref, got2, tr_ref, tr, f'cfg4 batch {EPB}', cfg=cfg)
+    del ref, tr_ref, tr
+    model = FGN(3, 3, state_dict=init_state_dict(cfg, 0))
+    untraced = model.simple_test(**both, rescale=True)
     for i in range(EPB):
+        for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+            assert np.array_equal(untraced[i][key], got2[i][key]), (i, key)     # the traced run is the product's bytes
+        assert untraced[i]['dt_isegmaps_rle'] == got2[i]['dt_isegmaps_rle']
         one = make_batch(40 + i, 1, **CONFIGS['cfg4'])
         got1 = model.simple_test(**one, rescale=True)[0]
         a, b = got2[i], got1
         assert a['qry_img_shape'].tolist() == [800, 1328, 3] and int(a['idx']) == 40 + i
-        assert abs(len(a['dt_scores']) - len(b['dt_scores'])) <= 2 and len(b['dt_scores']) > 0
+        assert len(b['dt_scores']) > 0
         pairs, ma, mb = match_detections(a['dt_bboxes'], a['dt_cat_ids'], b['dt_bboxes'], b['dt_cat_ids'])
         ia, ib = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
         ds = np.abs(a['dt_scores'][ia] - b['dt_scores'][ib]).max()
@@ -550,11 +588,6 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
               f'flips {len(ma)}/{len(mb)}, max|d score| {ds:.2e}')
         assert ds <= TOL and len(ma) == 0 and len(mb) == 0      # tile partition differs with the batch: fp32 order; 0 flips observed in every round
     del model
-    # ---- cfg4 against the ORACLE at the reference's own evaluation call shape: batch = 4 (fgn_test.py:49,108;
-    # fgn_train.py:56) at 800x1328 - every matched pair of all four episodes within north_star's tolerance, zero flips
-    ref, tr_ref, got, tr = _run(cfg, make_batch(40, 4, **CONFIGS['cfg4']))
-    assert len(ref) == len(got) == 4
-    _check_tolerance(ref, got, tr_ref, tr, 'cfg4 batch 4')
     # ---- cfg5
     shape = CONFIGS['cfg5']
     cfg5 = with_caps(fgn_r50_c4_config(5, 5), rpn_max=RPN_MAX_PER_IMG['cfg5'])
@@ -593,8 +626,11 @@ def test_cfg4_batched_and_cfg5_full_size_invariants():
     ref, tr_ref, got, tr = _run(cfg5, b5)
     n_ref, n_hip = len(tr_ref['proposals'][0]), int(tr['n_props'][0])
     print(f'[cfg5 full size] proposals ref/hip {n_ref}/{n_hip}, detections {len(ref[0]["dt_scores"])}/{len(got[0]["dt_scores"])}')
-    assert n_ref > 300 and abs(n_ref - n_hip) <= 4
-    _check_tolerance(ref, got, tr_ref, tr, 'cfg5 full size')
+    assert n_ref > 300
+    # ~1000 proposals out of 61 440 anchors with random weights: a few suppression decisions sit on the NMS threshold
+    # (IoU within 1e-4 of 0.7 in one path's arithmetic) - every row of the symmetric difference is printed WITH that
+    # reason and none may be unexplained; the final detections still agree with zero flips
+    _check_tolerance(ref, got, tr_ref, tr, 'cfg5 full size', cfg=cfg5, max_prop_flips=CFG5_PROP_FLIPS)
     for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
         assert np.array_equal(g[key], got[0][key]), key                    # same bytes as the un-traced runs above
 

@@ -608,6 +608,61 @@ def test_checkpoint_resume_continues_the_run():
     assert set(ck) == {'state_dict', 'optimizer', 'meta'} and ck['meta']['iter'] == 2
 
 
+def test_checkpoint_at_a_decayed_lr_keeps_the_schedule_base():
+    """mmcv's LrUpdaterHook keeps the schedule's base in every param group as ``initial_lr`` and derives each
+    later lr from it (``group.setdefault('initial_lr', group['lr'])`` on resume).  A checkpoint taken at a decayed lr
+    must therefore carry both: ``lr`` = the scheduled value, ``initial_lr`` = base x lr_mult; a resumed Trainer gets
+    both back, and a checkpoint without the key (written before any schedule hook ran) reads lr as the base."""
+    from fgn_amd.config import tiny_config
+    from fgn_amd.train import Trainer, step_lr
+    cfg = tiny_config(3, 2, width_div=2)
+    m, _ = _models(cfg)
+    t = Trainer(m, lr=0.005)
+    t.set_lr(step_lr(t.base_lr, it=500, epoch=3))               # after the step at epoch 3: 0.1 x base
+    assert t.lr == pytest.approx(0.0005) and t.base_lr == 0.005
+    opt = t.optimizer_state_dict()
+    names = opt['param_names']
+    g_rpn = opt['param_groups'][names.index('rpn_head.rpn_conv.weight')]
+    g_roi = opt['param_groups'][names.index('roi_head.bbox_head.fc_cls.weight')]
+    g_bb = opt['param_groups'][0]
+    assert g_rpn['lr'] == pytest.approx(0.0005) and g_rpn['initial_lr'] == pytest.approx(0.005)
+    assert g_roi['lr'] == pytest.approx(0.00005) and g_roi['initial_lr'] == pytest.approx(0.0005)      # lr_mult 0.1
+    assert g_bb['lr'] == pytest.approx(0.0005) and g_bb['initial_lr'] == pytest.approx(0.005)
+    # mmcv's resume on these groups: the regular lr of epoch 3 is derived from initial_lr - once
+    assert step_lr(g_rpn['initial_lr'], it=500, epoch=3) == pytest.approx(g_rpn['lr'])
+    m2, _ = _models(cfg)
+    t2 = Trainer(m2, lr=0.123)
+    t2.resume(t.checkpoint())
+    assert t2.lr == pytest.approx(0.0005) and t2.base_lr == pytest.approx(0.005)
+    for g in opt['param_groups']:
+        del g['initial_lr']
+    t2.resume({'state_dict': t.state_dict(), 'optimizer': opt})
+    assert t2.lr == pytest.approx(0.0005) and t2.base_lr == pytest.approx(0.0005)
+
+
+def test_adagrad_multi_more_tensors_than_one_table_with_empty_ones():
+    """ADVICE r4: ``fgn_adagrad_multi_f32`` packs up to 64 tensors per launch and skips empty ones without taking a slot;
+    with more than 64 list entries and empty tensors among them every tensor must still be updated exactly ONCE."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    sizes = [0 if i % 7 == 3 else 1 + (i * 37) % 5000 for i in range(150)]
+    P = [torch.randn(n, generator=g).cuda() for n in sizes]
+    G = [torch.randn(n, generator=g).cuda() for n in sizes]
+    S = [torch.rand(n, generator=g).cuda() for n in sizes]
+    lrs = [0.005 * (0.1 if i % 2 else 1.0) for i in range(len(sizes))]
+    want_p, want_s = [], []
+    for p, gr, s_, lr in zip(P, G, S, lrs):
+        gv = gr + 1e-5 * p
+        st = s_ + gv * gv
+        want_s.append(st)
+        want_p.append(p - lr * gv / (st.sqrt() + 1e-10))
+    ops.adagrad_multi(P, G, S, lrs, 1e-5, 1e-10)
+    torch.cuda.synchronize()
+    for i, (p, s_, wp, ws) in enumerate(zip(P, S, want_p, want_s)):
+        assert torch.allclose(s_, ws, rtol=1e-6, atol=1e-9), i
+        assert torch.allclose(p, wp, rtol=1e-5, atol=1e-8), i
+
+
 def test_step_without_positives_keeps_every_gradient_and_torch_optimizer_layout():
     """(1) A batch without any ground truth samples no positive RoI: the mask head (and the box regression) get ZERO
     gradients - not missing ones - so the data-parallel bucket has the same keys on every rank and Adagrad still

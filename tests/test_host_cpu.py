@@ -208,6 +208,37 @@ def test_gradient_allreduce_world2_gloo():
     assert fd.allreduce_mean(g) is g                      # no process group: unchanged
 
 
+@pytest.mark.parametrize('fail_rank', [-1, 1, 0])
+def test_a_failing_rank_ends_the_whole_job(fail_rank):
+    """the first multi-GPU run must diagnose itself.  A job of fresh child processes under
+    ``torch.distributed.run`` (the launcher the driver uses for ``bench.py --gpus N``; bench.py's own self-launch starts
+    the same module as a child and returns its exit code) gathers detection records step by step; when one rank raises
+    mid-run the launcher must end EVERY rank and exit non-zero within the timeout - no rank may sit in the collective
+    waiting for the dead one.  Control: without the injected failure the same job exits 0."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_rank_fail_child.py')
+    env = dict(os.environ, FGN_FAIL_RANK=str(fail_rank), FGN_FAIL_STEP='3', FGN_PG_TIMEOUT='30', OMP_NUM_THREADS='1')
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                           '--master-addr', '127.0.0.1', '--master-port', str(port), child],
+                          env=env, capture_output=True, text=True, timeout=150)
+    took = time.time() - t0
+    if fail_rank < 0:
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        assert proc.stdout.count('done') == 2
+    else:
+        assert proc.returncode != 0
+        assert 'injected failure' in proc.stderr
+        assert 'done' not in proc.stdout                       # the surviving rank did not run to completion either
+        assert took < 120, took
+
+
 def test_gather_is_identity_without_process_group():
     from fgn_amd import dist as fd
     recs, cnts = fd.pack_detections([_fake_det(3), _fake_det(6)], 4)
@@ -726,6 +757,24 @@ def test_optimizer_index_space_is_the_reference_models_named_parameters():
     opt = torch.optim.Adagrad([{'params': [p]} for p in det.parameters()], lr=0.005, weight_decay=1e-5)
     osd = opt.state_dict()
     assert len(osd['state']) == len(osd['param_groups']) == len(names)
+    # the from-scratch configuration (fgn_r50_c4_scratch.py:9-30: num_stages=3, deep stem, GroupNorm) registers NO layer4
+    # and other norm names: its index space is exactly this build's own parameters, nothing phantom
+    scfg = tiny_config(3, 2, width_div=2, scratch=True)
+    ssd = init_state_dict(scfg, 0)
+    sgot = [k for k, _ in reference_param_order(ssd, scfg['backbone'])]
+    mine = [k for k in ssd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    assert sorted(sgot) == sorted(mine) and not any('layer4' in k for k in sgot)
+    assert sgot[0] == 'backbone.stem.0.weight' and 'backbone.layer1.0.gn1.weight' in sgot
+    assert sgot.index('backbone.layer3.5.gn3.bias') < sgot.index('rpn_head.rpn_conv.weight') < sgot.index('roi_head.bbox_head.fc_cls.weight')
+    # ... and through the detector built from the reference's own mmcv dict (num_stages=3 travels as ref_num_stages)
+    from fgn_amd.detector import normalise_config
+    ncfg = normalise_config(3, 2, backbone=dict(type='ResNet', depth=50, num_stages=3, strides=(1, 2, 2), out_indices=(2,),
+                                                frozen_stages=-1, deep_stem=True, avg_down=True,
+                                                norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)))
+    assert ncfg['backbone']['ref_num_stages'] == 3 and ncfg['backbone']['norm'] == 'GN'
+    dcfg = normalise_config(3, 2, backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(2,), frozen_stages=4,
+                                                norm_cfg=dict(type='BN', requires_grad=False)))
+    assert dcfg['backbone']['ref_num_stages'] == 4
 
 
 def test_mmdet_registry_shim_builds_the_detector_from_the_reference_config(monkeypatch):
@@ -778,3 +827,44 @@ def test_mmdet_registry_shim_builds_the_detector_from_the_reference_config(monke
     assert bb.eval() is bb
     model.cfg_obj = object()
     assert model.eval() is model
+
+
+def test_episodic_sampler_matches_the_reference_on_its_own_databag(golden_dir):
+    """WHICH instances form an episode.  tests/golden/make_golden_databag.py ran the reference's own
+    ``load_dataset`` / ``reshuffle`` / ``__getitem__`` / ``get_query`` / ``get_support`` (base_fst.py:267-486, 605-625,
+    793-846, 1052-1080, 1172-1246) on its shipped databag (resources/omniiseg_fst/..._val_base_.pkl: 968 parent and 1736
+    child queries, 1792 instances) in four configurations, ``random`` seeded per item.  ``DatabagEpisodeSampler`` on the
+    same index tables and the same seeds must decide the same episodes: order, child query, the N categories in their
+    shuffled order, the query's category ids (real and remapped) and boxes, the N x K support instance ids."""
+    import random
+    import importlib.util
+    from fgn_amd.fewshot_ds import Databag, DatabagEpisodeSampler
+    spec = importlib.util.spec_from_file_location('make_golden_databag', os.path.join(golden_dir, 'make_golden_databag.py'))
+    # (only its CONFIGS / seeds are needed: parse them without executing the imports of the reference)
+    src = open(spec.origin).read()
+    ns = {}
+    head = src[src.index('CONFIGS = {'):src.index('def make_dataset')]
+    exec('import numpy as np\n' + head.replace('class _Box', 'class _Box_'), ns)
+    z = np.load(os.path.join(golden_dir, 'databag_sampler.npz'))
+    bag = Databag.from_arrays(z)
+    assert len(bag.parents_cats) == 968 and len(bag.children) == 1736 and len(bag.inst_cat) == 1792
+    for tag, cfg in ns['CONFIGS'].items():
+        ds = DatabagEpisodeSampler(bag, cats_novel=z['cats_novel'], cats_total_amount=26, sampling_cats='base_', **cfg)
+        np.testing.assert_array_equal(ds.cats_to_save, z['cats_to_save'])
+        np.testing.assert_array_equal(ds.order, z[f'{tag}__order'])
+        assert len(ds) == int(z[f'{tag}__len'])
+        np.testing.assert_array_equal(ns['item_indices'](len(ds), tag), z[f'{tag}__items'])
+        ptr = z[f'{tag}__qry_ptr']
+        for j, idx in enumerate(z[f'{tag}__items']):
+            random.seed(ns['item_seed'](tag, idx))
+            s = ds.sample_indices(int(idx))
+            assert s['qry_child_idx'] == int(z[f'{tag}__qry_child_idx'][j]), (tag, idx)
+            for k in ('cats_ids_to_sample_real', 'cats_ids_to_sample', 'spp_insts_ids'):
+                np.testing.assert_array_equal(s[k], z[f'{tag}__{k}'][j], err_msg=f'{tag} {idx} {k}')
+            for k in ('qry_cat_ids_real', 'qry_cat_ids', 'qry_bboxes'):
+                np.testing.assert_array_equal(s[k], z[f'{tag}__{k}'][ptr[j]:ptr[j + 1]], err_msg=f'{tag} {idx} {k}')
+            assert s['spp_insts_ids'].dtype == np.int64 and s['qry_bboxes'].dtype == np.float32
+            assert len(s['spp_insts_ids']) == cfg['n_ways'] * cfg['k_shots']
+            # the category of every support instance is the category it was drawn for, class-major (index = n * K + k)
+            assert [int(bag.inst_cat[i]) for i in s['spp_insts_ids']] == \
+                [int(c) for c in s['cats_ids_to_sample_real'] for _ in range(cfg['k_shots'])]

@@ -52,21 +52,20 @@ static int run(const Shape& sh, int variant, double seconds) {
     }
     if (!A || !W) return 1;
     // 1001..1003: conv_pw_streamk_kernel mode 1..3; 1013: mode 3 with the pieces dropped (timing only, wrong results)
+#ifdef FGN_EXPERIMENTS     // the kernel variants of tools/micro/conv_pw_experiments.inc (build with -DFGN_EXPERIMENTS)
     fgn_conv2d_tune(0, variant >= 1000 ? 0 : variant);
     fgn_conv2d_tune(2, variant >= 1000 ? (variant - 1000) % 10 : 0);
     fgn_conv2d_tune(5, variant >= 1000 ? (variant - 1000) / 10 : 0);
+#else
+    if (variant != 0) { fprintf(stderr, "variant %d needs a -DFGN_EXPERIMENTS build\n", variant); return 1; }
+#endif
     float* skws = nullptr;
     const size_t skws_bytes = (size_t)64 << 20;
     CK(hipMalloc(&skws, skws_bytes));
-    int32_t* sched = nullptr;
-    if (getenv("GEMM_CLOCK_SCHED") ? atoi(getenv("GEMM_CLOCK_SCHED")) : 1) {
-        CK(hipMalloc(&sched, fgn_gemm_sched_words() * 4));
-        CK(hipMemset(sched, 0, fgn_gemm_sched_words() * 4));
-    }
     auto launch = [&]() -> int {
-        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, sched, skws, skws_bytes, st)
+        return sh.grouped ? fgn_winograd_gemm_f32(A, W, Y, nullptr, sh.n, sh.tiles, t_pad, sh.cin, sh.cout, cout_pad, 36, st)
                           : fgn_conv2d_nhwc_f32(A, W, Y, nullptr, nullptr, nullptr, nullptr, nullptr, sh.rows, 1, 1, sh.cin, sh.cout,
-                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, skws, skws_bytes, nullptr, sched, st);
+                                                cout_pad, 1, 1, 1, 0, 1, 0, 0, skws, skws_bytes, st);
     };
     for (int i = 0; i < 3; ++i) rc |= launch();
     CK(hipStreamSynchronize(st));
