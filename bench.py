@@ -115,6 +115,11 @@ def parse_args():
                          "wait for them): 'last' (default: the final step, whose tail runs alone anyway), 'none', or a "
                          "comma list such as 5,20,35 (profiles/: three spread steps of a 60-step run; each costs the window "
                          "~1.5 ms of lost overlap)")
+    ap.add_argument('--launch-records', action='store_true',
+                    help='arm the launch records of the dominant kernel inside the captured graphs (roofline.timed_window: '
+                         'every launch of every timed step on the in-kernel 100 MHz clock).  Off by default: a recorded launch '
+                         'pays a returning atomic per workgroup at its exit, ~1 us per launch (measured r05: a first form '
+                         'with all 1024 workgroups on one counter cost the step 4-7 %)')
     ap.add_argument('--cache-supports', action='store_true',
                     help='not the headline: encode each support set once (SURVEY 8f row 3) and time query passes only')
     args = ap.parse_args()
@@ -299,6 +304,8 @@ def main():
         model.use_merged_support_head = os.environ['FGN_MERGED_SUPPORT_HEAD'] != '0'
     if os.environ.get('FGN_SIDE_STREAM'):
         model.use_side_stream = os.environ['FGN_SIDE_STREAM'] != '0'
+    if os.environ.get('FGN_PACKED_TRANSFERS'):
+        model.use_packed_transfers = os.environ['FGN_PACKED_TRANSFERS'] != '0'
 
     # distinct seeded episodes per rank in PINNED host memory (what a DataLoader with pin_memory hands over);
     # every step copies its episode to the device (--resident-inputs: parked in HBM instead, not the headline)
@@ -492,7 +499,7 @@ def main():
     # pin the host slots and let every kernel set its LDS attribute once
     prime = ops.ConvProfile()
     n_setup = 2 * len(ep_streams)         # every caller stream captures its hipGraph here, not in a warm-up / timed step
-    model.stamp_capacity = 256            # the captured graphs carry launch records of the dominant kernel (ops.read_stamps)
+    model.stamp_capacity = 256 if args.launch_records else 0     # launch records of the dominant kernel inside the graphs
     run(n_setup + 1, prof=prime, prof_steps=(n_setup,))   # also creates the first timing events (a one-time ~40 ms in HIP)
     # Instrumentation (timing events are created here, outside the timed region: HIP grows its event pool in bursts that
     # cost tens of ms):

@@ -123,13 +123,17 @@ def proposal_set_difference(ref_props, got_props, iou_thr: float, max_per_img: i
     return out
 
 
-def mask_iou_of_pairs(ref_rles, got_rles, pairs) -> np.ndarray:
-    """IoU of the FINAL binary masks (decoded COCO RLE, what ``dt_isegmaps_rle`` carries) of every matched pair."""
+def mask_iou_of_pairs(ref_rles, got_rles, pairs):
+    """The FINAL binary masks (decoded COCO RLE, what ``dt_isegmaps_rle`` carries) of every matched pair:
+    (IoU [n], differing pixels [n])."""
     from . import rle
-    out = np.ones(len(pairs))
+    iou, diff = np.ones(len(pairs)), np.zeros(len(pairs), np.int64)
     for k, (i, j) in enumerate(pairs):
+        if ref_rles[i] == got_rles[j]:
+            continue
         a, b = rle.decode(ref_rles[i]).astype(bool), rle.decode(got_rles[j]).astype(bool)
         union = np.logical_or(a, b).sum()
+        diff[k] = int(np.logical_xor(a, b).sum())
         if union:
-            out[k] = np.logical_and(a, b).sum() / union
-    return out
+            iou[k] = np.logical_and(a, b).sum() / union
+    return iou, diff

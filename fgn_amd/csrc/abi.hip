@@ -17,9 +17,10 @@ extern "C" int fgn_profile_next_launch(void* start_event, void* stop_event) {
 thread_local unsigned long long* fgn_stamp_base = nullptr;
 thread_local int fgn_stamp_next = 0, fgn_stamp_cap = 0;
 // Arm (records != NULL) / disarm the calling thread for launch records (common.h).  `records`: device memory, `capacity`
-// records of 8 x uint64, initialised by the caller to {~0, 0, 0, 0, ~0, 0, 0, 0} = {first start of the execution in
-// flight, sum of durations, workgroups arrived, executions, shortest, longest, -, -} in 10 ns ticks.  Returns the number
-// of records handed out since the last arming (the launches recorded, in launch order).
+// records of fgn_profile_stamp_words() x uint64, all zero except word 4 = ~0: {start of the execution in flight, sum of
+// spans, shards arrived, executions, shortest, longest, -, -, then eight shard counters on lines of their own} in 10 ns
+// ticks.  Returns the number of records handed out since the last arming (the launches recorded, in launch order).
+extern "C" int fgn_profile_stamp_words(void) { return FGN_STAMP_WORDS; }
 extern "C" int fgn_profile_stamps(void* records, int capacity) {
     const int used = fgn_stamp_next;
     fgn_stamp_base = reinterpret_cast<unsigned long long*>(records);

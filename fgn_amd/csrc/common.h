@@ -34,14 +34,15 @@ extern thread_local hipEvent_t fgn_prof_stop;
     } while (0)
 
 // Launch records of the dominant kernel that work INSIDE a replayed hipGraph (fgn_profile_stamps): while the calling
-// thread is armed, every launch of conv_pw_persist_kernel is handed the next 64-byte record of the caller's device
-// buffer; the kernel folds each of its executions into that record (first workgroup start -> last workgroup end on the
-// 100 MHz s_memrealtime clock: count, sum, min, max).  nullptr: the kernel executes no stamp instruction.
+// thread is armed, every launch of conv_pw_persist_kernel is handed the next record (FGN_STAMP_WORDS uint64) of the
+// caller's device buffer; the kernel folds each of its executions into that record (first workgroup start -> last
+// workgroup end on the 100 MHz s_memrealtime clock: count, sum, min, max).  nullptr: no stamp instruction executes.
+constexpr int FGN_STAMP_WORDS = 72;      // uint64 per record: one 64-byte header line + eight 64-byte shard lines
 extern thread_local unsigned long long* fgn_stamp_base;
 extern thread_local int fgn_stamp_next, fgn_stamp_cap;
 static inline unsigned long long* fgn_next_stamp_record() {
     if (!fgn_stamp_base || fgn_stamp_next >= fgn_stamp_cap) return nullptr;
-    return fgn_stamp_base + 8 * (size_t)fgn_stamp_next++;
+    return fgn_stamp_base + FGN_STAMP_WORDS * (size_t)fgn_stamp_next++;
 }
 
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the

@@ -293,12 +293,43 @@ class _BottleneckGN:
         return self._norm(ops.conv2d(y, self.conv3), 2, True, residual=idt)   # relu(gn3(conv3) + identity)
 
 
+class _ResultRecord:
+    """Every per-image output of one batch in ONE buffer (device, or its pinned host mirror): the selection / mask
+    kernels write straight into its views and ONE device-to-host copy moves it (round 5: the nine small copies per
+    episode it replaces were ~6 us blit kernels each on the caller stream).  Layout, 256-byte aligned fields:
+    [n_dets | rle_len | rle_overflow | mask_prob] (the zero-initialised head) | det_bboxes | det_labels | rle bytes."""
+
+    def __init__(self, batch: int, max_det: int, mask_size: int, device=None, pinned: bool = False):
+        self.key = (batch, max_det, mask_size, ops.RLE_BYTE_CAP)
+        off, spec = 0, []
+        for name, shape, dtype in (('cnt', (batch, 1), torch.int32), ('rle_len', (batch, max_det), torch.int32),
+                                   ('rle_ovf', (batch, max_det), torch.int32),
+                                   ('prob', (batch, max_det, mask_size, mask_size), torch.float32), (None, None, None),
+                                   ('det', (batch, max_det, 5), torch.float32), ('lab', (batch, max_det), torch.int64),
+                                   ('rle', (batch, max_det, ops.RLE_BYTE_CAP), torch.uint8)):
+            if name is None:
+                self.zero_bytes = off
+                continue
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            spec.append((name, shape, dtype, off, n))
+            off = (off + n + 255) // 256 * 256
+        self.nbytes = off
+        self.buf = torch.empty(off, dtype=torch.uint8, pin_memory=True) if pinned else \
+            torch.empty(off, dtype=torch.uint8, device=device)
+        for name, shape, dtype, o, n in spec:
+            setattr(self, name, self.buf[o:o + n].view(dtype).view(*shape))
+
+    def clear_head(self) -> None:
+        self.buf[:self.zero_bytes].zero_()
+
+
 class _GraphedEpisode:
     """The launch sequence of ``FGN._detect_eager`` for one input geometry, captured once as a
     hipGraph (both HIP streams of the path fork from and join the capture stream).  Inputs are copied
     into static device buffers (this copy is the H2D step of fgn.py:79-108 when the batch arrives on
     the host), outputs live in static buffers that the next replay overwrites - so the replay waits
-    for the previous download, and the two tensors the rare RLE-overflow fallback reads are cloned."""
+    for the previous download; that download (one copy of the batch's result record) carries every tensor
+    ``pack_results`` may read."""
     CODE_KEYS = ('vec', 'S', 'cat_mean_mp')
 
     def __init__(self, model, ins: dict, img_shape, support_code, dev, phase_counter=None):
@@ -339,7 +370,8 @@ class _GraphedEpisode:
 
     def run(self, model, ins: dict, support_code, main) -> list:
         for k, v in ins.items():
-            self.static[k].copy_(v, non_blocking=True)
+            if v is not self.static[k]:                # (already uploaded straight into the static buffer: detect_device)
+                self.static[k].copy_(v, non_blocking=True)
         if support_code is not None:
             for k in self.CODE_KEYS:
                 if support_code[k].data_ptr() != self.code[k].data_ptr():
@@ -347,12 +379,9 @@ class _GraphedEpisode:
         if self.last_download is not None:
             main.wait_event(self.last_download)       # static outputs are still being read by the copy stream
         self.graph.replay()
-        outs = []
-        for d in self.outs:
-            d = dict(d)
-            d['mask_prob'], d['det_bboxes_copy'] = d['mask_prob'].clone(), d['det_bboxes'].clone()
-            outs.append(d)
-        return outs          # detect_device queues the download and sets ``last_download``
+        # (the static outputs are views of the batch's result record: its one download carries everything pack_results
+        # reads, the mask probabilities and boxes of the rare RLE-overflow fallback included)
+        return [dict(d) for d in self.outs]          # detect_device queues the download and sets ``last_download``
 
 
 class FGN(torch.nn.Module):
@@ -416,6 +445,10 @@ class FGN(torch.nn.Module):
         # (106 MB at cfg3) is never written; False = the two launches of rounds 1-4 (identical bytes)
         self.use_stem_pool_fusion = ops.STEM_POOL_FUSION
         self.transfer_mode = 0                    # 0: upload + copy stream per caller; 1 / 2: see transfer_stream()
+        # one device-to-host copy per batch (every output lands in one `_ResultRecord`) and, under graph replay with the
+        # transfers on the caller stream, host inputs copied straight into the graph's static buffers (round 5: 15 -> 6
+        # small copies per episode on the caller stream); False = the per-field copies of rounds 1-4 (A/B knob)
+        self.use_packed_transfers = True
         self.stamp_capacity = 0                   # > 0: captured graphs carry launch records of the dominant kernel (ops.read_stamps)
         self._graphs: dict = {}
         self._streams: dict = {}                  # (role, caller stream) -> HIP stream: 'side', 'copy', 'upload'
@@ -755,7 +788,7 @@ class FGN(torch.nn.Module):
             x, y1 = ops.roi_align(fmap, rois, PS, inv, rh['roi_sampling_ratio'], True, n_dev), None
         return x, self._shared_head(x, n_dev, y1=y1)
 
-    def _mask_head(self, mf, vmask, n_dev=None):
+    def _mask_head(self, mf, vmask, n_dev=None, prob_out=None):
         """``_mask_forward`` after the shared_head (fgn_roi_head.py:379-380): support-vector guidance, FCNMaskHead
         (4 x conv3x3+ReLU, ConvTranspose 2x2/2 + ReLU as one 1x1 conv with 4*C' outputs, 1x1 logits), sigmoid.
         mf [D,7,7,C], vmask [D,C] -> logits, probabilities [D,14,14]."""
@@ -768,7 +801,8 @@ class FGN(torch.nn.Module):
             else:
                 m = ops.conv2d(m, layer, in_scale=scale, n_img_dev=n_dev)
         up = ops.conv2d(m, P['upsample'], n_img_dev=n_dev)                         # [D,7,7,4*C']
-        return ops.mask_logits(up, P['logit_w'], P['logit_b'], self.cfg['roi_head']['roi_out_size'], n_dev)
+        return ops.mask_logits(up, P['logit_w'], P['logit_b'], self.cfg['roi_head']['roi_out_size'], n_dev,
+                               prob_out=prob_out)
 
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
@@ -918,12 +952,14 @@ class FGN(torch.nn.Module):
         self.transfer_mode = int(mode)
         return self._stream_for('upload', torch.cuda.current_stream())
 
-    def _upload(self, tensors: dict, gt_masks, dev, main):
+    def _upload(self, tensors: dict, gt_masks, dev, main, into: Optional[dict] = None):
         """``modify_input`` (fgn.py:79-108): host -> device copies of one batch, on an upload stream so that they
         overlap the previous batch's kernels (a pinned source makes them asynchronous); the compute streams wait
         on one event.  Tensors already on the device pass through.  The ground-truth masks (copied to the GPU by
         the reference too, fgn.py:95) are run-length encoded right there (``qry_isegmaps_rle``, fgn.py:298): two
-        small kernels on the upload stream instead of ~4 ms of host work per 800x1333 episode."""
+        small kernels on the upload stream instead of ~4 ms of host work per 800x1333 episode.  ``into``: device
+        tensors to copy INTO (the static input buffers of a captured graph, when the upload stream is the caller
+        stream itself and so ordered behind the previous replay that reads them) instead of fresh allocations."""
         gts = None
         if gt_masks is not None:
             gts = [g if isinstance(g, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(g)) for g in gt_masks]
@@ -936,16 +972,21 @@ class FGN(torch.nn.Module):
         out, gt_out = {}, None
         with torch.cuda.stream(up):
             for k, t in tensors.items():
-                out[k] = None if t is None else t.to(dev, non_blocking=True)
+                if t is not None and into is not None and k in into and not t.is_cuda and into[k].dtype == t.dtype \
+                        and into[k].shape == t.shape:
+                    into[k].copy_(t, non_blocking=True)
+                    out[k] = into[k]
+                else:
+                    out[k] = None if t is None else t.to(dev, non_blocking=True)
             if gts is not None:
                 gt_out = []
                 for g in gts:
                     g = g.to(dev, non_blocking=True)
                     g = g if g.dtype in (torch.bool, torch.uint8) else (g != 0)
-                    gt_out.append(ops.dense_mask_rle(g.contiguous()))
+                    gt_out.append(ops.dense_mask_rle(g.contiguous(), packed=True))
             ready = up.record_event()
-        for t in out.values():
-            if t is not None:
+        for k, t in out.items():
+            if t is not None and not (into is not None and t is into.get(k)):
                 t.record_stream(main)
         return out, gt_out, ready
 
@@ -969,12 +1010,18 @@ class FGN(torch.nn.Module):
         ins = {'qry_img': qry_img}
         if support_code is None:
             ins.update(spp_imgs=spp_imgs, spp_bboxes=spp_bboxes, spp_isegmaps=spp_isegmaps)
-        ins, gt_rle, uploaded = self._upload(ins, qry_isegmaps, dev, main)
-        if uploaded is not None:
-            main.wait_event(uploaded)
         graphed = self.use_graphs and self.debug_trace is None and ops.PROFILE is None
         if phase_counter is None:
             phase_counter = self.phase_counter
+        # graph replay with the transfers on the caller stream: host tensors go straight into the graph's static input
+        # buffers (the caller stream orders the copy behind the previous replay that reads them) - no device-to-device hop
+        into = None
+        if graphed and self.use_packed_transfers and self._stream_for('upload', main) is main:
+            ge0 = self._graphs.get(self._graph_key(ins, img_shape, support_code, phase_counter, main, dev))
+            into = ge0.static if ge0 is not None else None
+        ins, gt_rle, uploaded = self._upload(ins, qry_isegmaps, dev, main, into=into)
+        if uploaded is not None:
+            main.wait_event(uploaded)
         if graphed:
             ge, outs = self._detect_graphed(ins, img_shape, support_code, phase_counter)
         else:
@@ -988,19 +1035,22 @@ class FGN(torch.nn.Module):
             ge.last_download = outs[0]['host_ready']
         return outs
 
-    def _detect_graphed(self, ins: dict, img_shape, support_code, phase_counter=None):
-        main = torch.cuda.current_stream()
-        dev = torch.device('cuda', torch.cuda.current_device())
+    def _graph_key(self, ins: dict, img_shape, support_code, phase_counter, main, dev) -> tuple:
         hw = tuple((int(s[0]), int(s[1])) for s in img_shape)
         # everything the captured launch sequence depends on besides the weights (those drop ``_graphs`` when they
         # change): the paste semantic is an argument of the captured RLE kernel, the transfer arrangement decides which
         # streams the capture forks, and the phase mark is a captured kernel with the counter's address in its arguments
         self._skip_empty()
         mark = None if (phase_counter is None or not self.phase_point) else (phase_counter.data_ptr(), self.phase_point)
-        key = (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone),
-               bool(self.use_merged_support_head), self.paste_semantics, int(self.transfer_mode), mark,
-               bool(self.use_side_stream), bool(self.use_stem_pool_fusion)) + \
-            tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items())
+        return (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone),
+                bool(self.use_merged_support_head), self.paste_semantics, int(self.transfer_mode), mark,
+                bool(self.use_side_stream), bool(self.use_stem_pool_fusion), bool(self.use_packed_transfers)) + \
+            tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items() if v is not None)
+
+    def _detect_graphed(self, ins: dict, img_shape, support_code, phase_counter=None):
+        main = torch.cuda.current_stream()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        key = self._graph_key(ins, img_shape, support_code, phase_counter, main, dev)
         ge = self._graphs.get(key)
         if ge is None:
             ge = self._graphs[key] = _GraphedEpisode(self, ins, img_shape, support_code, dev, phase_counter)
@@ -1186,10 +1236,15 @@ class FGN(torch.nn.Module):
         Q = ops.conv2d(feats, P['rel_q'], n_img_dev=cnt_all)
         cls_raw, reg_raw = ops.relation_gn_head(Q, S, rois_all, P['gn_w'], P['gn_b'], P['fc_w'], P['fc_b'], N,
                                                 rel['gn_groups'], rel['gn_eps'], cnt_all)
+        # the batch's result record: detections, labels, counts, mask probabilities and RLE strings land in one buffer
+        rec = _ResultRecord(B, D, 2 * PS, dev)
+        rec.clear_head()
+        packed = self.use_packed_transfers
         # one selection workgroup per image, one launch for the batch
         det_all, lab_all, n_det_all, mrois_all = ops.det_post(
             rois_all, cls_raw, reg_raw, N, ih, iw, bh['target_means'], bh['target_stds'], tc['rcnn']['score_thr'],
-            tc['rcnn']['nms_iou_threshold'], D, n_props, img_index=0, batch=B)      # mrois_all [B*D,5] = bbox2roi
+            tc['rcnn']['nms_iou_threshold'], D, n_props, img_index=0, batch=B,
+            out=(rec.det.view(B * D, 5), rec.lab.view(B * D), rec.cnt.view(B)))      # mrois_all [B*D,5] = bbox2roi
         dets = [det_all[i * D:(i + 1) * D] for i in range(B)]
         labs = [lab_all[i * D:(i + 1) * D] for i in range(B)]
         n_dets = [n_det_all[i:i + 1] for i in range(B)]
@@ -1198,7 +1253,7 @@ class FGN(torch.nn.Module):
         nd_all = n_dets[0] if B == 1 else None
         vmask = ops.gather_support_vectors(cat_mean_mp, lab_all, mrois_all, N, nd_all)
         _, mf = self._roi_feats(qry_fmap, g_map, mrois_all, nd_all)
-        mlog, mprob = self._mask_head(mf, vmask, nd_all)
+        mlog, mprob = self._mask_head(mf, vmask, nd_all, prob_out=rec.prob.view(B * D, 2 * PS, 2 * PS))
         outs = []
         for i in range(B):
             det, lab, n_det = dets[i], labs[i], n_dets[i]
@@ -1206,7 +1261,8 @@ class FGN(torch.nn.Module):
             # paste + threshold + COCO RLE fused on device: the D x H x W masks are never written
             skip_empty = self._skip_empty()
             rle_bytes, rle_len, rle_ovf = ops.mask_rle(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det,
-                                                       skip_empty=skip_empty)
+                                                       skip_empty=skip_empty,
+                                                       out=(rec.rle[i], rec.rle_len[i], rec.rle_ovf[i]))
             if tr is not None:
                 masks = ops.mask_paste(mp_i, det, ih, iw, tc['rcnn']['mask_thr_binary'], n_det, skip_empty=skip_empty)
                 tr.setdefault('per_image', []).append(dict(
@@ -1215,37 +1271,32 @@ class FGN(torch.nn.Module):
                     det=det, lab=lab, n_det=n_det, mask_logits=mlog[i * D:(i + 1) * D], mask_prob=mp_i,
                     masks=masks, mask_feats=mf[i * D:(i + 1) * D]))
             outs.append(dict(det_bboxes=det, det_labels=lab, n_dets=n_det, mask_prob=mp_i, rle_bytes=rle_bytes,
-                             rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw)))
+                             rle_len=rle_len, rle_overflow=rle_ovf, img_hw=(ih, iw), record=rec if packed else None))
         return outs
 
     MAX_SLOTS = 64
 
-    def _pinned_slot(self, batch: int, max_det: int, n_gt: int) -> dict:
+    def _pinned_slot(self, batch: int, max_det: int, n_gt: int, mask_size: int = 14) -> dict:
         """A free pinned host slot for one batch's results (pinned allocation is slow, so slots are kept per
-        (batch, max_det) and reused).  A slot is busy from ``detect_device`` until ``pack_results`` has read it;
-        when every slot is busy (more batches in flight than ever before) another one is allocated."""
-        key = (batch, max_det, ops.RLE_BYTE_CAP)
+        (batch, max_det, mask size) and reused): the host mirror of a ``_ResultRecord`` plus a byte buffer for the
+        packed ground-truth RLE.  A slot is busy from ``detect_device`` until ``pack_results`` has read it; when every
+        slot is busy (more batches in flight than ever before) another one is allocated."""
+        key = (batch, max_det, mask_size, ops.RLE_BYTE_CAP)
         ring = self._pinned.setdefault(key, [])
         slot = next((s for s in ring if not s['busy']), None)
-        pin = lambda *shape, dtype: torch.empty(shape, dtype=dtype, pin_memory=True)
         if slot is None:
             if len(ring) >= self.MAX_SLOTS:
                 raise ops._lib.FgnHipError(f'{self.MAX_SLOTS} batches are in flight without pack_results(); '
                                            'pack (or drop and call release_results on) earlier detect_device outputs')
-            slot = dict(key=key, busy=False, gt_cap=0,
-                        det=pin(batch, max_det, 5, dtype=torch.float32),
-                        lab=pin(batch, max_det, dtype=torch.int64),
-                        cnt=pin(batch, 1, dtype=torch.int32),
-                        rle_len=pin(batch, max_det, dtype=torch.int32),
-                        rle_ovf=pin(batch, max_det, dtype=torch.int32),
-                        rle=pin(batch, max_det, ops.RLE_BYTE_CAP, dtype=torch.uint8))
+            rec = _ResultRecord(batch, max_det, mask_size, pinned=True)
+            slot = dict(key=key, busy=False, gt_cap=0, rec=rec, det=rec.det, lab=rec.lab, cnt=rec.cnt, rle_len=rec.rle_len,
+                        rle_ovf=rec.rle_ovf, rle=rec.rle, prob=rec.prob)
             ring.append(slot)
         if n_gt > slot['gt_cap']:
             # generous from the start: growing a slot is a pinned allocation (~5 ms of host time) in the middle of a
             # pipelined run - with caps of 2 x the first count seen, slots kept growing for dozens of steps
             cap = max(64, 2 * n_gt)
-            slot.update(gt_cap=cap, gt_rle=pin(cap, ops.RLE_BYTE_CAP, dtype=torch.uint8),
-                        gt_len=pin(cap, dtype=torch.int32), gt_ovf=pin(cap, dtype=torch.int32))
+            slot.update(gt_cap=cap, gt_buf=torch.empty(cap * (ops.RLE_BYTE_CAP + 8), dtype=torch.uint8, pin_memory=True))
         slot['busy'] = True
         return slot
 
@@ -1262,30 +1313,39 @@ class FGN(torch.nn.Module):
         cp = self._stream_for('copy', main)
         max_det = outs[0]['det_bboxes'].shape[0]
         n_gt = sum(d['gt_rle'][1].shape[0] for d in outs if 'gt_rle' in d)
-        slot = self._pinned_slot(len(outs), max_det, n_gt)
+        rec = outs[0].get('record')
+        slot = self._pinned_slot(len(outs), max_det, n_gt, outs[0]['mask_prob'].shape[-1])
         cp.wait_stream(main)
         if also_wait is not None:
             cp.wait_event(also_wait)           # the ground-truth RLE kernels run on the upload stream
         with torch.cuda.stream(cp):
+            if rec is not None and rec.key == slot['rec'].key:
+                # ONE copy for the batch: detections, labels, counts, RLE strings and lengths, mask probabilities
+                slot['rec'].buf.copy_(rec.buf, non_blocking=True)
+                rec.buf.record_stream(cp)
+            else:                  # outputs assembled by hand (tests): field by field
+                for i, d in enumerate(outs):
+                    for dst, src in (('det', 'det_bboxes'), ('lab', 'det_labels'), ('cnt', 'n_dets'), ('rle_len', 'rle_len'),
+                                     ('rle_ovf', 'rle_overflow'), ('rle', 'rle_bytes'), ('prob', 'mask_prob')):
+                        slot[dst][i].copy_(d[src].reshape(slot[dst][i].shape), non_blocking=True)
+                        d[src].record_stream(cp)
             g0 = 0
-            for i, d in enumerate(outs):
-                slot['det'][i].copy_(d['det_bboxes'], non_blocking=True)
-                slot['lab'][i].copy_(d['det_labels'], non_blocking=True)
-                slot['cnt'][i].copy_(d['n_dets'], non_blocking=True)
-                slot['rle_len'][i].copy_(d['rle_len'], non_blocking=True)
-                slot['rle_ovf'][i].copy_(d['rle_overflow'], non_blocking=True)
-                slot['rle'][i].copy_(d['rle_bytes'], non_blocking=True)
-                for k in ('det_bboxes', 'det_labels', 'n_dets', 'rle_len', 'rle_overflow', 'rle_bytes'):
-                    d[k].record_stream(cp)
+            row = ops.RLE_BYTE_CAP + 8
+            for d in outs:
                 if 'gt_rle' in d:
-                    gb, gl, go = d['gt_rle']
-                    n = gl.shape[0]
+                    n = d['gt_rle'][1].shape[0]
                     if n:
-                        slot['gt_rle'][g0:g0 + n].copy_(gb, non_blocking=True)
-                        slot['gt_len'][g0:g0 + n].copy_(gl, non_blocking=True)
-                        slot['gt_ovf'][g0:g0 + n].copy_(go, non_blocking=True)
-                        for t in (gb, gl, go):
-                            t.record_stream(cp)
+                        if len(d['gt_rle']) == 4:        # packed [lens | overflow | bytes]: one copy per image
+                            slot['gt_buf'][g0 * row:(g0 + n) * row].copy_(d['gt_rle'][3], non_blocking=True)
+                            d['gt_rle'][3].record_stream(cp)
+                        else:
+                            hb = slot['gt_buf'][g0 * row:(g0 + n) * row]
+                            gb, gl, go = d['gt_rle'][:3]
+                            hb[:n * 4].view(torch.int32).copy_(gl, non_blocking=True)
+                            hb[n * 4:n * 8].view(torch.int32).copy_(go, non_blocking=True)
+                            hb[n * 8:].view(n, ops.RLE_BYTE_CAP).copy_(gb, non_blocking=True)
+                            for t in (gb, gl, go):
+                                t.record_stream(cp)
                     d['gt_slice'] = (g0, n)
                     g0 += n
             ev = cp.record_event()
@@ -1316,8 +1376,10 @@ class FGN(torch.nn.Module):
             if n and ovf.any():     # a device cap overflowed: dense paste + host RLE for those masks only
                 thr = self.cfg['test_cfg']['rcnn']['mask_thr_binary']
                 for j in np.flatnonzero(ovf):
-                    dense = ops.mask_paste(di['mask_prob'][j:j + 1].contiguous(),
-                                           di.get('det_bboxes_copy', di['det_bboxes'])[j:j + 1].contiguous(),
+                    # (from the HOST copies: a replayed graph may have overwritten the device tensors by now)
+                    pdev = di['det_bboxes'].device
+                    dense = ops.mask_paste(host['prob'][i, j:j + 1].to(pdev).contiguous(),
+                                           host['det'][i, j:j + 1].to(pdev).contiguous(),
                                            ih, iw, thr, skip_empty=self._skip_empty())
                     rles[j] = rle.encode(dense[0].cpu().numpy())
             one = {'dt_scores': db[:, 4].reshape(-1).copy(),
@@ -1330,8 +1392,10 @@ class FGN(torch.nn.Module):
             gt = qry_isegmaps[i] if qry_isegmaps is not None else None
             if 'gt_slice' in di:                   # ground-truth masks were encoded on the device (detect_device)
                 g0, ng = di['gt_slice']
-                glen, govf = host['gt_len'][g0:g0 + ng].numpy(), host['gt_ovf'][g0:g0 + ng].numpy()
-                gstr = host['gt_rle'][g0:g0 + ng].numpy()
+                row = ops.RLE_BYTE_CAP + 8
+                hb = host['gt_buf'][g0 * row:(g0 + ng) * row]
+                glen, govf = hb[:ng * 4].view(torch.int32).numpy(), hb[ng * 4:ng * 8].view(torch.int32).numpy()
+                gstr = hb[ng * 8:].view(ng, ops.RLE_BYTE_CAP).numpy()
                 one['qry_isegmaps_rle'] = [
                     {'size': [ih, iw], 'counts': gstr[j, :glen[j]].tobytes()} if not govf[j] else
                     rle.encode(np.asarray(gt[j].cpu() if isinstance(gt[j], torch.Tensor) else gt[j]))

@@ -19,6 +19,7 @@ _f = C.c_float
 SIGNATURES = {
     'fgn_abi_version': (_i, []),
     'fgn_profile_next_launch': (_i, [_p, _p]),
+    'fgn_profile_stamp_words': (_i, []),
     'fgn_profile_stamps': (_i, [_p, _i]),
     'fgn_phase_signal': (_i, [_p, _p]),
     'fgn_phase_wait': (_i, [_p, _i, _i, _p]),

@@ -132,9 +132,9 @@ class ConvProfile(list):
 
 # ---- launch records of the dominant kernel that work inside a replayed hipGraph (include/fgn_hip.h: fgn_profile_stamps) ----
 def new_stamp_records(capacity: int, device) -> torch.Tensor:
-    """``capacity`` records of 8 x uint64 (held as int64): {first start, sum, arrived, executions, shortest, longest, -, -}."""
-    t = torch.zeros((capacity, 8), dtype=torch.int64, device=device)
-    t[:, 0] = -1
+    """``capacity`` launch records (fgn_profile_stamp_words() x uint64 each, held as int64): {start, sum, shards arrived,
+    executions, shortest, longest, ...}."""
+    t = torch.zeros((capacity, _lib.load().fgn_profile_stamp_words()), dtype=torch.int64, device=device)
     t[:, 4] = -1
     return t
 
@@ -145,8 +145,8 @@ def arm_stamps(records: Optional[torch.Tensor]) -> int:
     if records is None:
         return int(_lib.load().fgn_profile_stamps(None, 0))
     _chk(records, 'records', torch.int64)
-    if records.dim() != 2 or records.shape[1] != 8:
-        raise _lib.FgnHipError('arm_stamps: records must be [capacity, 8] int64')
+    if records.dim() != 2 or records.shape[1] != _lib.load().fgn_profile_stamp_words():
+        raise _lib.FgnHipError('arm_stamps: records must be [capacity, fgn_profile_stamp_words()] int64')
     return int(_lib.load().fgn_profile_stamps(_ptr(records), records.shape[0]))
 
 
@@ -913,11 +913,12 @@ def rpn_proposals(scores: torch.Tensor, deltas: torch.Tensor, anchors_base: torc
 def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n_ways: int, img_h: int, img_w: int,
              means, stds, score_thr: float, iou_thr: float, max_per_img: int,
              n_rois_dev: Optional[torch.Tensor] = None, debug_scores: bool = False, img_index: Optional[int] = None,
-             batch: int = 1):
+             batch: int = 1, out=None):
     """-> det [max_per_img,5], labels, n_det (+ with ``img_index``: mask RoIs [max_per_img,5] = (img_index, box), the
     mask branch's bbox2roi, fgn_roi_head.py:654).  ``batch`` > 1: the RoIs of ``batch`` images stacked ([batch*R,5],
     ``n_rois_dev`` [batch] when given), one workgroup per image in one launch; outputs stacked the same way
-    ([batch*max_per_img,5], ..., n_det [batch]), image i carrying index ``img_index + i``."""
+    ([batch*max_per_img,5], ..., n_det [batch]), image i carrying index ``img_index + i``.  ``out``: caller-owned
+    (det, labels, n_det) of those shapes, n_det ZERO on entry (the packed result record of the detector)."""
     for t, nm in ((rois, 'rois'), (cls_raw, 'cls_raw'), (reg_raw, 'reg_raw')):
         _chk(t, nm)
     if batch < 1 or rois.shape[0] % batch:
@@ -930,9 +931,15 @@ def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n
         raise _lib.FgnHipError('det_post: n_rois_dev holds fewer counts than batch')
     L = _lib.load()
     scratch = torch.empty(batch * L.fgn_det_post_scratch_bytes(r, n_ways), device=rois.device, dtype=torch.uint8)
-    det = torch.empty((batch * max_per_img, 5), device=rois.device, dtype=torch.float32)
-    lab = torch.empty((batch * max_per_img,), device=rois.device, dtype=torch.int64)
-    n_det = zeros((batch,), rois.device, torch.int32)
+    if out is not None:
+        det, lab, n_det = out
+        _chk(det, 'out det'); _chk(lab, 'out labels', torch.int64); _chk(n_det, 'out n_det', torch.int32)
+        if tuple(det.shape) != (batch * max_per_img, 5) or tuple(lab.shape) != (batch * max_per_img,) or n_det.numel() != batch:
+            raise _lib.FgnHipError('det_post: bad out shapes')
+    else:
+        det = torch.empty((batch * max_per_img, 5), device=rois.device, dtype=torch.float32)
+        lab = torch.empty((batch * max_per_img,), device=rois.device, dtype=torch.int64)
+        n_det = zeros((batch,), rois.device, torch.int32)
     mrois = torch.empty((batch * max_per_img, 5), device=rois.device, dtype=torch.float32) \
         if img_index is not None else None
     # softmax scores [r, n_ways + 1] of the first image followed by 16 words of phase stamps (tools/post_time.py)
@@ -951,7 +958,7 @@ def det_post(rois: torch.Tensor, cls_raw: torch.Tensor, reg_raw: torch.Tensor, n
 
 
 def mask_logits(x: torch.Tensor, w: torch.Tensor, bias, roi_size: int,
-                n_dev: Optional[torch.Tensor] = None):
+                n_dev: Optional[torch.Tensor] = None, prob_out: Optional[torch.Tensor] = None):
     """x [D, P, P, 4*C] (deconv output, sub-position major) -> logits, prob [D, 2P, 2P].  ``bias``: a float, or a
     one-element device tensor the kernel reads itself (no host read of a parameter a training step has just updated)."""
     _chk(x, 'x')
@@ -961,7 +968,13 @@ def mask_logits(x: torch.Tensor, w: torch.Tensor, bias, roi_size: int,
     if x[0].numel() != roi_size * roi_size * 4 * c:
         raise _lib.FgnHipError('mask_logits: x shape inconsistent with weight')
     logits = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
-    prob = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
+    if prob_out is not None:        # caller-owned, ZERO on entry (rows beyond the device count are not written)
+        _chk(prob_out, 'prob_out')
+        if tuple(prob_out.shape) != (d, 2 * roi_size, 2 * roi_size):
+            raise _lib.FgnHipError('mask_logits: bad prob_out shape')
+        prob = prob_out
+    else:
+        prob = zeros((d, 2 * roi_size, 2 * roi_size), x.device)
     bias_dev = None
     if isinstance(bias, torch.Tensor):
         _chk(bias, 'bias')
@@ -993,9 +1006,9 @@ RLE_BYTE_CAP = 16384      # COCO string bytes per detection
 
 
 def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, thr: float,
-             n_dev: Optional[torch.Tensor] = None, skip_empty: bool = True):
+             n_dev: Optional[torch.Tensor] = None, skip_empty: bool = True, out=None):
     """Fused paste + threshold + COCO RLE.  Returns (bytes [D,RLE_BYTE_CAP] u8, lens [D] i32,
-    overflow [D] i32), all on device."""
+    overflow [D] i32), all on device.  ``out``: caller-owned tensors of those shapes, lens / overflow ZERO on entry."""
     _chk(prob, 'prob')
     _chk(boxes, 'boxes')
     d, m, _ = prob.shape
@@ -1003,9 +1016,15 @@ def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, th
         raise _lib.FgnHipError('mask_rle: boxes shape mismatch')
     dev = prob.device
     scratch = torch.empty((d, RLE_TRANS_CAP), device=dev, dtype=torch.int32)
-    out = torch.empty((d, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
-    lens = zeros((d,), dev, torch.int32)
-    ovf = zeros((d,), dev, torch.int32)
+    if out is not None:
+        out, lens, ovf = out
+        _chk(out, 'out bytes', torch.uint8); _chk(lens, 'out lens', torch.int32); _chk(ovf, 'out overflow', torch.int32)
+        if tuple(out.shape) != (d, RLE_BYTE_CAP) or lens.numel() != d or ovf.numel() != d:
+            raise _lib.FgnHipError('mask_rle: bad out shapes')
+    else:
+        out = torch.empty((d, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
+        lens = zeros((d,), dev, torch.int32)
+        ovf = zeros((d,), dev, torch.int32)
     rc = _lib.load().fgn_mask_rle(_ptr(prob), _ptr(boxes), boxes.shape[1], _ptr(scratch), _ptr(out), _ptr(lens),
                                   _ptr(ovf), _ptr(n_dev), d, img_h, img_w, m, float(thr), RLE_TRANS_CAP,
                                   RLE_BYTE_CAP, int(bool(skip_empty)), _stream())
@@ -1013,9 +1032,11 @@ def mask_rle(prob: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, th
     return out, lens, ovf
 
 
-def dense_mask_rle(masks: torch.Tensor):
+def dense_mask_rle(masks: torch.Tensor, packed: bool = False):
     """COCO RLE of dense binary masks [n,H,W] (bool / uint8) on the device: the ground-truth masks of the query
-    (``qry_isegmaps_rle``, fgn.py:298).  Returns (bytes [n,RLE_BYTE_CAP] u8, lens [n] i32, overflow [n] i32)."""
+    (``qry_isegmaps_rle``, fgn.py:298).  Returns (bytes [n,RLE_BYTE_CAP] u8, lens [n] i32, overflow [n] i32).
+    ``packed``: the three are views of ONE allocation laid out [lens | overflow | bytes] (one device-to-host copy
+    moves them all) and that allocation is returned as a fourth value."""
     if masks.dtype == torch.bool:
         masks = masks.view(torch.uint8)
     _chk(masks, 'masks', torch.uint8)
@@ -1023,17 +1044,24 @@ def dense_mask_rle(masks: torch.Tensor):
         raise _lib.FgnHipError('dense_mask_rle: masks must be [n,H,W]')
     n, h, w = masks.shape
     dev = masks.device
-    out = torch.empty((n, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
-    lens = torch.zeros((n,), device=dev, dtype=torch.int32)
-    ovf = torch.zeros((n,), device=dev, dtype=torch.int32)
+    buf = None
+    if packed:
+        buf = torch.empty(n * (RLE_BYTE_CAP + 8), device=dev, dtype=torch.uint8)
+        buf[:n * 8].zero_()
+        lens, ovf = buf[:n * 4].view(torch.int32), buf[n * 4:n * 8].view(torch.int32)
+        out = buf[n * 8:].view(n, RLE_BYTE_CAP)
+    else:
+        out = torch.empty((n, RLE_BYTE_CAP), device=dev, dtype=torch.uint8)
+        lens = torch.zeros((n,), device=dev, dtype=torch.int32)
+        ovf = torch.zeros((n,), device=dev, dtype=torch.int32)
     if n == 0:
-        return out, lens, ovf
+        return (out, lens, ovf, buf) if packed else (out, lens, ovf)
     L = _lib.load()
     nbytes = L.fgn_dense_rle_scratch_bytes(n, h, w, RLE_TRANS_CAP)
     scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     _lib.check(L.fgn_dense_mask_rle(_ptr(masks), _ptr(scratch), nbytes, _ptr(out), _ptr(lens), _ptr(ovf), n, h, w,
                                     RLE_TRANS_CAP, RLE_BYTE_CAP, _stream()), 'fgn_dense_mask_rle')
-    return out, lens, ovf
+    return (out, lens, ovf, buf) if packed else (out, lens, ovf)
 
 
 # --------------------------------------------------------------------------------------

@@ -39,10 +39,12 @@ int fgn_abi_version(void);
 int fgn_profile_next_launch(void* start_event, void* stop_event);
 /* Launch records that work inside a replayed hipGraph (no reference counterpart): while the calling thread is armed,
  * every launch of the dominant kernel (conv_pw_persist_kernel) is handed the next record of `records` (device memory,
- * `capacity` records of 8 x uint64, initialised to {~0, 0, 0, 0, ~0, 0, 0, 0}); each execution of such a launch - every
- * replay of a graph it was captured into - adds its span (first workgroup start -> last workgroup end, 10 ns ticks of
- * the constant 100 MHz clock) to the record: [1] sum, [3] executions, [4] shortest, [5] longest.  NULL disarms.
+ * `capacity` records of fgn_profile_stamp_words() x uint64, all zero except word 4 = ~0); each execution of such a
+ * launch - every replay of a graph it was captured into - adds its span (first workgroup start -> last workgroup end,
+ * 10 ns ticks of the constant 100 MHz clock) to the record: [1] sum, [3] executions, [4] shortest, [5] longest.  A
+ * recorded launch pays one returning atomic per workgroup at its exit (~1 us at the end of the launch).  NULL disarms.
  * Returns the number of records handed out since the previous call (= launches recorded, in launch order). */
+int fgn_profile_stamp_words(void);
 int fgn_profile_stamps(void* records, int capacity);
 /* Phase marks between streams that replay captured graphs (no reference counterpart; the pipelined serving loop of
  * INTEGRATION.md): fgn_phase_signal bumps *counter (device memory, int32) from inside an episode - captured into its

@@ -17,7 +17,12 @@ TOL = 1e-4      # BASELINE.json north_star: "masks/scores within 1e-4 fp32"
 # 1e-2 px, so a pair that drifted past the bound fails as a box difference, not as a "flip".
 BOX_TOL = 4e-3
 CFG5_PROP_FLIPS = 8         # rows of the proposal symmetric difference tolerated at cfg5 (each with its printed reason)
-MASK_IOU_MIN = 0.999     # final binary masks (decoded dt_isegmaps_rle) of matched pairs: single pixels may sit on the 0.5 threshold
+# final binary masks (decoded dt_isegmaps_rle) of matched pairs: IoU >= 0.999, or - a mask of a few hundred pixels loses
+# more than that to ONE pixel whose probability sits on the 0.5 threshold - at most MASK_DIFF_PX differing pixels
+# (tests/test_hip_mask.py checks pixel by pixel that a differing pixel has the oracle's own sample within 1e-5 of the
+# threshold).  Measured r05 over cfg1-cfg5: 98-100 of 100 RLE strings byte-identical per image, worst IoU 0.99899 (1 pixel).
+MASK_IOU_MIN = 0.999
+MASK_DIFF_PX = 3
 
 
 def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0, cfg=None, max_prop_flips=0):
@@ -61,19 +66,22 @@ def _check_tolerance(ref, got, tr_ref, tr, name, max_flips=0, cfg=None, max_prop
                            tr_ref['mask_logits'][start:start + n_ref].numpy(), pi['mask_logits'][:n_got].cpu().numpy())
         start += n_ref
         pairs, _, _ = match_detections(ref[i]['dt_bboxes'], ref[i]['dt_cat_ids'], got[i]['dt_bboxes'], got[i]['dt_cat_ids'])
-        ious = mask_iou_of_pairs(ref[i]['dt_isegmaps_rle'], got[i]['dt_isegmaps_rle'], pairs)
+        ious, ndiff = mask_iou_of_pairs(ref[i]['dt_isegmaps_rle'], got[i]['dt_isegmaps_rle'], pairs)
         m['min_mask_iou'] = float(ious.min()) if len(ious) else 1.0
+        m['max_mask_diff_px'] = int(ndiff.max()) if len(ndiff) else 0
+        m['masks_outside_bound'] = int(((ious < MASK_IOU_MIN) & (ndiff > MASK_DIFF_PX)).sum())
         m['masks_identical'] = int(sum(ref[i]['dt_isegmaps_rle'][a] == got[i]['dt_isegmaps_rle'][b] for a, b in pairs))
         print(f'[parity {name} img {i}] detections ref/hip {m["n_ref"]}/{m["n_got"]}, matched {m["matched"]}, '
               f'selection flips ref/hip {m["flips_ref"]}/{m["flips_got"]}; on matched pairs: max|d score| '
               f'{m["max_dscore"]:.2e}, max|d mask prob| {m["max_dprob"]:.2e}, max|d box| {m["max_dbox"]:.2e} px, '
               f'max|d mask logit| {m["max_dlogit"]:.2e} (|logit| <= {m.get("max_abs_logit", 0):.1f}); final masks: '
-              f'min IoU {m["min_mask_iou"]:.6f}, {m["masks_identical"]}/{m["matched"]} RLE strings byte-identical')
+              f'min IoU {m["min_mask_iou"]:.6f}, at most {m["max_mask_diff_px"]} differing pixels, '
+              f'{m["masks_identical"]}/{m["matched"]} RLE strings byte-identical')
         assert m['matched'] > 0
         assert m['max_dscore'] <= TOL, (name, i, m)
         assert m['max_dprob'] <= TOL, (name, i, m)
         assert m['max_dbox'] <= BOX_TOL, (name, i, m)
-        assert m['min_mask_iou'] >= MASK_IOU_MIN, (name, i, m)
+        assert m['masks_outside_bound'] == 0, (name, i, m)
         assert m['flips_ref'] <= max_flips and m['flips_got'] <= max_flips, (name, i, m)
         out.append(m)
     return out

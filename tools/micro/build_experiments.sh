@@ -5,10 +5,10 @@
 #   tools/micro/gemm_clock          in-kernel clock / workgroup-span stamps of one GEMM shape per kernel variant
 set -euo pipefail
 cd "$(dirname "$0")/../.."
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFGN_EXPERIMENTS -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-function"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFGN_EXPERIMENTS -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-function -Wno-inline-asm"
 hipcc $F -c fgn_amd/csrc/conv_igemm.hip -o /tmp/conv_igemm_exp.o
 objs=/tmp/conv_igemm_exp.o
-for f in abi spatial norm winograd relation rpn_post det_post mask train train_bwd stem_pool; do
+for f in abi spatial norm winograd relation rpn_post det_post mask train train_bwd; do
   [ -f fgn_amd/csrc/$f.o ] || python -m fgn_amd.build
   objs="$objs fgn_amd/csrc/$f.o"
 done
