@@ -72,6 +72,12 @@ struct ConvParams {
     const int32_t* grp_count_dev;
     // launch record (conv_pw_persist_kernel; fgn_profile_stamps): FGN_STAMP_WORDS x uint64 in device memory or nullptr
     unsigned long long* stamp;
+    // second A operand of conv_pw_persist_kernel (fgn_conv1x1_dual_nhwc_f32): the K-tiles from kt1 on are read from x2
+    // (rows of cin2 floats) instead of x (rows of Cin floats) - two 1x1 convolutions on the same pixels summed in one
+    // K loop (a bottleneck's conv3 and the 1x1 / stride 1 shortcut of its stage's first block).  nullptr: one operand.
+    const float* x2;
+    unsigned x2_bytes;
+    int kt1, cin2;
 };
 
 #ifndef CONV_DMA_STAGES
@@ -822,44 +828,52 @@ __global__ __launch_bounds__(256, MIN_WAVES) void conv_igemm_dma_pair_kernel(con
 
 
 // ------------------------------------------------------------------------------------------------
-// Persistent point-wise kernel (the dominant kernel of an episode): 64x64 output tiles of 1x1 / stride 1 convolutions and
-// of the grouped Winograd GEMM, walked by persistent workgroups (tile, tile + grid, ...; 1024 workgroups = 4 per CU,
-// measured best against 512 / 768 / 1280 in round 3) when a launch has more tiles than that.
-//   * FIVE waves per workgroup.  Waves 0..3 are the consumers: ds_read_b128 fragments + MFMA (wave tile 32x32 as 2x2
-//     tiles of v_mfma_f32_16x16x4_f32: lane group g = lane >> 4 reads the 16-byte chunk 4 kk + g of its row, MFMA j
-//     contracts k in {j, 4+j, 8+j, 12+j} of the 16-deep step) and the epilogue; they issue NO LDS-DMA.  Wave 4 is the
-//     PRODUCER (round 5): it issues the 16 `buffer_load ... lds` of every K-tile (8 A-row groups + 8 B-row groups of
-//     8 rows x 128 B), waits for them and joins the one barrier per K-tile.  Round 4's decomposition of this kernel put
-//     the in-loop DMA issue at 4 points of its rate (0.858 -> 0.900 on a shape without a partial round when the loop's
-//     DMA was removed); with the issue moved out of the MFMA waves the pipelined step gained 1.6 % (same box,
-//     interleaved: 193.5 / 193.6 -> 196.6 / 196.7 img/s over 100 steps; profiles/r05_producer_wave.txt).  The round-4
-//     form (every wave issues its own DMA) lives on in tools/micro/conv_pw_experiments.inc for A/B.
-//   * Two LDS stages of 16 KB; the first K-tile of the NEXT output tile is in flight (stage 0) while the epilogue of
-//     the current one drains through stage 1 (the C tile, 64 x 64 floats): 32 KB per workgroup, 20 waves per CU.
-//   * Epilogue: y = acc * scale + shift (+ residual) (ReLU), 16-byte stores of whole output rows.
-//   * Launch record (fgn_profile_stamps; opt-in): an execution's span = first workgroup start -> arrival of the last
-//     workgroup on the 100 MHz clock, folded into the record by that workgroup - works inside a replayed hipGraph, where
-//     no HIP event can be placed around one kernel.  One returning atomic per workgroup at its exit (~1 us on the last
-//     one: the price of a record, which is why bench.py arms them only with --launch-records); nothing when the launch
-//     carries no record.
+// Persistent point-wise kernel (the dominant kernel of an episode): the 64x64 LDS-DMA kernel in MODE 1 (1x1 / stride 1
+// convolutions and the grouped Winograd GEMM) with workgroups that walk several output tiles (tile, tile + grid, ...;
+// 1024 workgroups = 4 per CU, measured best against 512 / 768 / 1280 in round 3), used when a launch has more tiles
+// than that.  In the one-tile-per-workgroup kernel every workgroup of a round runs its prologue (index math, first
+// DMA, its latency) and its epilogue (accumulators -> LDS -> 16 B stores) at the same time as its neighbours, so the
+// matrix pipe idles ~20 % of a launch.  Here the first K-tile of the NEXT output tile is in flight (LDS stage 0) while
+// the epilogue of the current one drains through stage 1, and workgroups drift out of phase after their first tile.
+// LDS: [stage 0: 16 KB][stage 1: 16 KB]; the C tile of the epilogue (64 x 64 floats) lives in stage 1: 32 KB per
+// workgroup.  Wave tile 32x32 as 2x2 tiles of v_mfma_f32_16x16x4_f32: lane group g = lane >> 4 reads the 16-byte
+// chunk 4*kk + g of its row, MFMA j contracts k in {j, 4+j, 8+j, 12+j} of the 16-deep step (same cycles per FLOP as
+// the 32x32x2 form, +3..5 % on the large GEMMs: another power / clock point, MI355X_MICROARCH.md "DVFS give-back" 7).
+//   * Optional second A operand (fgn_conv1x1_dual_nhwc_f32): the K-tiles from p.kt1 on come from p.x2.
+//   * Optional launch record (fgn_profile_stamps): an execution's span = first workgroup start -> arrival of the last
+//     workgroup on the 100 MHz clock, folded into the record by that workgroup - works inside a replayed hipGraph,
+//     where no HIP event can be placed around one kernel.  One returning atomic per workgroup at its exit (the step
+//     pays 0.8 % with every launch recorded, r05: bench.py arms them only with --launch-records).
+//   * A form with a PRODUCER wave (a fifth wave issues every LDS-DMA, the four MFMA waves none) is 1.9 % faster on the
+//     large GEMMs in isolation and 2.7 % SLOWER in the pipelined step (20 instead of 16 waves per CU leave the other
+//     episode's kernels less room): tools/micro/conv_pw_experiments.inc, profiles/r05_producer_wave.txt.
 // Where its rate goes (in-kernel stamps, Stream-K, decomposition by diagnostic builds, r04): DESIGN.md 4.1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParams p, const int total_tiles) {
     constexpr int BM = 64, BN = 64, WN = 32, WM = 32;
+    constexpr int A_LD = 2, B_LD = 2;
     constexpr int STAGE = (BM + BN) * BK;          // floats
-    constexpr int PITCH = BN;
+    constexpr int PITCH = BN;       // unpadded: ds_write_b32 halves and the 16-lane groups of ds_read_b128 hit distinct banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const bool producer = __builtin_amdgcn_readfirstlane(wv) == 4;
-    const int wm = (wv >> 1) & 1, wn = wv & 1;
+    const int wm = wv >> 1, wn = wv & 1;
     const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
     int grp_valid = p.grp_valid;
     if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+
+    const int col4 = t & 7, row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
+    const bool dual = p.x2 != nullptr;                         // (launch-uniform) second A operand from K-tile p.kt1 on
+    const i32x4 x2_rs = make_rsrc(dual ? p.x2 : p.x, dual ? p.x2_bytes : p.x_bytes);
     const int KT = p.K / BK;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
     constexpr unsigned OOB = 0x7ffffff0u;
 
+    // tile -> (m0, n0): XCD-contiguous runs of logical tiles (the grid is a multiple of 8), optional banded raster
     const int nq = total_tiles >> 3, nr = total_tiles & 7;
     auto coords = [&](int tile, int& m0, int& n0) -> bool {
         const int xcd = tile & 7, idx = tile >> 3;
@@ -883,19 +897,56 @@ __global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParam
         if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
         return true;
     };
+    // first tile of this workgroup that has work; the xcd/idx form needs tile < total_tiles
     auto next_active = [&](int tile, int& m0, int& n0) -> int {
         for (; tile < total_tiles; tile += gridDim.x)
             if (coords(tile, m0, n0)) return tile;
         return -1;
     };
 
-    // launch record (FGN_STAMP_WORDS x uint64; see the header of this kernel).  Start: workgroup 0 alone (a 1024-workgroup
-    // grid starts within ~0.5 us).  End: arrivals are counted in eight shards on cache lines of their own (blockIdx & 7:
-    // 128 arrivals per address, spread over the tail of the launch - 1024 arrivals on ONE address queue for ~12 us, which
-    // the first form of this code paid at the start of every launch), the last arriver of a shard reports to the top
-    // counter, the last of those folds the span into the record and re-arms it for the next replay.
+    unsigned a_voff[A_LD], a2_voff[A_LD], b_voff[B_LD];
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+            a2_voff[i] = (dual && m < M) ? (unsigned)((m * p.cin2 + src_c4 * 4) * 4) : OOB;
+        }
+        int b0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
+        if (p.grp_rows) b0 += (m0 / p.grp_rows) * p.grp_w_stride * 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) b_voff[i] = (unsigned)(b0 + i * 32 * p.K * 4);
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sa = lds_base + stage * (STAGE * 4) + wave_row_bytes;
+        const unsigned ko = (unsigned)(kt * BK * 4);
+        // the K-tile's byte offset rides in the instruction's scalar offset: no vector arithmetic per K-tile (round 4:
+        // +1..2.5 % on the large GEMMs against `voff + ko` with its select for out-of-range rows and M0 save / restore)
+        if (dual && kt >= p.kt1) {                             // its own rows, K offset counted from kt1
+            const unsigned ko2 = (unsigned)((kt - p.kt1) * BK * 4);
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) lds_dma16_s(x2_rs, sa + i * 32 * 128, a2_voff[i], ko2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * 32 * 128, a_voff[i], ko);
+        }
+        const unsigned sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, sb + i * 32 * 128, b_voff[i], ko);
+    };
+
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const float* const rd_a = smem + (wm * WM + r16) * BK;
+    const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
+    float* const cbase = smem + STAGE;              // stage 1
+
+    // launch record (FGN_STAMP_WORDS x uint64).  Start: workgroup 0 alone (a 1024-workgroup grid starts within ~0.5 us).
+    // End: arrivals are counted in eight shards on cache lines of their own (blockIdx & 7: 128 arrivals per address,
+    // spread over the tail of the launch - 1024 arrivals on ONE address queue for ~12 us, which the first form of this
+    // code paid at the start of every launch: 4-7 % of the step), the last arriver of a shard reports to the top counter,
+    // the last of those folds the span into the record and re-arms it for the next replay.
     if (p.stamp && t == 0 && blockIdx.x == 0) atomicExch(p.stamp, __builtin_amdgcn_s_memrealtime());
-    auto leave = [&]() {                            // (wave 0's first lane, on every exit path of the consumers)
+    auto leave = [&]() {
         if (!p.stamp || t != 0) return;
         const unsigned shard = blockIdx.x & 7u;
         const unsigned long long in_shard = (gridDim.x - shard + 7u) / 8u;
@@ -913,76 +964,25 @@ __global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParam
     };
     int m0, n0;
     int tile = next_active(blockIdx.x, m0, n0);
-    if (tile < 0) { leave(); return; }              // workgroup-uniform: nobody waits at a barrier
+    if (tile < 0) { leave(); return; }
     CLOCK_STAMP_BEGIN();
+    set_offsets(m0, n0);
+    issue_tile(0, 0);
 
-    if (producer) {
-        // ---- wave 4: the LDS-DMA of every K-tile.  Lane l covers row 8 i + (l >> 3), 16-byte chunk l & 7 of instruction i
-        const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
-        const i32x4 w_rs = make_rsrc(p.w, p.w_bytes);
-        const int r8 = lane >> 3, c8 = lane & 7;
-        unsigned a_voff[8], b_voff[8];
-        auto set_offsets = [&](int tm0, int tn0) {
-            int b0 = tn0 * p.K * 4;
-            if (p.grp_rows) b0 += (tm0 / p.grp_rows) * p.grp_w_stride * 4;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 8 * i + r8;
-                const int src_c4 = c8 ^ ((row >> 1) & 7);
-                const int m = tm0 + row;
-                a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
-                b_voff[i] = (unsigned)(b0 + (row * p.K + src_c4 * 4) * 4);
-            }
-        };
-        auto issue_tile = [&](int kt, int stage) {
-            const unsigned sa = lds_base + stage * (STAGE * 4);
-            const unsigned ko = (unsigned)(kt * BK * 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) lds_dma16_s(x_rs, sa + i * 1024, a_voff[i], ko);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) lds_dma16_s(w_rs, sa + BM * 128 + i * 1024, b_voff[i], ko);
-        };
-        set_offsets(m0, n0);
-        issue_tile(0, 0);
-        while (true) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // (top of the tile)
-            int cur = 0;
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                  // (the loop's barrier)
-                cur ^= 1;
-            }
-            int nm0 = 0, nn0 = 0;
-            const int next = next_active(tile + gridDim.x, nm0, nn0);
-            if (next >= 0) {
-                set_offsets(nm0, nn0);
-                issue_tile(0, 0);                              // stage 0 is free; the epilogue drains through stage 1
-            }
-            __builtin_amdgcn_s_barrier();                      // (the epilogue's barrier)
-            if (next < 0) break;
-            tile = next;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // ---- waves 0..3: fragments + MFMA + epilogue (conv_pw_persist_kernel without its DMA)
-    const int r16 = lane & 15, g16 = lane >> 4;
-    const float* const rd_a = smem + (wm * WM + r16) * BK;
-    const float* const rd_b = smem + BM * BK + (wn * WN + r16) * BK;
-    float* const cbase = smem + STAGE;
     while (true) {
         f32x4 acc4[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // K-tile 0 of this output tile has landed (own DMAs counted, the barrier covers the other waves'); the same
+        // barrier orders the previous epilogue's reads of the C tile before this tile's DMA into stage 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
             const float* As = rd_a + cur * STAGE;
             const float* Bs = rd_b + cur * STAGE;
 #pragma unroll
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParam
                 float4 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int row = r16 + 16 * i;
+                    const int row = r16 + 16 * i;                       // row within the wave's 32
                     const int pc = ((kk * 4 + g16) ^ ((row >> 1) & 7)) * 4;
                     af[i] = *reinterpret_cast<const float4*>(As + 16 * i * BK + pc);
                     bf[i] = *reinterpret_cast<const float4*>(Bs + 16 * i * BK + pc);
@@ -1005,13 +1005,21 @@ __global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParam
                         acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc4[i][j], 0, 0, 0);
                     }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // see conv_igemm_dma_kernel: reads of stage `cur` must have returned before the barrier is signalled
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
+        // both stages are free now.  Next output tile: its first K-tile goes to stage 0 while the epilogue below
+        // drains this tile through stage 1.
         const int em0 = m0, en0 = n0;
         int nm0 = 0, nn0 = 0;
         const int next = next_active(tile + gridDim.x, nm0, nn0);
+        if (next >= 0) {
+            set_offsets(nm0, nn0);
+            issue_tile(0, 0);
+        }
+        // 16x16 C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1020,9 +1028,9 @@ __global__ __launch_bounds__(320, 5) void conv_pw_persist_kernel(const ConvParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cw[r * PITCH] = acc4[i][j][r];
             }
-        __syncthreads();                                       // (one s_barrier: the producer's third barrier of the tile)
+        __syncthreads();
         {
-            constexpr int C4 = BN / 4, RPP = 256 / C4;
+            constexpr int C4 = BN / 4, RPP = 256 / C4;       // 16 float4 per row, 16 rows per pass
             const int c4 = t % C4, rr = t / C4;
             const int n = en0 + c4 * 4;
             if (n < p.Cout) {
@@ -1179,9 +1187,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
         }
 #endif
         else if (pw && BM == 64 && BN == 64 && p.splits == 1 && (p.Cout & 3) == 0 && (int)grid.x > persist_blocks()) {
-            // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel).
-            // (Launches with FEWER tiles stay on the one-tile-per-workgroup kernel: routed here too - one tile per
-            // five-wave workgroup - the pipelined step lost 2 %, r05: 190.4 -> 186.7 img/s, same box, interleaved.)
+            // more output tiles than resident workgroups: persistent workgroups walk them (conv_pw_persist_kernel)
             static unsigned long long pk_ok = 0ull;
             attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
             if (attr != hipSuccess) return (int)attr;
@@ -1190,7 +1196,7 @@ static int launch_cfg(const ConvParams& p0, int M_max, bool cin4, hipStream_t st
             { int rc = FGN_OK; if (fgn_exp_launch_persist_ws(p, (int)grid.x, stream, &rc)) return rc; }
 #endif
             p.stamp = fgn_next_stamp_record();
-            FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(320), plds, stream, p, (int)grid.x);
+            FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(persist_blocks()), dim3(256), plds, stream, p, (int)grid.x);
         } else if (pw)
             FGN_LAUNCH_TIMED((conv_igemm_dma_kernel<BM, BN, WM, WN, NST, MW, 1>), grid, dim3(256), dlds, stream, p);
         else
@@ -1284,7 +1290,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (a_img_div < 1 || stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.stamp = nullptr;
+    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
 #ifdef FGN_EXPERIMENTS
     p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif
@@ -1366,7 +1372,7 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
     for (int i = 0; i < 2; ++i) {
         ConvParams& p = ps[i];
         p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
-        p.in_scale = nullptr; p.n_img_dev = nullptr; p.stamp = nullptr;
+        p.in_scale = nullptr; p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
 #ifdef FGN_EXPERIMENTS
         p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif
@@ -1406,6 +1412,46 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
     return FGN_OK;
 }
 
+// y = (x * W1^T + x2 * W2^T) + shift (ReLU) on the same rows: two 1x1 / stride 1 convolutions summed in ONE K loop of
+// conv_pw_persist_kernel - a bottleneck's conv3 (+BN) and the 1x1 / stride 1 shortcut (+BN) of the first block of a stage
+// whose stride is 1 (mmdet ResNet layer1.0: out = relu(bn3(conv3(y)) + bn_d(conv_d(x)))), with the two BatchNorm scales
+// folded into the packed weights [cout_pad][Cin1 + Cin2] and the two shifts added.  Saves the shortcut's launch and the
+// write + re-read of its [rows, Cout] output (106 MB at cfg3).  x [rows, Cin1], x2 [rows, Cin2], y [rows, Cout].
+extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const float* w_packed, float* y, const float* shift,
+                                         int rows, int Cin1, int Cin2, int Cout, int cout_pad, int relu, hipStream_t stream) {
+    if (!x || !x2 || !w_packed || !y) return FGN_ERR_ARG;
+    if (rows <= 0) return FGN_OK;
+    if (Cin1 % BK || Cin2 % BK || Cin1 <= 0 || Cin2 <= 0 || (Cout & 3) || cout_pad % 128 || cout_pad < Cout) return FGN_ERR_SHAPE;
+    const long long K = (long long)Cin1 + Cin2;
+    const long long xb = (long long)rows * Cin1 * 4, x2b = (long long)rows * Cin2 * 4, wb = (long long)cout_pad * K * 4;
+    if (xb >= 0x7fffff00ll || x2b >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    p.x = x; p.w = w_packed; p.y = y; p.scale = nullptr; p.shift = shift; p.residual = nullptr; p.in_scale = nullptr;
+    p.n_img_dev = nullptr; p.stamp = nullptr;
+#ifdef FGN_EXPERIMENTS
+    p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
+    p.x2 = x2; p.x2_bytes = (unsigned)x2b; p.kt1 = Cin1 / BK; p.cin2 = Cin2;
+    p.n_img = rows; p.H = 1; p.W = 1; p.Cin = Cin1; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
+    p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = relu; p.K = (int)K;
+    p.ws = nullptr; p.splits = 1; p.kt_per_split = (int)K / BK;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0; p.grp_count_dev = nullptr;
+    p.n_tiles_n = cdiv(Cout, 64);
+    const int m_tiles = cdiv(rows, 64);
+    set_band(p, 64, 64, m_tiles);
+    const int tiles = m_tiles * p.n_tiles_n;
+    static unsigned long long pk_ok = 0ull;
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_persist_kernel), &pk_ok);
+    if (attr != hipSuccess) return (int)attr;
+    const size_t plds = (size_t)2 * (64 + 64) * BK * sizeof(float);
+    const int grid = std::min(persist_blocks(), (tiles + 7) / 8 * 8);
+    p.stamp = fgn_next_stamp_record();
+    FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(grid), dim3(256), plds, stream, p, tiles);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The 16 / 36 GEMMs of a Winograd F(2x2,3x3) / F(4x4,3x3) convolution (winograd.hip holds the transforms):
 //   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = position in the 4x4 / 6x6 transformed tile
@@ -1429,7 +1475,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
-    p.n_img_dev = nullptr; p.stamp = nullptr;
+    p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
 #ifdef FGN_EXPERIMENTS
     p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif

@@ -396,40 +396,73 @@ __global__ __launch_bounds__(RLE_THREADS) void dense_rle_kernel(const uint8_t* _
     const uint8_t* m = cols + (size_t)d * W * Hp;
     const int cpc = Hp / 16;                                   // chunks per column
     const int n_chunks = W * cpc;
-    const int per = (n_chunks + RLE_THREADS - 1) / RLE_THREADS;
-    const int c_lo = min(t * per, n_chunks), c_hi = min(c_lo + per, n_chunks);
-    // change bits of chunk c: bit r set iff pixel (x, 16*k + r) differs from its predecessor in scan order
-    auto chunk_bits = [&](int c, int& prev) -> unsigned {
-        const uint4 v = *reinterpret_cast<const uint4*>(m + (size_t)c * 16);
+    // Chunk -> thread: every WAVE owns a contiguous range of chunks and walks it 64 chunks at a time, lane l reading
+    // chunk base + l - one contiguous kilobyte per wave-load.  (Round 4 gave every THREAD a contiguous range: the 64
+    // lanes of a load then touched 64 different cache lines a kilobyte apart, 130 000 line requests per mask from the
+    // one CU a mask runs on - the kernel's 85 us were that, not its arithmetic.)
+    const int lane = t & 63, wv = t >> 6;
+    constexpr int NW = RLE_THREADS / 64;
+    const int per_wave = ((n_chunks + NW - 1) / NW + 63) / 64 * 64;
+    const int w_lo = min(wv * per_wave, n_chunks), w_hi = min(w_lo + per_wave, n_chunks);
+    // The walk is latency-bound, not bandwidth-bound (one workgroup per mask: 16 waves on one CU): a wave that waits for
+    // every load before it issues the next pays ~0.7 us x 65 steps x 2 passes - what the kernel's ~100 us were.  U loads
+    // are therefore issued ahead of the U steps that consume them.
+    constexpr int U = 8;
+    auto load_chunk = [&](int c) -> uint4 {
+        return c < w_hi ? *reinterpret_cast<const uint4*>(m + (size_t)c * 16) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    // change bits of chunk c (its 16 bytes in v): bit r set iff pixel (x, 16*k + r) differs from its predecessor in scan
+    // order (the last pixel of the previous chunk: the neighbouring lane's, or for lane 0 one byte load)
+    auto chunk_bits = [&](int c, const uint4& v) -> unsigned {
+        const bool in = c < w_hi;
         // the 16 bytes are 0 / 1 (mask_to_columns_kernel normalises them): a multiply gathers the four low bits of a
         // word into one nibble (b0 | b1 << 1 | b2 << 2 | b3 << 3 lands in bits 24..27, the partial products never
         // carry), and "differs from its predecessor" is one XOR against the value shifted by a pixel
         const unsigned px = ((v.x * 0x01020408u) >> 24 & 0xfu) | ((v.y * 0x01020408u) >> 20 & 0xf0u) |
                             ((v.z * 0x01020408u) >> 16 & 0xf00u) | ((v.w * 0x01020408u) >> 12 & 0xf000u);
-        const unsigned bits = (px ^ ((px << 1) | (unsigned)prev)) & 0xffffu;
-        prev = (int)(px >> 15);
+        unsigned prev = __shfl_up(px >> 15, 1, 64);
+        if (lane == 0) prev = (in && c > 0) ? (unsigned)(m[(size_t)c * 16 - 1] & 1) : 0u;
+        if (!in) return 0u;
+        const unsigned bits = (px ^ ((px << 1) | prev)) & 0xffffu;
         const int k = c % cpc;
         const int valid = min(16, H - 16 * k);                  // pad rows never differ, but mask them anyway
         return valid >= 16 ? bits : (bits & ((1u << valid) - 1u));
     };
-    int prev0 = 0;
-    if (c_lo > 0 && c_lo < n_chunks) prev0 = m[(size_t)c_lo * 16 - 1] & 1;
     int cnt = 0;
-    {
-        int prev = prev0;
-        for (int c = c_lo; c < c_hi; ++c) cnt += __popc(chunk_bits(c, prev));
+    for (int c0 = w_lo; c0 < w_hi; c0 += 64 * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + 64 * u < w_hi) cnt += __popc(chunk_bits(c0 + 64 * u + lane, v[u]));
     }
     int T;
-    int o = block_exclusive_scan(cnt, wave_sums, &T);
+    const int o_thread = block_exclusive_scan(cnt, wave_sums, &T);
     if (T > trans_cap) {
         if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
         return;
     }
     uint32_t* tr = trans + (size_t)d * trans_cap;
-    {
-        int prev = prev0;
-        for (int c = c_lo; c < c_hi; ++c) {
-            unsigned bits = chunk_bits(c, prev);
+    int run = __shfl(o_thread, 0, 64);           // transitions in front of this wave's range
+    for (int c0 = w_lo; c0 < w_hi; c0 += 64 * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + 64 * u >= w_hi) break;      // (wave-uniform)
+            const int c = c0 + 64 * u + lane;
+            unsigned bits = chunk_bits(c, v[u]);
+            const int n = __popc(bits);
+            int incl = n;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            int o = run + incl - n;
+            run += __shfl(incl, 63, 64);
             const int x = c / cpc, k = c - x * cpc;
             while (bits) {
                 const int r = __ffs(bits) - 1;

@@ -134,16 +134,25 @@ class _Bottleneck:
             if winograd and stride == 1 and w2.shape[1] % 32 == 0 and w2.shape[0] % 4 == 0 else None
         self.conv3 = ops.pack_conv(sd[prefix + '.conv3.weight'], bn=bn('bn3'), relu=True, eps=eps)
         self.down = None
+        self.conv3_dual = None
         if (prefix + '.downsample.0.weight') in sd:
             dbn = {k: sd[f'{prefix}.downsample.1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
-            self.down = ops.pack_conv(sd[prefix + '.downsample.0.weight'], bn=dbn, stride=stride, eps=eps)
+            wd = sd[prefix + '.downsample.0.weight']
+            self.down = ops.pack_conv(wd, bn=dbn, stride=stride, eps=eps)
+            # first block of a stride-1 stage (layer1.0): conv3 + bn3 and the shortcut conv + bn read the same pixels -
+            # one dual-operand K loop, no launch and no [rows, Cout] round trip for the shortcut (ops.conv1x1_dual)
+            w3 = sd[prefix + '.conv3.weight']
+            if ops.FUSED_SHORTCUT and stride == 1 and tuple(wd.shape[2:]) == (1, 1) and w3.shape[1] % 32 == 0 and \
+                    wd.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0:
+                self.conv3_dual = ops.pack_conv_dual(w3, bn('bn3'), wd, dbn, relu=True, eps=eps)
 
     def layers(self):
-        return [l for l in (self.conv1, self.conv2, self.conv3, self.down, self.conv2_wg) if l is not None]
+        return [l for l in (self.conv1, self.conv2, self.conv3, self.down, self.conv2_wg, self.conv3_dual) if l is not None]
 
     def __call__(self, x, n_img_dev=None, y1=None):
         """``y1``: the output of conv1 (+BN+ReLU) when the caller already has it (shared_head entry)."""
-        idt = x if self.down is None else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
+        fused = self.conv3_dual is not None and n_img_dev is None
+        idt = x if (self.down is None or fused) else ops.conv2d(x, self.down, n_img_dev=n_img_dev)
         y = y1 if y1 is not None else ops.conv2d(x, self.conv1, n_img_dev=n_img_dev)
         if self.conv2_wg is not None and \
                 ops.winograd_pays(y.shape[0], y.shape[1], y.shape[2], self.conv2_wg.cin, self.conv2_wg.cout,
@@ -151,6 +160,8 @@ class _Bottleneck:
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
+        if fused:
+            return ops.conv1x1_dual(y, x, self.conv3_dual)                     # relu(bn3(conv3(y)) + bn_d(conv_d(x)))
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
 
 
@@ -194,7 +205,8 @@ def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
     stride-1 downsample and the Winograd GEMM; two-tensor launches for the strided convolutions and the transforms."""
     stride = blk.conv2.stride
     out_hw = lambda t: ((t.shape[1] - 1) // stride + 1, (t.shape[2] - 1) // stride + 1)
-    if blk.down is None:
+    fused = blk.conv3_dual is not None
+    if blk.down is None or fused:
         idt = x
     else:
         idt = x.like(blk.down.cout, out_hw(x.q), out_hw(x.s))
@@ -211,7 +223,10 @@ def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
     else:
         _conv_pair(y1.q, y1.s, blk.conv2, y2.q, y2.s)
     out = y2.like(blk.conv3.cout)
-    ops.conv2d(y2.flat, blk.conv3, residual=idt.flat, out=out.flat)
+    if fused:       # (stride 1: y2 and x hold the same rows)
+        ops.conv1x1_dual(y2.flat, x.flat, blk.conv3_dual, out=out.flat)
+    else:
+        ops.conv2d(y2.flat, blk.conv3, residual=idt.flat, out=out.flat)
     return out
 
 
@@ -605,7 +620,7 @@ class FGN(torch.nn.Module):
         def mv(o):
             if isinstance(o, torch.Tensor):
                 return o.float().contiguous().to(device)
-            if isinstance(o, (ops.ConvLayer, ops.WinogradLayer)):
+            if isinstance(o, (ops.ConvLayer, ops.WinogradLayer, ops.DualConvLayer)):
                 return o.to(device)
             if isinstance(o, (_Bottleneck, _BasicBlock)):
                 for l in o.layers():

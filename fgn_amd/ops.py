@@ -29,6 +29,8 @@ PROFILE = None
 
 # stem 7x7/2 + BN + ReLU + 3x3/2 max-pool as ONE kernel (csrc/stem_pool.hip; detector.FGN.use_stem_pool_fusion).  A/B knob.
 STEM_POOL_FUSION = os.environ.get('FGN_STEM_POOL', '0') != '0'
+# conv3 + shortcut conv of the first block of a stride-1 stage as one dual-operand K loop (conv1x1_dual).  A/B knob.
+FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 
 _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
 
@@ -317,6 +319,71 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     return out
 
 
+@dataclass
+class DualConvLayer:
+    """Two 1x1 / stride 1 convolutions with their eval-mode BatchNorms, packed for ONE K loop (``conv1x1_dual``):
+    w [cout_pad, cin1 + cin2] with the two BN scales folded into its rows (fp64 fold, one rounding), shift = sum of the
+    two BN shifts."""
+    w: torch.Tensor
+    shift: torch.Tensor
+    cin1: int
+    cin2: int
+    cout: int
+    cout_pad: int
+    relu: bool
+
+    def to(self, device):
+        self.w, self.shift = self.w.to(device), self.shift.to(device)
+        return self
+
+
+def pack_conv_dual(w1: torch.Tensor, bn1: dict, w2: torch.Tensor, bn2: dict, relu: bool = True, eps: float = 1e-5) -> DualConvLayer:
+    """w1 [Cout,Cin1,1,1] + bn1 (a bottleneck's conv3 / bn3), w2 [Cout,Cin2,1,1] + bn2 (its shortcut conv / bn)."""
+    cout, cin1 = w1.shape[:2]
+    cin2 = w2.shape[1]
+    if tuple(w1.shape[2:]) != (1, 1) or tuple(w2.shape[2:]) != (1, 1) or w2.shape[0] != cout or cin1 % 32 or cin2 % 32 or cout % 4:
+        raise _lib.FgnHipError('pack_conv_dual: two 1x1 kernels with one Cout, Cin1 / Cin2 multiples of 32, Cout % 4 == 0')
+    rows, shift = [], 0.0
+    for w, bn in ((w1, bn1), (w2, bn2)):
+        sc = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + eps)
+        shift = shift + (bn['bias'].double() - bn['running_mean'].double() * sc)
+        rows.append(w.detach().double().reshape(cout, -1) * sc[:, None])
+    cout_pad = (cout + 127) // 128 * 128
+    wp = torch.zeros(cout_pad, cin1 + cin2, dtype=torch.float32)
+    wp[:cout] = torch.cat(rows, 1).float()
+    return DualConvLayer(wp.contiguous(), shift.float().contiguous(), cin1, cin2, cout, cout_pad, relu)
+
+
+def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x1 [..., Cin1], x2 [..., Cin2] over the same leading dims (rows) -> relu?(x1 W1^T + x2 W2^T + shift) [..., Cout]."""
+    _chk(x1, 'x1')
+    _chk(x2, 'x2')
+    if x1.shape[-1] != layer.cin1 or x2.shape[-1] != layer.cin2 or x1.shape[:-1] != x2.shape[:-1]:
+        raise _lib.FgnHipError('conv1x1_dual: operand shapes inconsistent with the layer')
+    rows = x1.numel() // layer.cin1
+    shape = tuple(x1.shape[:-1]) + (layer.cout,)
+    if out is None:
+        out = torch.empty(shape, device=x1.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        if tuple(out.shape) != shape:
+            raise _lib.FgnHipError('conv1x1_dual: bad out shape')
+    prof = PROFILE
+    L = _lib.load()
+    if prof is not None:
+        e0, e1 = prof.arm()
+    rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(layer.w), _ptr(out), _ptr(layer.shift), rows, layer.cin1,
+                                     layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
+    _lib.check(rc, 'fgn_conv1x1_dual_nhwc_f32')
+    if prof is not None:
+        k = layer.cin1 + layer.cin2
+        flop = 2.0 * rows * layer.cout * k
+        prof.append(dict(kind='conv', kernel='conv_pw_persist_kernel', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+                         n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k), residual=False,
+                         shape=(1, rows, 1, k, layer.cout, 1, 1)))
+    return out
+
+
 def conv2d_pair(x0: torch.Tensor, x1: torch.Tensor, layer: ConvLayer, out0: Optional[torch.Tensor] = None,
                 out1: Optional[torch.Tensor] = None):
     """The same convolution (weights, folded BN, ReLU) on two NHWC tensors of different geometry in ONE launch - the
@@ -391,6 +458,7 @@ _WG_G = {
                      [1 / 15, -2 / 15, 4 / 15], [0.0, 0.0, 1.0]], dtype=torch.float64),
 }
 WINOGRAD_M = 4       # default output tile edge
+_WG_MIN_CIN = int(os.environ.get('FGN_WG_MIN_CIN', '64'))     # A/B knob of round 5 (layer1 direct vs F(4x4)): see winograd_pays
 
 
 def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -476,7 +544,7 @@ def winograd_pays(n_img: int, H: int, W: int, cin: int, cout: int, m: Optional[i
     9-RoI support head (441 pixels) loses to the launch costs of the three kernels.  F(4x4) pays from 64 input
     channels, F(2x2) from 128; both need about a thousand output pixels."""
     m = WINOGRAD_M if m is None else m
-    return cin >= (64 if m == 4 else 128) and n_img * H * W >= 1024 and winograd_fits(n_img, H, W, cin, cout, m)
+    return cin >= (_WG_MIN_CIN if m == 4 else 128) and n_img * H * W >= 1024 and winograd_fits(n_img, H, W, cin, cout, m)
 
 
 def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[torch.Tensor] = None,

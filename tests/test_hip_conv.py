@@ -234,3 +234,34 @@ def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
     oq, os_ = buf[:yq.numel()].view(yq.shape), buf[yq.numel():].view(ys.shape)
     ops.conv2d_pair(xq, xs, layer, oq, os_)
     assert torch.equal(oq, yq) and torch.equal(os_, ys)
+
+
+@pytest.mark.parametrize('rows,cin1,cin2,cout', [(103664, 64, 64, 256), (5000, 32, 96, 132), (777, 128, 32, 64)])
+def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, cout):
+    """``conv1x1_dual`` (fgn_conv1x1_dual_nhwc_f32): relu(bn3(conv3(y)) + bn_d(conv_d(x))) of the first Bottleneck of a
+    stride-1 stage as ONE K loop over [y | x] with the BatchNorm scales folded into the weights - against fp64, and
+    against the two-launch form it replaces (shortcut conv, then conv3 with the residual in its epilogue), at the cfg3
+    layer1.0 shape and at ragged ones (fewer tiles than persistent workgroups, Cout not a multiple of 64)."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    y, x = torch.randn(rows, cin1, generator=g), torch.randn(rows, cin2, generator=g)
+    w3, wd = torch.randn(cout, cin1, 1, 1, generator=g) / cin1 ** 0.5, torch.randn(cout, cin2, 1, 1, generator=g) / cin2 ** 0.5
+    mk = lambda: dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+                      running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    bn3, bnd = mk(), mk()
+
+    def affine(v, bn):
+        sc = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + 1e-5)
+        return v * sc + (bn['bias'].double() - bn['running_mean'].double() * sc)
+    ref = torch.relu(affine(y.double() @ w3.reshape(cout, cin1).double().T, bn3) +
+                     affine(x.double() @ wd.reshape(cout, cin2).double().T, bnd))
+    layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
+    yc, xc = y.cuda().view(1, rows, 1, cin1), x.cuda().view(1, rows, 1, cin2)
+    got = ops.conv1x1_dual(yc, xc, layer)
+    assert tuple(got.shape) == (1, rows, 1, cout)
+    assert (got.view(rows, cout).cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'),
+                     residual=ops.conv2d(xc, ops.pack_conv(wd, bn=bnd).to('cuda')))
+    assert (got - two).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    again = ops.conv1x1_dual(yc, xc, layer)
+    assert torch.equal(got, again)

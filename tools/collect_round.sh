@@ -34,5 +34,5 @@ FGN_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 5 --steps 10 --w
 echo "5 ranks: $(cut -c1-160 "$OUT/${R}_rehearsal_5rank_gloo.json")"
 # 5. per-launch roofline table of one episode, in-kernel clock of the large GEMMs under sustained load
 timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch.csv" 7 > "$OUT/per_launch.txt" 2>&1; tail -14 "$OUT/per_launch.txt"
-timeout -k 10 200 tools/micro/gemm_clock 2.5 0,2002 > "$OUT/${R}_gemm_clock.jsonl" 2> "$OUT/gemm_clock.err"; cut -c1-260 "$OUT/${R}_gemm_clock.jsonl"
+timeout -k 10 200 tools/micro/gemm_clock 2.5 0,2001 > "$OUT/${R}_gemm_clock.jsonl" 2> "$OUT/gemm_clock.err"; cut -c1-260 "$OUT/${R}_gemm_clock.jsonl"
 ls "$OUT"

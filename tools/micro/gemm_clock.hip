@@ -53,11 +53,11 @@ static int run(const Shape& sh, int variant, double seconds) {
     if (!A || !W) return 1;
     // 1001..1003: conv_pw_streamk_kernel mode 1..3; 1013: mode 3 with the pieces dropped (timing only, wrong results)
 #ifdef FGN_EXPERIMENTS     // the kernel variants of tools/micro/conv_pw_experiments.inc (build with -DFGN_EXPERIMENTS)
-    // 1..48: conv_pw_persist2_kernel tile codes; 1001..1013: Stream-K modes; 2002: the round-4 persistent kernel (no producer wave)
+    // 1..48: conv_pw_persist2_kernel tile codes; 1001..1013: Stream-K modes; 2001: the producer-wave form of the persistent kernel
     fgn_conv2d_tune(0, variant >= 1000 ? 0 : variant);
     fgn_conv2d_tune(2, variant >= 1000 && variant < 2000 ? (variant - 1000) % 10 : 0);
     fgn_conv2d_tune(5, variant >= 1000 && variant < 2000 ? (variant - 1000) / 10 : 0);
-    fgn_conv2d_tune(6, variant == 2002 ? 2 : 0);
+    fgn_conv2d_tune(6, variant == 2001 ? 1 : 0);
 #else
     if (variant != 0) { fprintf(stderr, "variant %d needs a -DFGN_EXPERIMENTS build\n", variant); return 1; }
 #endif
