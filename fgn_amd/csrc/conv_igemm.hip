@@ -78,6 +78,7 @@ struct ConvParams {
     const float* x2;
     unsigned x2_bytes;
     int kt1, cin2;
+    const int32_t* x2_rows;      // optional: row m of the output reads row x2_rows[m] of x2 (a strided shortcut); nullptr: row m
 };
 
 #ifndef CONV_DMA_STAGES
@@ -910,7 +911,8 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
         for (int i = 0; i < A_LD; ++i) {
             const int m = m0 + row0 + 32 * i;
             a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
-            a2_voff[i] = (dual && m < M) ? (unsigned)((m * p.cin2 + src_c4 * 4) * 4) : OOB;
+            a2_voff[i] = OOB;
+            if (dual && m < M) a2_voff[i] = (unsigned)(((p.x2_rows ? p.x2_rows[m] : m) * p.cin2 + src_c4 * 4) * 4);
         }
         int b0 = ((n0 + row0) * p.K + src_c4 * 4) * 4;
         if (p.grp_rows) b0 += (m0 / p.grp_rows) * p.grp_w_stride * 4;
@@ -1290,7 +1292,7 @@ extern "C" int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float*
     if (a_img_div < 1 || stride < 1 || cout_pad % 128 != 0 || cout_pad < Cout) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
+    p.in_scale = in_scale; p.n_img_dev = n_img_dev; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0; p.x2_rows = nullptr;
 #ifdef FGN_EXPERIMENTS
     p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif
@@ -1372,7 +1374,7 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
     for (int i = 0; i < 2; ++i) {
         ConvParams& p = ps[i];
         p.x = xs[i]; p.w = w_packed; p.y = ys[i]; p.scale = scale; p.shift = shift; p.residual = nullptr;
-        p.in_scale = nullptr; p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
+        p.in_scale = nullptr; p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0; p.x2_rows = nullptr;
 #ifdef FGN_EXPERIMENTS
         p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif
@@ -1416,14 +1418,18 @@ extern "C" int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, 
 // conv_pw_persist_kernel - a bottleneck's conv3 (+BN) and the 1x1 / stride 1 shortcut (+BN) of the first block of a stage
 // whose stride is 1 (mmdet ResNet layer1.0: out = relu(bn3(conv3(y)) + bn_d(conv_d(x)))), with the two BatchNorm scales
 // folded into the packed weights [cout_pad][Cin1 + Cin2] and the two shifts added.  Saves the shortcut's launch and the
-// write + re-read of its [rows, Cout] output (106 MB at cfg3).  x [rows, Cin1], x2 [rows, Cin2], y [rows, Cout].
-extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const float* w_packed, float* y, const float* shift,
-                                         int rows, int Cin1, int Cin2, int Cout, int cout_pad, int relu, hipStream_t stream) {
+// write + re-read of its [rows, Cout] output (106 MB at cfg3).  x [rows, Cin1], y [rows, Cout]; x2 [x2_total_rows, Cin2]:
+// output row m reads row x2_rows[m] of it (int32 on the device: the 1x1 / STRIDE 2 shortcut of layer2.0 / layer3.0 reads
+// every second pixel of every second row of the stage's input), or row m when x2_rows is NULL (then x2_total_rows = rows).
+extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                                         const float* w_packed, float* y, const float* shift, int rows, int Cin1, int Cin2,
+                                         int Cout, int cout_pad, int relu, hipStream_t stream) {
     if (!x || !x2 || !w_packed || !y) return FGN_ERR_ARG;
     if (rows <= 0) return FGN_OK;
     if (Cin1 % BK || Cin2 % BK || Cin1 <= 0 || Cin2 <= 0 || (Cout & 3) || cout_pad % 128 || cout_pad < Cout) return FGN_ERR_SHAPE;
+    if ((!x2_rows && x2_total_rows != rows) || x2_total_rows < 1) return FGN_ERR_ARG;
     const long long K = (long long)Cin1 + Cin2;
-    const long long xb = (long long)rows * Cin1 * 4, x2b = (long long)rows * Cin2 * 4, wb = (long long)cout_pad * K * 4;
+    const long long xb = (long long)rows * Cin1 * 4, x2b = (long long)x2_total_rows * Cin2 * 4, wb = (long long)cout_pad * K * 4;
     if (xb >= 0x7fffff00ll || x2b >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = x; p.w = w_packed; p.y = y; p.scale = nullptr; p.shift = shift; p.residual = nullptr; p.in_scale = nullptr;
@@ -1431,7 +1437,7 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
 #ifdef FGN_EXPERIMENTS
     p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif
-    p.x2 = x2; p.x2_bytes = (unsigned)x2b; p.kt1 = Cin1 / BK; p.cin2 = Cin2;
+    p.x2 = x2; p.x2_bytes = (unsigned)x2b; p.kt1 = Cin1 / BK; p.cin2 = Cin2; p.x2_rows = x2_rows;
     p.n_img = rows; p.H = 1; p.W = 1; p.Cin = Cin1; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
     p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = relu; p.K = (int)K;
     p.ws = nullptr; p.splits = 1; p.kt_per_split = (int)K / BK;
@@ -1475,7 +1481,7 @@ extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, 
     if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
     ConvParams p;
     p.x = V; p.w = U; p.y = Mo; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr;
-    p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0;
+    p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0; p.x2_rows = nullptr;
 #ifdef FGN_EXPERIMENTS
     p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
 #endif

@@ -360,12 +360,12 @@ extern "C" int fgn_mask_rle(const float* prob, const float* boxes, int box_strid
 // COCO RLE of DENSE binary masks: the ground-truth masks of the query image, which the reference moves to the
 // GPU with the rest of the batch (fgn.py:92-99) and run-length encodes on the host at the end of simple_test
 // (fgn.py:298, `qry_isegmaps_rle`).  Here they stay on the device: 4 host milliseconds of numpy per episode become
-// two small kernels beside the network, and only the strings cross PCIe.
+// four small kernels beside the network, and only the strings cross PCIe.
 //   1. mask_to_columns_kernel: [n][H][W] bytes -> column-major [n][W][Hp] (Hp = H rounded up to 16, the pad rows
 //      repeat the column's last pixel), i.e. pycocotools' Fortran scan order as contiguous 16-byte chunks;
-//   2. dense_rle_kernel, one workgroup per mask: every thread owns a contiguous range of 16-row chunks, counts
-//      value changes against the preceding pixel (the pad makes "previous pixel of row 0" the last row of the
-//      previous column), block scan, writes the positions x*H + y in order, then the shared string emitter.
+//   2. dense_rle_walk_kernel (count, then emit; 32 workgroups per mask): value changes against the preceding pixel (the
+//      pad makes "previous pixel of row 0" the last row of the previous column), positions x*H + y written in order;
+//   3. dense_rle_string_kernel, one workgroup per mask: the shared string emitter.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_to_columns_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                                int H, int W, int Hp) {
@@ -386,34 +386,48 @@ __global__ __launch_bounds__(256) void mask_to_columns_kernel(const uint8_t* __r
     }
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void dense_rle_kernel(const uint8_t* __restrict__ cols, uint32_t* __restrict__ trans,
-                                                                uint8_t* __restrict__ out_bytes,
-                                                                int32_t* __restrict__ out_len,
-                                                                int32_t* __restrict__ overflow, int H, int W, int Hp,
-                                                                int trans_cap, int byte_cap) {
-    __shared__ int wave_sums[RLE_THREADS / 64];
-    const int d = blockIdx.x, t = threadIdx.x;
+// The walk over a mask's change bits, split over DENSE_SEGS workgroups per mask (round 5: one 1024-thread workgroup per
+// mask kept 4 of the 256 CUs busy for ~100 us - 66 steps of ~150 instructions per wave, two integer divisions among them -
+// on the caller stream of the pipelined serving loop).  Three launches:
+//   dense_rle_walk_kernel<false>  per (segment, mask): counts the transitions of its contiguous chunk range
+//   dense_rle_walk_kernel<true>   ...: its offset = the counts of the segments before it; writes its transitions
+//   dense_rle_string_kernel       one workgroup per mask: transitions -> COCO string (emit_coco_string)
+// Inside a segment every wave owns a contiguous chunk range and walks it 64 chunks at a time (one contiguous kilobyte per
+// wave-load, DENSE_U loads issued ahead); the column / chunk-in-column of a chunk advance incrementally (no division).
+constexpr int DENSE_SEGS = 32;
+constexpr int DENSE_THREADS = 256;
+constexpr int DENSE_U = 4;
+
+template <bool EMIT>
+__global__ __launch_bounds__(DENSE_THREADS) void dense_rle_walk_kernel(const uint8_t* __restrict__ cols,
+                                                                         uint32_t* __restrict__ trans,
+                                                                         int32_t* __restrict__ seg_counts,
+                                                                         int H, int W, int Hp, int trans_cap) {
+    __shared__ int wave_sums[DENSE_THREADS / 64];
+    const int seg = blockIdx.x, d = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const uint8_t* m = cols + (size_t)d * W * Hp;
     const int cpc = Hp / 16;                                   // chunks per column
     const int n_chunks = W * cpc;
-    // Chunk -> thread: every WAVE owns a contiguous range of chunks and walks it 64 chunks at a time, lane l reading
-    // chunk base + l - one contiguous kilobyte per wave-load.  (Round 4 gave every THREAD a contiguous range: the 64
-    // lanes of a load then touched 64 different cache lines a kilobyte apart, 130 000 line requests per mask from the
-    // one CU a mask runs on - the kernel's 85 us were that, not its arithmetic.)
-    const int lane = t & 63, wv = t >> 6;
-    constexpr int NW = RLE_THREADS / 64;
-    const int per_wave = ((n_chunks + NW - 1) / NW + 63) / 64 * 64;
-    const int w_lo = min(wv * per_wave, n_chunks), w_hi = min(w_lo + per_wave, n_chunks);
-    // The walk is latency-bound, not bandwidth-bound (one workgroup per mask: 16 waves on one CU): a wave that waits for
-    // every load before it issues the next pays ~0.7 us x 65 steps x 2 passes - what the kernel's ~100 us were.  U loads
-    // are therefore issued ahead of the U steps that consume them.
-    constexpr int U = 8;
+    constexpr int NW = DENSE_THREADS / 64;
+    const int per_seg = ((n_chunks + DENSE_SEGS - 1) / DENSE_SEGS + 64 * NW - 1) / (64 * NW) * (64 * NW);
+    const int per_wave = per_seg / NW;                         // a multiple of 64
+    const int w_lo = min(seg * per_seg + wv * per_wave, n_chunks), w_hi = min(w_lo + per_wave, n_chunks);
+    int base = 0;
+    if (EMIT) {
+        int total = 0;
+        for (int s2 = 0; s2 < DENSE_SEGS; ++s2) {
+            const int c = seg_counts[d * DENSE_SEGS + s2];
+            if (s2 < seg) base += c;
+            total += c;
+        }
+        if (total > trans_cap) return;                         // (dense_rle_string_kernel flags the overflow)
+    }
     auto load_chunk = [&](int c) -> uint4 {
         return c < w_hi ? *reinterpret_cast<const uint4*>(m + (size_t)c * 16) : make_uint4(0u, 0u, 0u, 0u);
     };
-    // change bits of chunk c (its 16 bytes in v): bit r set iff pixel (x, 16*k + r) differs from its predecessor in scan
-    // order (the last pixel of the previous chunk: the neighbouring lane's, or for lane 0 one byte load)
-    auto chunk_bits = [&](int c, const uint4& v) -> unsigned {
+    // change bits of chunk c = chunk k of column x (its 16 bytes in v): bit r set iff pixel (x, 16 k + r) differs from its
+    // predecessor in scan order (the last pixel of the previous chunk: the neighbouring lane's, or for lane 0 one byte load)
+    auto chunk_bits = [&](int c, int k, const uint4& v) -> unsigned {
         const bool in = c < w_hi;
         // the 16 bytes are 0 / 1 (mask_to_columns_kernel normalises them): a multiply gathers the four low bits of a
         // word into one nibble (b0 | b1 << 1 | b2 << 2 | b3 << 3 lands in bits 24..27, the partial products never
@@ -424,61 +438,101 @@ __global__ __launch_bounds__(RLE_THREADS) void dense_rle_kernel(const uint8_t* _
         if (lane == 0) prev = (in && c > 0) ? (unsigned)(m[(size_t)c * 16 - 1] & 1) : 0u;
         if (!in) return 0u;
         const unsigned bits = (px ^ ((px << 1) | prev)) & 0xffffu;
-        const int k = c % cpc;
         const int valid = min(16, H - 16 * k);                  // pad rows never differ, but mask them anyway
         return valid >= 16 ? bits : (bits & ((1u << valid) - 1u));
     };
-    int cnt = 0;
-    for (int c0 = w_lo; c0 < w_hi; c0 += 64 * U) {
-        uint4 v[U];
+    // (x, k) of this lane's chunk, advanced by 64 chunks per step without a division
+    int c = w_lo + lane;
+    int x = c / cpc, k = c - x * cpc;
+    const int dx = 64 / cpc, dk = 64 - dx * cpc;
+    uint32_t* tr = trans + (size_t)d * trans_cap;
+    int cnt = 0, run = 0;
+    // ---- pass A (both variants): this thread's count (the emitting variant needs it for its offsets inside the segment)
+    {
+        int ca = c, ka = k;
+        for (int c0 = w_lo; c0 < w_hi; c0 += 64 * DENSE_U) {
+            uint4 v[DENSE_U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
+            for (int u = 0; u < DENSE_U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (c0 + 64 * u < w_hi) cnt += __popc(chunk_bits(c0 + 64 * u + lane, v[u]));
+            for (int u = 0; u < DENSE_U; ++u) {
+                if (c0 + 64 * u < w_hi) cnt += __popc(chunk_bits(ca, ka, v[u]));
+                ca += 64; ka += dk;
+                if (ka >= cpc) ka -= cpc;
+            }
+        }
     }
-    int T;
-    const int o_thread = block_exclusive_scan(cnt, wave_sums, &T);
+    // workgroup-level exclusive scan of the per-thread counts (thread order = wave-major); a wave's base = lane 0's
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_sums[wv] = incl;
+    __syncthreads();
+    int wave_base = 0, seg_total = 0;
+    for (int w = 0; w < NW; ++w) {
+        if (w < wv) wave_base += wave_sums[w];
+        seg_total += wave_sums[w];
+    }
+    if (!EMIT) {
+        if (t == 0) seg_counts[d * DENSE_SEGS + seg] = seg_total;
+        return;
+    }
+    // ---- pass B: emit, in (step, lane) order inside the wave's range
+    run = base + wave_base;
+    for (int c0 = w_lo; c0 < w_hi; c0 += 64 * DENSE_U) {
+        uint4 v[DENSE_U];
+#pragma unroll
+        for (int u = 0; u < DENSE_U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < DENSE_U; ++u) {
+            if (c0 + 64 * u < w_hi) {                            // (wave-uniform)
+                unsigned bits = chunk_bits(c, k, v[u]);
+                const int n = __popc(bits);
+                int sc = n;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(sc, off, 64);
+                    if (lane >= off) sc += up;
+                }
+                int o = run + sc - n;
+                run += __shfl(sc, 63, 64);
+                while (bits) {
+                    const int r = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    tr[o++] = (uint32_t)x * (uint32_t)H + (uint32_t)(16 * k + r);
+                }
+            }
+            c += 64; x += dx; k += dk;
+            if (k >= cpc) { k -= cpc; ++x; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void dense_rle_string_kernel(const uint32_t* __restrict__ trans,
+                                                                       const int32_t* __restrict__ seg_counts,
+                                                                       uint8_t* __restrict__ out_bytes,
+                                                                       int32_t* __restrict__ out_len,
+                                                                       int32_t* __restrict__ overflow, int H, int W,
+                                                                       int trans_cap, int byte_cap) {
+    __shared__ int wave_sums[RLE_THREADS / 64];
+    const int d = blockIdx.x, t = threadIdx.x;
+    int T = 0;
+    for (int s2 = 0; s2 < DENSE_SEGS; ++s2) T += seg_counts[d * DENSE_SEGS + s2];
     if (T > trans_cap) {
         if (t == 0) { overflow[d] = 1; out_len[d] = 0; }
         return;
     }
-    uint32_t* tr = trans + (size_t)d * trans_cap;
-    int run = __shfl(o_thread, 0, 64);           // transitions in front of this wave's range
-    for (int c0 = w_lo; c0 < w_hi; c0 += 64 * U) {
-        uint4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = load_chunk(c0 + 64 * u + lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (c0 + 64 * u >= w_hi) break;      // (wave-uniform)
-            const int c = c0 + 64 * u + lane;
-            unsigned bits = chunk_bits(c, v[u]);
-            const int n = __popc(bits);
-            int incl = n;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            int o = run + incl - n;
-            run += __shfl(incl, 63, 64);
-            const int x = c / cpc, k = c - x * cpc;
-            while (bits) {
-                const int r = __ffs(bits) - 1;
-                bits &= bits - 1;
-                tr[o++] = (uint32_t)x * (uint32_t)H + (uint32_t)(16 * k + r);
-            }
-        }
-    }
-    __syncthreads();
-    emit_coco_string(tr, T, (long long)H * W, out_bytes + (size_t)d * byte_cap, byte_cap, out_len + d, overflow + d,
-                     wave_sums);
+    emit_coco_string(trans + (size_t)d * trans_cap, T, (long long)H * W, out_bytes + (size_t)d * byte_cap, byte_cap,
+                     out_len + d, overflow + d, wave_sums);
 }
 
 extern "C" size_t fgn_dense_rle_scratch_bytes(int n_masks, int img_h, int img_w, int trans_cap) {
     const size_t hp = (size_t)(img_h + 15) / 16 * 16;
-    return (size_t)n_masks * img_w * hp + (size_t)n_masks * trans_cap * sizeof(uint32_t) + 256;
+    return (size_t)n_masks * img_w * hp + (size_t)n_masks * trans_cap * sizeof(uint32_t) + 256 +
+           (size_t)n_masks * DENSE_SEGS * sizeof(int32_t) + 256;
 }
 
 extern "C" int fgn_dense_mask_rle(const uint8_t* masks, void* scratch, size_t scratch_bytes, uint8_t* out_bytes,
@@ -494,11 +548,19 @@ extern "C" int fgn_dense_mask_rle(const uint8_t* masks, void* scratch, size_t sc
     uint8_t* cols = reinterpret_cast<uint8_t*>(scratch);
     const size_t cols_bytes = ((size_t)n_masks * img_w * hp + 255) / 256 * 256;
     uint32_t* trans = reinterpret_cast<uint32_t*>(cols + cols_bytes);
+    const size_t trans_bytes = ((size_t)n_masks * trans_cap * sizeof(uint32_t) + 255) / 256 * 256;
+    int32_t* seg_counts = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(trans) + trans_bytes);
     hipLaunchKernelGGL(mask_to_columns_kernel, dim3(cdiv(img_w, 64), cdiv(hp, 64), n_masks), dim3(256), 0, stream, masks,
                        cols, img_h, img_w, hp);
     FGN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dense_rle_kernel, dim3(n_masks), dim3(RLE_THREADS), 0, stream, cols, trans, out_bytes, out_len,
-                       overflow, img_h, img_w, hp, trans_cap, byte_cap);
+    hipLaunchKernelGGL(dense_rle_walk_kernel<false>, dim3(DENSE_SEGS, n_masks), dim3(DENSE_THREADS), 0, stream, cols, trans,
+                       seg_counts, img_h, img_w, hp, trans_cap);
+    FGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_rle_walk_kernel<true>, dim3(DENSE_SEGS, n_masks), dim3(DENSE_THREADS), 0, stream, cols, trans,
+                       seg_counts, img_h, img_w, hp, trans_cap);
+    FGN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_rle_string_kernel, dim3(n_masks), dim3(RLE_THREADS), 0, stream, trans, seg_counts, out_bytes,
+                       out_len, overflow, img_h, img_w, trans_cap, byte_cap);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }

@@ -139,11 +139,12 @@ class _Bottleneck:
             dbn = {k: sd[f'{prefix}.downsample.1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')}
             wd = sd[prefix + '.downsample.0.weight']
             self.down = ops.pack_conv(wd, bn=dbn, stride=stride, eps=eps)
-            # first block of a stride-1 stage (layer1.0): conv3 + bn3 and the shortcut conv + bn read the same pixels -
-            # one dual-operand K loop, no launch and no [rows, Cout] round trip for the shortcut (ops.conv1x1_dual)
+            # first block of a stage: conv3 + bn3 and the 1x1 shortcut conv + bn as ONE dual-operand K loop - no launch
+            # and no [rows, Cout] round trip for the shortcut (ops.conv1x1_dual).  Stride 1 (layer1.0): both read the
+            # same pixels; stride 2 (layer2.0, layer3.0): the shortcut's rows come through a row table (_strided_rows)
             w3 = sd[prefix + '.conv3.weight']
-            if ops.FUSED_SHORTCUT and stride == 1 and tuple(wd.shape[2:]) == (1, 1) and w3.shape[1] % 32 == 0 and \
-                    wd.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0:
+            if ops.FUSED_SHORTCUT and stride in ops.FUSED_SHORTCUT_STRIDES and tuple(wd.shape[2:]) == (1, 1) and \
+                    w3.shape[1] % 32 == 0 and wd.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0:
                 self.conv3_dual = ops.pack_conv_dual(w3, bn('bn3'), wd, dbn, relu=True, eps=eps)
 
     def layers(self):
@@ -160,9 +161,23 @@ class _Bottleneck:
             y = ops.conv3x3_winograd(y, self.conv2_wg, n_img_dev=n_img_dev)
         else:
             y = ops.conv2d(y, self.conv2, n_img_dev=n_img_dev)
-        if fused:
-            return ops.conv1x1_dual(y, x, self.conv3_dual)                     # relu(bn3(conv3(y)) + bn_d(conv_d(x)))
+        if fused:                                                              # relu(bn3(conv3(y)) + bn_d(conv_d(x)))
+            rows = None if self.down.stride == 1 else _strided_rows([tuple(x.shape[:3])], self.down.stride, x.device)
+            return ops.conv1x1_dual(y, x, self.conv3_dual, x2_rows=rows)
         return ops.conv2d(y, self.conv3, residual=idt, n_img_dev=n_img_dev)   # relu(bn3(conv3) + identity)
+
+
+_ROW_TABLES: dict = {}
+
+
+def _strided_rows(shapes, stride, device):
+    """``ops.strided_rows`` cached per (geometry, stride, device): built once on the host, outside any graph capture of
+    the same geometry (the eager run that precedes a capture fills the cache)."""
+    key = (tuple(shapes), int(stride), str(device))
+    t = _ROW_TABLES.get(key)
+    if t is None:
+        t = _ROW_TABLES[key] = ops.strided_rows(shapes, stride, device)
+    return t
 
 
 class _Pair:
@@ -223,8 +238,9 @@ def _bottleneck_pair(blk: '_Bottleneck', x: _Pair) -> _Pair:
     else:
         _conv_pair(y1.q, y1.s, blk.conv2, y2.q, y2.s)
     out = y2.like(blk.conv3.cout)
-    if fused:       # (stride 1: y2 and x hold the same rows)
-        ops.conv1x1_dual(y2.flat, x.flat, blk.conv3_dual, out=out.flat)
+    if fused:       # (stride 1: y2 and x hold the same rows; stride 2: the shortcut's rows through a row table)
+        rows = None if stride == 1 else _strided_rows([tuple(x.q.shape[:3]), tuple(x.s.shape[:3])], stride, x.buf.device)
+        ops.conv1x1_dual(y2.flat, x.flat, blk.conv3_dual, out=out.flat, x2_rows=rows)
     else:
         ops.conv2d(y2.flat, blk.conv3, residual=idt.flat, out=out.flat)
     return out

@@ -31,6 +31,7 @@ PROFILE = None
 STEM_POOL_FUSION = os.environ.get('FGN_STEM_POOL', '0') != '0'
 # conv3 + shortcut conv of the first block of a stride-1 stage as one dual-operand K loop (conv1x1_dual).  A/B knob.
 FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
+FUSED_SHORTCUT_STRIDES = tuple(int(v) for v in os.environ.get('FGN_FUSED_SHORTCUT_STRIDES', '1,2').split(','))
 
 _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
 
@@ -354,13 +355,35 @@ def pack_conv_dual(w1: torch.Tensor, bn1: dict, w2: torch.Tensor, bn2: dict, rel
     return DualConvLayer(wp.contiguous(), shift.float().contiguous(), cin1, cin2, cout, cout_pad, relu)
 
 
-def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x1 [..., Cin1], x2 [..., Cin2] over the same leading dims (rows) -> relu?(x1 W1^T + x2 W2^T + shift) [..., Cout]."""
+def strided_rows(shapes, stride: int, device) -> torch.Tensor:
+    """Row table of a 1x1 / stride ``stride`` convolution over NHWC tensors that lie one behind the other in one buffer
+    (``shapes`` = [(n, H, W), ...]): output row m (images, then output rows, then output columns, tensor after tensor) ->
+    the input row it reads.  int32 on ``device``; for ``conv1x1_dual(..., x2_rows=)``."""
+    out, base = [], 0
+    for n, H, W in shapes:
+        ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        img = torch.arange(n, dtype=torch.int64)[:, None, None] * (H * W)
+        oy = torch.arange(ho, dtype=torch.int64)[None, :, None] * (stride * W)
+        ox = torch.arange(wo, dtype=torch.int64)[None, None, :] * stride
+        out.append((base + img + oy + ox).reshape(-1))
+        base += n * H * W
+    return torch.cat(out).to(torch.int32).to(device)
+
+
+def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: Optional[torch.Tensor] = None,
+                 x2_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x1 [..., Cin1] -> relu?(x1 W1^T + x2' W2^T + shift) [..., Cout], x2' = x2 over the same leading dims (rows), or -
+    with ``x2_rows`` (int32 [rows], ``strided_rows``) - row x2_rows[m] of x2 [..., Cin2] for output row m."""
     _chk(x1, 'x1')
     _chk(x2, 'x2')
-    if x1.shape[-1] != layer.cin1 or x2.shape[-1] != layer.cin2 or x1.shape[:-1] != x2.shape[:-1]:
-        raise _lib.FgnHipError('conv1x1_dual: operand shapes inconsistent with the layer')
     rows = x1.numel() // layer.cin1
+    if x1.shape[-1] != layer.cin1 or x2.shape[-1] != layer.cin2 or (x2_rows is None and x1.shape[:-1] != x2.shape[:-1]):
+        raise _lib.FgnHipError('conv1x1_dual: operand shapes inconsistent with the layer')
+    x2_total = x2.numel() // layer.cin2
+    if x2_rows is not None:
+        _chk(x2_rows, 'x2_rows', torch.int32)
+        if x2_rows.numel() != rows:
+            raise _lib.FgnHipError('conv1x1_dual: x2_rows must hold one input row per output row')
     shape = tuple(x1.shape[:-1]) + (layer.cout,)
     if out is None:
         out = torch.empty(shape, device=x1.device, dtype=torch.float32)
@@ -372,8 +395,8 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(layer.w), _ptr(out), _ptr(layer.shift), rows, layer.cin1,
-                                     layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
+    rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, _ptr(layer.w), _ptr(out), _ptr(layer.shift),
+                                     rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
     _lib.check(rc, 'fgn_conv1x1_dual_nhwc_f32')
     if prof is not None:
         k = layer.cin1 + layer.cin2
@@ -458,7 +481,7 @@ _WG_G = {
                      [1 / 15, -2 / 15, 4 / 15], [0.0, 0.0, 1.0]], dtype=torch.float64),
 }
 WINOGRAD_M = 4       # default output tile edge
-_WG_MIN_CIN = int(os.environ.get('FGN_WG_MIN_CIN', '64'))     # A/B knob of round 5 (layer1 direct vs F(4x4)): see winograd_pays
+_WG_MIN_CIN = int(os.environ.get('FGN_WG_MIN_CIN', '128'))    # F(4x4) from this many input channels (A/B knob: see winograd_pays)
 
 
 def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -541,8 +564,10 @@ def winograd_fits(n_img: int, H: int, W: int, cin: int, cout: int, m: Optional[i
 def winograd_pays(n_img: int, H: int, W: int, cin: int, cout: int, m: Optional[int] = None) -> bool:
     """Measured on MI355X (tools/wg_bench.py, direct -> F(2x2) -> F(4x4)): AG-RPN conv 2.23 -> 0.95 -> 0.57 ms,
     shared_head 3x3 on 300 RoIs 0.65 -> 0.43 -> 0.29 ms, layer1 (64 channels, 200x334) 65 -> 70 -> 57 us; the
-    9-RoI support head (441 pixels) loses to the launch costs of the three kernels.  F(4x4) pays from 64 input
-    channels, F(2x2) from 128; both need about a thousand output pixels."""
+    9-RoI support head (441 pixels) loses to the launch costs of the three kernels.  Both forms need about a thousand
+    output pixels and 128 input channels.  (Alone, F(4x4) wins at 64 channels too - layer1: 57 us against 65 for the direct
+    form - but its three launches move 5.5x the bytes, and in the pipelined step, beside the other episode's GEMMs, the
+    direct form wins: round 5, same box, three interleaved pairs 203.2-204.0 -> 204.4-204.8 img/s.)"""
     m = WINOGRAD_M if m is None else m
     return cin >= (_WG_MIN_CIN if m == 4 else 128) and n_img * H * W >= 1024 and winograd_fits(n_img, H, W, cin, cout, m)
 

@@ -86,10 +86,12 @@ int fgn_conv2d_nhwc_f32(const float* x, const float* w_packed, float* y, const f
 /* Two 1x1 / stride 1 convolutions on the same rows summed in one K loop: y = x W1^T + x2 W2^T + shift (ReLU), w_packed
  * [cout_pad][Cin1 + Cin2] with both BatchNorm scales folded into its rows.  Replaces conv3 + bn3 and the shortcut
  * conv + bn + add + ReLU of the first Bottleneck of a stride-1 stage (mmdet ResNet layer1.0 under fgn.py:212,215):
- * no launch and no [rows, Cout] round trip for the shortcut.  x [rows,Cin1], x2 [rows,Cin2], y [rows,Cout];
- * Cin1, Cin2 multiples of 32, Cout % 4 == 0. */
-int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const float* w_packed, float* y, const float* shift,
-                              int rows, int Cin1, int Cin2, int Cout, int cout_pad, int relu, void* stream);
+ * no launch and no [rows, Cout] round trip for the shortcut.  x [rows,Cin1], y [rows,Cout]; x2 [x2_total_rows,Cin2]:
+ * output row m reads row x2_rows[m] of it (device int32: the 1x1 / stride 2 shortcut of layer2.0 / layer3.0), or row m
+ * when x2_rows is NULL (x2_total_rows = rows).  Cin1, Cin2 multiples of 32, Cout % 4 == 0. */
+int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                              const float* w_packed, float* y, const float* shift, int rows, int Cin1, int Cin2, int Cout,
+                              int cout_pad, int relu, void* stream);
 
 /* The same convolution (w_packed, scale, shift, relu as in fgn_conv2d_nhwc_f32) on TWO NHWC tensors of different
  * geometry in one launch: x0 [n_img0,H0,W0,Cin] -> y0, x1 [n_img1,H1,W1,Cin] -> y1.  For the backbone layers that

@@ -265,3 +265,31 @@ def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, co
     assert (got - two).abs().max().item() <= 4e-6 * ref.abs().max().item()
     again = ops.conv1x1_dual(yc, xc, layer)
     assert torch.equal(got, again)
+
+
+def test_dual_operand_conv_with_a_strided_shortcut():
+    """The 1x1 / stride 2 shortcut of layer2.0 / layer3.0 inside conv3's K loop: output row m reads row x2_rows[m] of the
+    stage's input (``ops.strided_rows`` over the query map and the support maps lying one behind the other) - against the
+    two-launch form (strided shortcut conv, then conv3 with the residual in its epilogue) and fp64."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    cin1, cin2, cout = 64, 96, 128
+    q, s_ = torch.randn(1, 21, 34, cin2, generator=g), torch.randn(3, 10, 10, cin2, generator=g)
+    buf = torch.cat([q.reshape(-1, cin2), s_.reshape(-1, cin2)]).cuda().contiguous()
+    rows_tab = ops.strided_rows([(1, 21, 34), (3, 10, 10)], 2, 'cuda')
+    rows = rows_tab.numel()
+    assert rows == 11 * 17 + 3 * 5 * 5
+    y = torch.randn(rows, cin1, generator=g)
+    w3, wd = torch.randn(cout, cin1, 1, 1, generator=g) / 8, torch.randn(cout, cin2, 1, 1, generator=g) / 10
+    mk = lambda: dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
+                      running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
+    bn3, bnd = mk(), mk()
+    layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
+    yc = y.cuda().view(1, rows, 1, cin1)
+    got = ops.conv1x1_dual(yc, buf.view(1, -1, 1, cin2), layer, x2_rows=rows_tab)
+    down = ops.pack_conv(wd, bn=bnd, stride=2).to('cuda')
+    idt = torch.cat([ops.conv2d(q.cuda(), down).reshape(-1, cout), ops.conv2d(s_.cuda(), down).reshape(-1, cout)])
+    two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'), residual=idt.view(1, rows, 1, cout))
+    assert (got - two).abs().max().item() <= 4e-6 * two.abs().max().item()
+    with pytest.raises(Exception):
+        ops.conv1x1_dual(yc, buf.view(1, -1, 1, cin2), layer)                 # rows differ and no table

@@ -13,7 +13,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_default.out" 2> "$O
 echo "default: $(cut -c1-160 "$OUT/${R}_bench_line.json")"
 # 1b. where in the timed window the isolated instrumented step sits: step 0 (the first work after the barrier's device
 # synchronisation - what rounds 1-4 reported), steps in the middle and the last one (the default), one run
-python bench.py --gpus 1 --steps 60 --warmup 5 --isolated-steps 0,15,30,45,59 --no-cpu-baseline > "$OUT/b.out" 2> "$OUT/bench_iso.err"; last_json "$OUT/b.out" > "$OUT/${R}_bench_isolated_spread.json"
+python bench.py --gpus 1 --steps 60 --warmup 5 --isolated-steps 0,15,30,45,59 --launch-records --no-cpu-baseline > "$OUT/b.out" 2> "$OUT/bench_iso.err"; last_json "$OUT/b.out" > "$OUT/${R}_bench_isolated_spread.json"
 python - "$OUT/${R}_bench_isolated_spread.json" <<'PY'
 import json, sys
 r = json.load(open(sys.argv[1]))['roofline']

@@ -5,7 +5,7 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 roles = {'persistGEMM': 'conv_pw_persist', 'det_post': 'det_post_kernel', 'class_vector(side)': 'class_vector_kernel',
-         'roi_align_mask(side)': 'roi_align_mask_kernel', 'dense_rle(upload)': 'dense_rle_kernel', 'blit': '__amd_rocclr_copyBuffer',
+         'roi_align_mask(side)': 'roi_align_mask_kernel', 'dense_rle(upload)': 'dense_rle_walk_kernel', 'blit': '__amd_rocclr_copyBuffer',
          'mask_rle(main end)': 'mask_rle_kernel', 'wg4_input': 'wg4_input_kernel', 'fill': 'FillFunctor', 'cat': 'CatArrayBatchedCopy'}
 per = collections.defaultdict(lambda: collections.Counter())
 busy = collections.Counter()
