@@ -505,7 +505,8 @@ def main():
     # cost tens of ms):
     #  * every launch of the dominant kernel in EVERY timed step adds its span to a launch record inside the kernel
     #    (in-kernel 100 MHz stamps, first workgroup start -> last workgroup end: works inside the replayed graphs at two
-    #    atomics per workgroup) -> `roofline.timed_window`, the regime a rocprofv3 kernel trace of this command sees;
+    #    atomics per workgroup) -> `roofline.timed_window`: the untraced pipeline (a rocprofv3 kernel trace slows the step
+    #    to ~6 ms and its launches hardly overlap: its averages are the isolated regime's);
     #  * `--isolated-steps` (default: the last timed step) are launched eagerly with a start / stop HIP event pair per
     #    convolution launch while they have the GPU to themselves -> `roofline.achieved / frac / by_kernel /
     #    launch_classes`.  Rounds 1-4 instrumented step 0 - the first work after the barrier's device synchronisation, on
@@ -670,8 +671,8 @@ def main():
                             for a, r in zip(per_site, sites) if a['executions'] and r['e0'].elapsed_time(r['e1']) > 0)
             window = {'what': 'EVERY launch of the kernel in the timed region (all steps, both caller streams, inside the '
                               'replayed hipGraphs): span first workgroup start -> last workgroup end on the 100 MHz '
-                              'in-kernel clock, folded into a launch record by the kernel itself (fgn_profile_stamps); the '
-                              'regime a rocprofv3 kernel trace of this command reports',
+                              'in-kernel clock, folded into a launch record by the kernel itself (fgn_profile_stamps): the '
+                              'launches as they run in the untraced pipeline, beside the other caller stream',
                       'launches': n_exec, 'launch_sites_per_step': len(sites),
                       'executions_per_site': sorted({a['executions'] for a in per_site}),
                       'avg_launch_us': round(w_us / n_exec, 2),

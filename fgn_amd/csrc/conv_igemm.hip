@@ -79,6 +79,10 @@ struct ConvParams {
     unsigned x2_bytes;
     int kt1, cin2;
     const int32_t* x2_rows;      // optional: row m of the output reads row x2_rows[m] of x2 (a strided shortcut); nullptr: row m
+    // conv_pw_x3_kernel (conv_pw_x3.h): the weights as three bf16 planes, [group][K-tile][plane][npad3][32], or nullptr
+    const void* w3 = nullptr;
+    unsigned w3_bytes = 0;
+    int npad3 = 0;
 };
 
 #ifndef CONV_DMA_STAGES
@@ -1069,6 +1073,8 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
     CLOCK_STAMP_END(blockIdx.x);
 }
 
+#include "conv_pw_x3.h"
+
 #ifdef FGN_EXPERIMENTS
 #define FGN_EXP_PART 1       // kernels and tuning state
 #include "../../tools/micro/conv_pw_experiments.inc"
@@ -1456,6 +1462,86 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
     FGN_LAUNCH_TIMED(conv_pw_persist_kernel, dim3(grid), dim3(256), plds, stream, p, tiles);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw_x3_kernel launches (conv_pw_x3.h): p describes a point-wise / grouped GEMM as for conv_pw_persist_kernel and
+// carries the bf16-plane image of its weights (w3, w3_bytes, npad3).  bm: 0 = choose, 64 / 128 = force the row tile;
+// nterms 6 (default) or 9.  The persistent grid is 2 workgroups per CU (LDS: 64 / 80 KB per workgroup).
+// ------------------------------------------------------------------------------------------------
+static int x3_pick_bm(long long M, int Cout, int grp_rows, int bm) {
+    if (bm == 64 || bm == 128) return (grp_rows && grp_rows % bm) ? 0 : bm;
+    const long long t128 = ((M + 127) / 128) * cdiv(Cout, X3_BN);
+    if (t128 >= 448 && (!grp_rows || grp_rows % 128 == 0)) return 128;
+    return (grp_rows && grp_rows % 64) ? 0 : 64;
+}
+
+template <int WMW, int NT>
+static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
+    constexpr int BM = 32 * WMW;
+    const int m_tiles = cdiv(M_max, BM);
+    {   // banded raster: <= 2 MB of weight image per band (see ConvParams::band_nt)
+        const long long per_nt = (long long)X3_BN * p.K * 6;
+        p.band_nt = 0; p.band_mt = 0;
+        if (per_nt * p.n_tiles_n > 2048 * 1024) {
+            int nb = (int)std::max<long long>(1, 2048 * 1024 / per_nt);
+            while (nb > 1 && p.n_tiles_n % nb) --nb;
+            const int mt = p.grp_rows ? p.grp_rows / BM : m_tiles;
+            if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
+        }
+    }
+    const int tiles = m_tiles * p.n_tiles_n;
+    static unsigned long long ok = 0ull;
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_x3_kernel<WMW, NT>), &ok);
+    if (attr != hipSuccess) return (int)attr;
+    const size_t lds = (size_t)2 * (BM * 128 + X3_B_STAGE);
+    const int grid = std::min(512, (tiles + 7) / 8 * 8);
+    p.stamp = fgn_next_stamp_record();
+    FGN_LAUNCH_TIMED((conv_pw_x3_kernel<WMW, NT>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+static int launch_x3(const ConvParams& p0, int M_max, int bm, int nterms, hipStream_t stream) {
+    ConvParams p = p0;
+    if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.splits != 1) return FGN_ERR_SHAPE;
+    p.n_tiles_n = cdiv(p.Cout, X3_BN);
+    const int BM = x3_pick_bm(M_max, p.Cout, p.grp_rows, bm);
+    if (BM == 0) return FGN_ERR_SHAPE;
+    if (nterms == 9)
+        return BM == 128 ? launch_x3_cfg<4, 9>(p, M_max, stream) : launch_x3_cfg<2, 9>(p, M_max, stream);
+    return BM == 128 ? launch_x3_cfg<4, 6>(p, M_max, stream) : launch_x3_cfg<2, 6>(p, M_max, stream);
+}
+
+extern "C" size_t fgn_x3_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * K * npad * 6; }
+
+// y[rows, Cout] = relu?(x[rows, K] * W^T + shift + residual) with W given as its bf16-plane image (ops.pack_x3);
+// grouped: rows = n_groups * grp_rows, group g uses image g and computes its first grp_valid rows.  The direct entry
+// of conv_pw_x3_kernel (tests, tools); the convolution entry points take the image as an optional argument.
+extern "C" int fgn_gemm_x3_f32(const float* x, const void* w3, float* y, const float* shift, const float* residual,
+                               int rows, int K, int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups,
+                               int bm, int nterms, hipStream_t stream) {
+    if (!x || !w3 || !y) return FGN_ERR_ARG;
+    if (rows <= 0) return FGN_OK;
+    if (K % BK || K <= 0 || (Cout & 3) || npad % X3_BN || npad < Cout || n_groups < 1) return FGN_ERR_SHAPE;
+    if (n_groups > 1 && (grp_rows <= 0 || (long long)n_groups * grp_rows != rows || grp_valid > grp_rows)) return FGN_ERR_SHAPE;
+    const long long xb = (long long)rows * K * 4, wb = (long long)fgn_x3_image_bytes(K, npad, n_groups);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    p.x = x; p.w = nullptr; p.y = y; p.scale = nullptr; p.shift = shift; p.residual = residual; p.in_scale = nullptr;
+    p.n_img_dev = nullptr; p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0; p.x2_rows = nullptr;
+#ifdef FGN_EXPERIMENTS
+    p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
+    p.n_img = rows; p.H = 1; p.W = 1; p.Cin = K; p.Ho = 1; p.Wo = 1; p.Cout = Cout; p.KH = 1; p.KW = 1;
+    p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = relu; p.K = K;
+    p.ws = nullptr; p.splits = 1; p.kt_per_split = K / BK;
+    p.x_bytes = (unsigned)xb; p.w_bytes = 0;
+    p.grp_rows = n_groups > 1 ? grp_rows : 0; p.grp_valid = grp_valid; p.grp_items = 0; p.grp_rows_per_item = 0;
+    p.grp_w_stride = 0; p.grp_count_dev = nullptr;
+    p.band_nt = 0; p.band_mt = 0; p.n_tiles_n = 0;
+    p.w3 = w3; p.w3_bytes = (unsigned)wb; p.npad3 = npad;
+    return launch_x3(p, rows, bm, nterms, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

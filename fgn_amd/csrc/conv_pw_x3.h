@@ -1,0 +1,297 @@
+// conv_pw_x3_kernel - the point-wise / grouped GEMM of conv_pw_persist_kernel with its products on the BF16 matrix pipe.
+// Included by conv_igemm.hip (ConvParams, make_rsrc, lds_dma16_s, BK are defined there).
+//
+// Why.  gfx950 has no xf32 / TF32 form; its f32-input MFMA runs at the VECTOR rate, 64 FLOP / clk / SIMD, 1/16 of the
+// bf16 MFMA (MI355X_MICROARCH.md, matrix cores).  conv_pw_persist_kernel holds 0.84-0.87 of that f32 peak on its large
+// GEMMs back to back: the remaining head-room of this path is the pipe, not the kernel.  An f32 value is the
+// EXACT sum of three bf16 values (8 significant bits each: x1 = x with the low 16 bits cleared, x2 the same of x - x1,
+// x3 = x - x1 - x2, each subtraction exact), and the product of two bf16 values is exact in f32 (16 significant bits).
+// a * b = sum of nine bf16 products; the three smallest (a2 b3, a3 b2, a3 b3) are below 2^-23 |a b| - the rounding an f32
+// FMA chain makes at every step - and are left out: six bf16 MFMAs per f32 MFMA's worth of K, accumulated in f32 by the
+// matrix pipe, at 16x the rate: 6/16 of the f32 pipe's time.  Measured against fp64 the result is as close as the f32
+// MFMA kernel's (tests/test_hip_conv.py::test_x3_*; NT = 9 takes all nine terms).
+//
+// Operands.  A: f32 activations exactly as conv_pw_persist_kernel reads them (rows of Cin floats, LDS-DMA, the same
+// XOR-swizzled 128-byte tile rows, optional second operand / row table); split into its three bf16 planes in REGISTERS,
+// after the ds_read (~5.5 vector instructions per element; a wave's 32 rows are used against 64 output columns, so
+// the split is 44 instructions per 12 MFMAs of 32 cycles and hides under them).  B: the weights, split ONCE at pack
+// time (fgn_amd/ops.py::pack_x3) into an image that is the LDS image tile by tile: [group][K-tile][plane][Npad][32]
+// bf16, 64 bytes per row, the row's four 16-byte chunks XOR-ed with (n >> 2) & 3 - a K-tile of one plane for 128
+// output columns is 8 KB of contiguous memory, fetched by 8 wave-instructions.
+// Tile: BM = 32 * WMW rows x 128 columns, 64 * 2 * WMW threads, wave tile 32 x 64 as two v_mfma_f32_32x32x16_bf16
+// blocks.  An output tile of 128 x 128 moves 0.078 B / MAC through L2 -> LDS against 0.125 for the 64 x 64 f32 tile:
+// at twice the MAC rate ~10 TB/s of L2 -> LDS traffic, which the XCD L2s deliver (17-19 TB/s measured by the guide).
+// LDS: 2 stages x (BM * 128 + 24576) bytes; the C tile of the epilogue (64 rows x 128 floats per pass) lives in stage 1
+// while stage 0 receives the first K-tile of the next output tile, as in conv_pw_persist_kernel.
+#pragma once
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct X3Frag { bf16x8_t p1, p2, p3; };
+
+// eight f32 -> three planes of eight bf16 (truncating split: every plane has the sign of x, x = p1 + p2 + p3 exactly)
+__device__ __forceinline__ X3Frag x3_split(const float4& lo, const float4& hi) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
+        q1[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                       // hi16(u0) | hi16(u1) << 16
+        const float r0 = x[2 * i] - __uint_as_float(u0 & 0xffff0000u);
+        const float r1 = x[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        q2[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
+        const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        q3[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    X3Frag f;
+    f.p1 = __builtin_bit_cast(bf16x8_t, make_uint4(q1[0], q1[1], q1[2], q1[3]));
+    f.p2 = __builtin_bit_cast(bf16x8_t, make_uint4(q2[0], q2[1], q2[2], q2[3]));
+    f.p3 = __builtin_bit_cast(bf16x8_t, make_uint4(q3[0], q3[1], q3[2], q3[3]));
+    return f;
+}
+
+constexpr int X3_BN = 128;
+constexpr int X3_B_STAGE = 3 * X3_BN * 64;       // bytes of one K-tile of the weight image for 128 columns
+
+template <int WMW, int NT>
+__global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kernel(const ConvParams p, const int total_tiles) {
+    constexpr int BM = 32 * WMW, BN = X3_BN, NTHR = 128 * WMW, NW = 2 * WMW;
+    constexpr int A_STAGE = BM * 128;                       // bytes
+    constexpr int STAGE = A_STAGE + X3_B_STAGE;             // bytes
+    constexpr int B_LD = 24 / NW;                           // weight wave-instructions per wave per K-tile
+    constexpr int ROWS_PER_PASS = NTHR / 8;                 // A rows one pass of the workgroup's DMAs covers
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
+    int grp_valid = p.grp_valid;
+    if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
+
+    const int col4 = t & 7, row0 = t >> 3;
+    const int src_c4 = col4 ^ ((row0 >> 1) & 7);
+    const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
+    const i32x4 w_rs = make_rsrc(p.w3, p.w3_bytes);
+    const bool dual = p.x2 != nullptr;
+    const i32x4 x2_rs = make_rsrc(dual ? p.x2 : p.x, dual ? p.x2_bytes : p.x_bytes);
+    const int KT = p.K / BK;
+    const unsigned kt_bytes = (unsigned)(3 * p.npad3 * 64);          // one K-tile of the image, all planes, all rows
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem_x3));
+    const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    const int nq = total_tiles >> 3, nr = total_tiles & 7;
+    auto coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int bid = (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + idx;
+        int tile_m = bid / p.n_tiles_n;
+        int tile_n = bid - tile_m * p.n_tiles_n;
+        if (p.band_nt > 0) {
+            const int per_grp = p.band_mt * p.n_tiles_n;
+            const int grp = bid / per_grp;
+            int r = bid - grp * per_grp;
+            const int per_band = p.band_mt * p.band_nt;
+            const int band = r / per_band;
+            r -= band * per_band;
+            const int mi = r / p.band_nt;
+            tile_m = grp * p.band_mt + mi;
+            tile_n = band * p.band_nt + (r - mi * p.band_nt);
+        }
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        if (m0 >= M) return false;
+        if (p.grp_rows && m0 - (m0 / p.grp_rows) * p.grp_rows >= grp_valid) return false;
+        return true;
+    };
+    auto next_active = [&](int tile, int& m0, int& n0) -> int {
+        for (; tile < total_tiles; tile += gridDim.x)
+            if (coords(tile, m0, n0)) return tile;
+        return -1;
+    };
+
+    unsigned a_voff[2], a2_voff[2], b_voff[B_LD];
+    unsigned b_lds[B_LD];
+    {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = wv + NW * i;                     // wave-instruction q of 24: plane q / 8, rows 16 * (q % 8) ..
+            b_lds[i] = __builtin_amdgcn_readfirstlane((unsigned)(A_STAGE + (q >> 3) * (BN * 64) + (q & 7) * 1024));
+        }
+    }
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + row0 + ROWS_PER_PASS * i;
+            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+            a2_voff[i] = OOB;
+            if (dual && m < M) a2_voff[i] = (unsigned)(((p.x2_rows ? p.x2_rows[m] : m) * p.cin2 + src_c4 * 4) * 4);
+        }
+        unsigned g0 = 0;
+        if (p.grp_rows) g0 = (unsigned)(m0 / p.grp_rows) * (unsigned)KT * kt_bytes;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = wv + NW * i;
+            const int plane = q >> 3, row = (q & 7) * 16 + (lane >> 2);
+            b_voff[i] = g0 + (unsigned)(((plane * p.npad3 + n0 + row) * 4 + (lane & 3)) * 16);
+        }
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned st = lds_base + stage * STAGE;
+        const unsigned sa = st + wave_row_bytes;
+        const unsigned ko = (unsigned)(kt * BK * 4);
+        if (dual && kt >= p.kt1) {
+            const unsigned ko2 = (unsigned)((kt - p.kt1) * BK * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, a2_voff[i], ko2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, a_voff[i], ko);
+        }
+        const unsigned kb = (unsigned)kt * kt_bytes;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, st + b_lds[i], b_voff[i], kb);
+    };
+
+    // fragment addresses (bytes within a stage).  32x32x16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h + 7
+    const int r32 = lane & 31, h = lane >> 5;
+    const int a_row = wm * 32 + r32;
+    const unsigned a_sw = (unsigned)((a_row >> 1) & 7);
+    const unsigned a_rd = (unsigned)(a_row * 128);
+    unsigned b_rd[2], b_sw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + 32 * j + r32;
+        b_rd[j] = (unsigned)(A_STAGE + n * 64);
+        b_sw[j] = (unsigned)((n >> 2) & 3);
+    }
+    float* const cbase = reinterpret_cast<float*>(smem_x3 + STAGE);          // stage 1
+
+    if (p.stamp && t == 0 && blockIdx.x == 0) atomicExch(p.stamp, __builtin_amdgcn_s_memrealtime());
+    auto leave = [&]() {
+        if (!p.stamp || t != 0) return;
+        const unsigned shard = blockIdx.x & 7u;
+        const unsigned long long in_shard = (gridDim.x - shard + 7u) / 8u;
+        unsigned long long* const sc = p.stamp + 8 * (1 + shard);
+        if (atomicAdd(sc, 1ull) != in_shard - 1) return;
+        atomicExch(sc, 0ull);
+        const unsigned long long shards = gridDim.x < 8u ? gridDim.x : 8u;
+        if (atomicAdd(p.stamp + 2, 1ull) != shards - 1) return;
+        const unsigned long long d = __builtin_amdgcn_s_memrealtime() - atomicExch(p.stamp, 0ull);
+        atomicExch(p.stamp + 2, 0ull);
+        atomicAdd(p.stamp + 1, d);
+        atomicAdd(p.stamp + 3, 1ull);
+        atomicMin(p.stamp + 4, d);
+        atomicMax(p.stamp + 5, d);
+    };
+    int m0, n0;
+    int tile = next_active(blockIdx.x, m0, n0);
+    if (tile < 0) { leave(); return; }
+    set_offsets(m0, n0);
+    issue_tile(0, 0);
+
+    while (true) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            const unsigned char* const S = smem_x3 + cur * STAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned ca = (unsigned)(4 * s + 2 * h);
+                const float4 alo = *reinterpret_cast<const float4*>(S + a_rd + ((ca ^ a_sw) << 4));
+                const float4 ahi = *reinterpret_cast<const float4*>(S + a_rd + (((ca + 1) ^ a_sw) << 4));
+                bf16x8_t b1[2], b2[2], b3[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned off = b_rd[j] + ((((unsigned)(2 * s + h)) ^ b_sw[j]) << 4);
+                    b1[j] = *reinterpret_cast<const bf16x8_t*>(S + off);
+                    b2[j] = *reinterpret_cast<const bf16x8_t*>(S + off + BN * 64);
+                    b3[j] = *reinterpret_cast<const bf16x8_t*>(S + off + 2 * BN * 64);
+                }
+                const X3Frag a = x3_split(alo, ahi);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (NT == 9) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b3[j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b2[j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b3[j], acc[j], 0, 0, 0);
+                    }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b1[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b3[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b2[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b1[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b2[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b1[j], acc[j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        const int em0 = m0, en0 = n0;
+        int nm0 = 0, nn0 = 0;
+        const int next = next_active(tile + gridDim.x, nm0, nn0);
+        if (next >= 0) {
+            set_offsets(nm0, nn0);
+            issue_tile(0, 0);
+        }
+        // 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 64 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < WMW / 2; ++pass) {
+            if (pass) __syncthreads();
+            if ((wm >> 1) == pass) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* cw = cbase + ((wm & 1) * 32 + 4 * h) * BN + wn * 64 + 32 * j + r32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * BN] = acc[j][r];
+                }
+            }
+            __syncthreads();
+            constexpr int C4 = BN / 4, RPP = NTHR / C4, NPASS = 64 / RPP;
+            const int c4 = t % C4, rr = t / C4;
+            const int n = en0 + c4 * 4;
+            if (n < p.Cout) {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+                for (int k0 = 0; k0 < NPASS; k0 += 4) {
+                    float4 res[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = em0 + 64 * pass + rr + RPP * (k0 + k);
+                        res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.residual && m < M) res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = rr + RPP * (k0 + k);
+                        const int m = em0 + 64 * pass + row;
+                        if (m >= M) continue;
+                        float4 v = *reinterpret_cast<const float4*>(cbase + row * BN + c4 * 4);
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                        v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w;
+                        if (p.relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+                    }
+                }
+            }
+        }
+        if (next < 0) break;
+        tile = next; m0 = nm0; n0 = nn0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    leave();
+}

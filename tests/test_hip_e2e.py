@@ -721,3 +721,91 @@ def test_paste_semantics_of_the_cuda_reference_end_to_end():
     for a, b in zip(got['cpu']['dt_isegmaps_rle'], got['cuda']['dt_isegmaps_rle']):
         n_diff += int((rle.decode(a) != rle.decode(b)).sum())
     assert n_diff > 0                    # below 0.5 the semantics really differ
+
+
+def test_graph_cache_key_covers_what_a_captured_episode_bakes_in():
+    """a captured hipGraph bakes in the paste semantic (an argument of the fused RLE kernel), the
+    transfer arrangement (which streams the capture forks) and the phase mark (a captured kernel with the counter's
+    address).  Changing any of them after the first graphed call must capture a NEW graph, not replay the old one: at a
+    mask threshold below 0.5 the two paste semantics give different masks, and a replayed episode must bump the counter it
+    was GIVEN for this call."""
+    import copy
+    from fgn_amd import ops, rle
+    from fgn_amd.config import tiny_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = copy.deepcopy(tiny_config(3, 2, width_div=2))
+    cfg['test_cfg']['rcnn']['mask_thr_binary'] = 0.2
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FGN(3, 2, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+                    test_cfg=cfg['test_cfg'], state_dict=init_state_dict(cfg, 0))
+    batch = make_batch(3, 1, 3, 2, 160, 224, 64)
+    eager = {}
+    for sem in ('cpu', 'cuda'):
+        model.paste_semantics = sem
+        eager[sem] = model.simple_test(**batch, rescale=True)[0]['dt_isegmaps_rle']
+    assert eager['cpu'] != eager['cuda']
+    model.use_graphs = True
+    for sem in ('cpu', 'cuda', 'cpu'):
+        model.paste_semantics = sem
+        assert model.simple_test(**batch, rescale=True)[0]['dt_isegmaps_rle'] == eager[sem], sem
+    assert len(model._graphs) == 2
+    # phase mark: the counter is an argument of the call; two counters -> two graphs, each bumping its own
+    model.phase_point = 'rpn'
+    marks = torch.zeros(2, dtype=torch.int32, device='cuda')
+    for k in (0, 1, 1, 0, 1):
+        dets = model.detect_device(batch['qry_img'], batch['spp_imgs'], batch['spp_bboxes'], batch['spp_isegmaps'],
+                                   batch['img_shape'], phase_counter=marks[k:k + 1])
+        model.pack_results(dets, 1, img_shape=batch['img_shape'])
+    torch.cuda.synchronize()
+    assert marks.tolist() == [2, 3] and len(model._graphs) == 4
+    n = len(model._graphs)
+    model.transfer_stream(3)
+    model.simple_test(**batch, rescale=True)
+    assert len(model._graphs) == n + 1
+
+
+def test_launch_records_and_packed_transfers():
+    """(1) Launch records (``FGN.stamp_capacity``, fgn_profile_stamps): every launch of the persistent GEMM kernel inside a
+    captured episode gets a record, and every REPLAY adds exactly one execution with a plausible span.  (2) The packed
+    result record / direct uploads (``use_packed_transfers``) give the bytes of the per-field transfers."""
+    from fgn_amd import ops
+    from fgn_amd.config import fgn_r50_c4_config
+    from fgn_amd.detector import FGN
+    from fgn_amd.episodes import CONFIGS, make_batch
+    from fgn_amd.weights import init_state_dict
+    cfg = fgn_r50_c4_config(3, 1)
+    sd = init_state_dict(cfg, 0)
+    batch = make_batch(5, 1, **CONFIGS['cfg2'])
+    batch = {k: (v.pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    res = {}
+    for packed in (False, True):
+        model = FGN(3, 1, state_dict=sd)
+        model.use_packed_transfers = packed
+        model.use_graphs = True
+        model.transfer_stream(3)
+        model.stamp_capacity = 128
+        out = [model.simple_test(**batch, rescale=True) for _ in range(4)]
+        for o in out[1:]:
+            for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+                assert np.array_equal(o[0][key], out[0][0][key])
+            assert o[0]['dt_isegmaps_rle'] == out[0][0]['dt_isegmaps_rle'] and o[0]['qry_isegmaps_rle'] == out[0][0]['qry_isegmaps_rle']
+        res[packed] = out[0][0]
+        torch.cuda.synchronize()
+        (ge,) = model._graphs.values()
+        assert ge.stamps is not None and 0 < ge.stamp_count <= 128
+        recs = ops.read_stamps(ge.stamps, ge.stamp_count)
+        assert all(r['executions'] == 4 for r in recs), [r['executions'] for r in recs]
+        assert all(0.5 < r['min_us'] <= r['max_us'] < 5000 and r['total_us'] >= 4 * r['min_us'] - 1e-6 for r in recs)
+        ops.reset_stamps(ge.stamps)
+        model.simple_test(**batch, rescale=True)
+        torch.cuda.synchronize()
+        assert all(r['executions'] == 1 for r in ops.read_stamps(ge.stamps, ge.stamp_count))
+    assert len(res[True]['dt_scores']) > 0
+    for key in ('dt_scores', 'dt_bboxes', 'dt_cat_ids'):
+        assert np.array_equal(res[True][key], res[False][key]), key
+    assert res[True]['dt_isegmaps_rle'] == res[False]['dt_isegmaps_rle']
+    assert res[True]['qry_isegmaps_rle'] == res[False]['qry_isegmaps_rle']
