@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 DATASET = {'cfg1': 'MNISTISEG', 'cfg2': 'OMNIISEG', 'cfg3': 'COCO2VOC', 'cfg4': 'COCO2VOC', 'cfg5': 'COCO2VOC'}
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # the same table, "Peak BF16/FP16 MFMA" (dense): 16x the f32-input MFMA
+X3_TERMS = 6                       # bf16 MFMA products conv_pw_x3_kernel issues per f32 product (csrc/conv_pw_x3.h)
 
 
 def algorithmic_gflop(cfg, H, W, S, R, D):
@@ -602,6 +604,8 @@ def main():
         8 TB/s = 19.7 FLOP/B.  A 1x1 convolution with K = 64 writes 4 bytes per 128 FLOP of its row: no MFMA rate
         can make it faster than its output stream."""
         out = {'mfma_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0), 'hbm_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0)}
+        # f32-equivalent MFMA ceiling of the kernel: the f32 pipe, or the bf16 pipe at six products per f32 product
+        peak_eq = PEAK_BF16_MFMA_TFLOPS / X3_TERMS if kernel.startswith('conv_pw_x3_kernel') else PEAK_FP32_MFMA_TFLOPS
         for rec in records:
             if rec['kernel'] != kernel or 'gemm' not in rec:
                 continue
@@ -610,7 +614,7 @@ def main():
             M = rows * n if rec['kind'] == 'conv' else rows
             byts = 4.0 * g * (M * K + N * K + M * N * (2 if rec.get('residual') else 1))
             flop = rec['flop_issued'] * n
-            c = out['mfma_bound' if flop / max(byts, 1.0) >= PEAK_FP32_MFMA_TFLOPS / 8.0 else 'hbm_bound']
+            c = out['mfma_bound' if flop / max(byts, 1.0) >= peak_eq / 8.0 else 'hbm_bound']
             c['launches'] += 1
             c['ms'] += rec['e0'].elapsed_time(rec['e1'])
             c['flop'] += flop
@@ -619,7 +623,7 @@ def main():
         for k, c in out.items():
             if c['launches']:
                 res[k] = {'launches': c['launches'], 'ms': round(c['ms'], 3), 'tflops': round(c['flop'] / c['ms'] / 1e9, 1),
-                          'frac_of_mfma_peak': round(c['flop'] / c['ms'] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          'frac_of_mfma_peak': round(c['flop'] / c['ms'] / 1e9 / peak_eq, 4),
                           'algorithmic_tb_per_s': round(c['bytes'] / c['ms'] / 1e9, 2),
                           'frac_of_hbm_peak': round(c['bytes'] / c['ms'] / 1e9 / 8.0, 4)}
         return res
@@ -638,17 +642,21 @@ def main():
                issued=sum(k['issued'] for k in by_kernel.values()), direct=sum(k['direct'] for k in by_kernel.values()))
     dom = by_kernel.get(dom_name, dict(ms=0.0, launches=0, issued=0.0, direct=0.0))
     tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    achieved = tf(dom['issued'], dom['ms'])
+    # conv_pw_x3_kernel issues X3_TERMS bf16 MFMA products per f32 product of its GEMM: its roofline is the bf16 pipe,
+    # `achieved` the bf16 MFMA FLOPs it issued per second; the f32 products per second are reported beside it
+    dom_x3 = dom_name.startswith('conv_pw_x3_kernel')
+    dom_terms, dom_peak = (X3_TERMS, PEAK_BF16_MFMA_TFLOPS) if dom_x3 else (1, PEAK_FP32_MFMA_TFLOPS)
+    achieved = tf(dom['issued'], dom['ms']) * dom_terms
     iso_table = [dict(step=i, kernel_ms=round(iso[i][dom_name]['ms'], 4), launches=iso[i][dom_name]['launches'],
                       avg_launch_us=round(iso[i][dom_name]['ms'] * 1e3 / max(iso[i][dom_name]['launches'], 1), 2),
-                      frac=round(tf(iso[i][dom_name]['issued'], iso[i][dom_name]['ms']) / PEAK_FP32_MFMA_TFLOPS, 4),
+                      frac=round(tf(iso[i][dom_name]['issued'], iso[i][dom_name]['ms']) * dom_terms / dom_peak, 4),
                       all_conv_ms=round(sum(k['ms'] for k in iso[i].values()), 3))
                  for i in sorted(iso) if dom_name in iso[i]]
 
     # ---- the dominant kernel over the WHOLE timed window: the launch records inside the captured graphs --------------
     window = None
     sites = [rec for rec in records_med if rec['kernel'] == dom_name]
-    if model.use_graphs and sites and dom_name == 'conv_pw_persist_kernel':
+    if model.use_graphs and sites and (dom_name == 'conv_pw_persist_kernel' or dom_x3):
         per_site = [dict(executions=0, total_us=0.0, min_us=None, max_us=None) for _ in sites]
         # (a graph whose captured launch sequence does not have the isolated step's launch sites cannot be matched)
         ok = bool(graphs) and all(ge.stamps is not None and ge.stamp_count == len(sites) for ge in graphs)
@@ -676,8 +684,8 @@ def main():
                       'launches': n_exec, 'launch_sites_per_step': len(sites),
                       'executions_per_site': sorted({a['executions'] for a in per_site}),
                       'avg_launch_us': round(w_us / n_exec, 2),
-                      'achieved': round(w_flop / w_us / 1e6, 2),
-                      'frac': round(w_flop / w_us / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
+                      'achieved': round(w_flop / w_us / 1e6 * dom_terms, 2),
+                      'frac': round(w_flop / w_us / 1e6 * dom_terms / dom_peak, 4),
                       'site_us_over_isolated_event_us': ({'p10': round(ratios[len(ratios) // 10], 3), 'p50': round(ratios[len(ratios) // 2], 3),
                                                           'p90': round(ratios[(len(ratios) * 9) // 10], 3)} if ratios else None),
                       'largest_site': (lambda k: {'avg_us': round(per_site[k]['total_us'] / per_site[k]['executions'], 1),
@@ -717,6 +725,10 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
+            # operands, accumulation, epilogues and results are f32 in both settings; 'x3' computes the GEMM-shaped launches'
+            # products as six bf16 MFMA products of exact three-way splits (same error against fp64 as the f32 MFMA kernels:
+            # tests/test_hip_conv.py::test_x3_*), 'f32' (FGN_GEMM_MATH=f32) on the f32-input MFMA
+            'gemm_math': ops.GEMM_MATH,
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {DATASET.get(args.workload, "synthetic")} {shape["n_ways"]}-way {shape["k_shots"]}-shot, '
                                    f'query 3x{shape["height"]}x{shape["width"]}, supports '
@@ -764,9 +776,16 @@ def main():
             # frac = MFMA FLOPs the dominant kernel actually ISSUED / its summed HIP-event launch durations / peak.
             # Reproducible from profiles/rNN_kernel_stats.csv: flop_per_step * steps / TotalDurationNs of `kernel`.
             'roofline': {'bound': 'mfma', 'kernel': dom_name,
-                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'achieved': round(achieved, 2), 'peak': dom_peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / dom_peak, 4),
                          'traffic': traffic,
+                         'mfma': ('v_mfma_f32_32x32x16_bf16: %d bf16 products per f32 product of the GEMM (exact 3-way splits of '
+                                  'both f32 operands, f32 accumulation); achieved / peak are bf16 MFMA FLOP/s' % X3_TERMS) if dom_x3
+                                 else 'v_mfma_f32_16x16x4_f32 (f32 operands)',
+                         # the GEMM's own (f32) products per second, and against the f32-input MFMA peak this kernel no
+                         # longer runs on - above 1.0 means faster than any f32-MFMA kernel could be
+                         'f32_equivalent_tflops': round(achieved / dom_terms, 2),
+                         'f32_equivalent_over_f32_mfma_peak': round(achieved / dom_terms / PEAK_FP32_MFMA_TFLOPS, 4),
                          'flop_per_step': round(dom['issued'] / n_prof_steps),
                          'launches_per_step': dom['launches'] / n_prof_steps,
                          'avg_launch_us': round(dom['ms'] * 1e3 / max(dom['launches'], 1), 2),
@@ -790,7 +809,7 @@ def main():
                          'overlapped': (lambda k: None if not k or not k['ms'] else {
                              'avg_launch_us': round(k['ms'] * 1e3 / max(k['launches'], 1), 2),
                              'achieved': round(tf(k['issued'], k['ms']), 2),
-                             'frac': round(tf(k['issued'], k['ms']) / PEAK_FP32_MFMA_TFLOPS, 4),
+                             'frac': round(tf(k['issued'], k['ms']) * dom_terms / dom_peak, 4),
                              'all_conv_ms_per_step': round(sum(v['ms'] for v in by_kernel_overlapped.values()), 3),
                              'measured_in': 'a warm-up step with steps queued before and behind it' if overlapped_in_warmup else 'a mid-run timed step',
                              'what': 'per-launch durations while another episode runs on the second caller stream: '
@@ -944,7 +963,10 @@ def trained_heads_leg(args, cfg, sd, batches) -> dict:
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t0
     sd2 = tr.state_dict()
-    m.load_state_dict(sd2)
+    del tr, m
+    # a model of its own for the scoring: packed without a live Trainer, i.e. with the build's default GEMM arithmetic
+    m = FGN(n_ways, k_shots, backbone=cfg['backbone'], rpn_head=cfg['rpn_head'], roi_head=cfg['roi_head'],
+            test_cfg=cfg['test_cfg'], state_dict=sd2)
     ev_b = train_b[:max(1, args.trained_eval_episodes)]
     hip_res, cpu_res, maxima = [], [], []
     for j, b in enumerate(ev_b):

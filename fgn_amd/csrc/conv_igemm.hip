@@ -1471,12 +1471,12 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
 // ------------------------------------------------------------------------------------------------
 static int x3_pick_bm(long long M, int Cout, int grp_rows, int bm) {
     if (bm == 64 || bm == 128) return (grp_rows && grp_rows % bm) ? 0 : bm;
-    const long long t128 = ((M + 127) / 128) * cdiv(Cout, X3_BN);
-    if (t128 >= 448 && (!grp_rows || grp_rows % 128 == 0)) return 128;
+    // (measured, r05 call 10: 128 rows x 3 stages at one workgroup per CU is 4-25 % slower than 64 rows x 2 stages at two
+    // on every GEMM of a cfg3 episode - its eight waves run their phases in lockstep: tools/x3_probe.py --phases)
     return (grp_rows && grp_rows % 64) ? 0 : 64;
 }
 
-template <int WMW, int NT>
+template <int WMW, int NT, int NST>
 static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     constexpr int BM = 32 * WMW;
     const int m_tiles = cdiv(M_max, BM);
@@ -1492,28 +1492,39 @@ static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     }
     const int tiles = m_tiles * p.n_tiles_n;
     static unsigned long long ok = 0ull;
-    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_x3_kernel<WMW, NT>), &ok);
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_x3_kernel<WMW, NT, NST>), &ok);
     if (attr != hipSuccess) return (int)attr;
-    const size_t lds = (size_t)2 * (BM * 128 + X3_B_STAGE);
-    const int grid = std::min(512, (tiles + 7) / 8 * 8);
+    const size_t lds = (size_t)NST * (BM * 128 + X3_B_STAGE);
+    const int per_cu = (int)(160 * 1024 / lds);                       // resident workgroups per CU (LDS-bound)
+    const int grid = std::min(256 * per_cu, (tiles + 7) / 8 * 8);
     p.stamp = fgn_next_stamp_record();
-    FGN_LAUNCH_TIMED((conv_pw_x3_kernel<WMW, NT>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
+    FGN_LAUNCH_TIMED((conv_pw_x3_kernel<WMW, NT, NST>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
 
 static int launch_x3(const ConvParams& p0, int M_max, int bm, int nterms, hipStream_t stream) {
     ConvParams p = p0;
-    if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.splits != 1) return FGN_ERR_SHAPE;
+    if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
     p.n_tiles_n = cdiv(p.Cout, X3_BN);
     const int BM = x3_pick_bm(M_max, p.Cout, p.grp_rows, bm);
     if (BM == 0) return FGN_ERR_SHAPE;
     if (nterms == 9)
-        return BM == 128 ? launch_x3_cfg<4, 9>(p, M_max, stream) : launch_x3_cfg<2, 9>(p, M_max, stream);
-    return BM == 128 ? launch_x3_cfg<4, 6>(p, M_max, stream) : launch_x3_cfg<2, 6>(p, M_max, stream);
+        return BM == 128 ? launch_x3_cfg<4, 9, 3>(p, M_max, stream) : launch_x3_cfg<2, 9, 2>(p, M_max, stream);
+    return BM == 128 ? launch_x3_cfg<4, 6, 3>(p, M_max, stream) : launch_x3_cfg<2, 6, 2>(p, M_max, stream);
 }
 
 extern "C" size_t fgn_x3_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * K * npad * 6; }
+
+#ifdef X3_PHASES        // tools/micro/build_x3_phases.sh: phase clocks of wave 0 of workgroups 0 / 1 (conv_pw_x3.h)
+static unsigned long long* g_x3_ph = nullptr;
+extern "C" int fgn_x3_phases(unsigned long long* host16) {
+    if (!g_x3_ph) return FGN_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return FGN_ERR_ARG;
+    if (hipMemcpy(host16, g_x3_ph, 128, hipMemcpyDeviceToHost) != hipSuccess) return FGN_ERR_ARG;
+    return hipMemset(g_x3_ph, 0, 128) == hipSuccess ? FGN_OK : FGN_ERR_ARG;
+}
+#endif
 
 // y[rows, Cout] = relu?(x[rows, K] * W^T + shift + residual) with W given as its bf16-plane image (ops.pack_x3);
 // grouped: rows = n_groups * grp_rows, group g uses image g and computes its first grp_valid rows.  The direct entry
@@ -1541,7 +1552,87 @@ extern "C" int fgn_gemm_x3_f32(const float* x, const void* w3, float* y, const f
     p.grp_w_stride = 0; p.grp_count_dev = nullptr;
     p.band_nt = 0; p.band_mt = 0; p.n_tiles_n = 0;
     p.w3 = w3; p.w3_bytes = (unsigned)wb; p.npad3 = npad;
+#ifdef X3_PHASES
+    if (!g_x3_ph && (hipMalloc(&g_x3_ph, 128) != hipSuccess || hipMemset(g_x3_ph, 0, 128) != hipSuccess)) return FGN_ERR_ARG;
+    p.ws = reinterpret_cast<float*>(g_x3_ph);
+#endif
     return launch_x3(p, rows, bm, nterms, stream);
+}
+
+// The three GEMM-shaped entry points of the detector on conv_pw_x3_kernel.  Arguments as their f32-MFMA counterparts
+// (fgn_conv2d_nhwc_f32 for a 1x1 / stride 1 / unpadded convolution, fgn_conv1x1_dual_nhwc_f32, fgn_winograd_gemm_f32),
+// with the weights given as the bf16-plane image of ops.pack_x3 ([groups][K / 32][3][cout_pad][32] bf16) instead of
+// [cout_pad][K] floats.  Results: the same f32 values to within the rounding of an f32 accumulation (conv_pw_x3.h).
+static void x3_base_params(ConvParams& p) {
+    p.w = nullptr; p.scale = nullptr; p.shift = nullptr; p.residual = nullptr; p.in_scale = nullptr; p.n_img_dev = nullptr;
+    p.stamp = nullptr; p.x2 = nullptr; p.x2_bytes = 0; p.kt1 = 0; p.cin2 = 0; p.x2_rows = nullptr;
+#ifdef FGN_EXPERIMENTS
+    p.tickets = nullptr; p.sched = nullptr; p.sk_U = 0; p.sk_dp = 0;
+#endif
+    p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.a_img_div = 1; p.relu = 0;
+    p.ws = nullptr; p.splits = 1; p.w_bytes = 0;
+    p.grp_rows = 0; p.grp_valid = 0; p.grp_items = 0; p.grp_rows_per_item = 0; p.grp_w_stride = 0; p.grp_count_dev = nullptr;
+    p.band_nt = 0; p.band_mt = 0; p.n_tiles_n = 0;
+}
+
+extern "C" int fgn_conv1x1_x3_nhwc_f32(const float* x, const void* w_x3, float* y, const float* scale, const float* shift,
+                                       const float* residual, const int32_t* n_img_dev, int n_img, int H, int W, int Cin,
+                                       int Cout, int cout_pad, int relu, hipStream_t stream) {
+    if (!x || !w_x3 || !y) return FGN_ERR_ARG;
+    if (n_img <= 0) return FGN_OK;
+    if (Cin % BK || Cin < 2 * BK || (Cout & 3) || cout_pad % X3_BN || cout_pad < Cout || H <= 0 || W <= 0) return FGN_ERR_SHAPE;
+    const long long M = (long long)n_img * H * W;
+    const long long xb = M * Cin * 4, wb = (long long)fgn_x3_image_bytes(Cin, cout_pad, 1);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || M * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = x; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual; p.n_img_dev = n_img_dev;
+    p.n_img = n_img; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.K = Cin;
+    p.kt_per_split = Cin / BK; p.x_bytes = (unsigned)xb;
+    p.w3 = w_x3; p.w3_bytes = (unsigned)wb; p.npad3 = cout_pad;
+    return launch_x3(p, (int)M, 0, 6, stream);
+}
+
+extern "C" int fgn_conv1x1_dual_x3_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                                            const void* w_x3, float* y, const float* shift, int rows, int Cin1, int Cin2,
+                                            int Cout, int cout_pad, int relu, hipStream_t stream) {
+    if (!x || !x2 || !w_x3 || !y) return FGN_ERR_ARG;
+    if (rows <= 0) return FGN_OK;
+    if (Cin1 % BK || Cin2 % BK || Cin1 <= 0 || Cin2 <= 0 || (Cout & 3) || cout_pad % X3_BN || cout_pad < Cout) return FGN_ERR_SHAPE;
+    if ((!x2_rows && x2_total_rows != rows) || x2_total_rows < 1) return FGN_ERR_ARG;
+    const int K = Cin1 + Cin2;
+    const long long xb = (long long)rows * Cin1 * 4, x2b = (long long)x2_total_rows * Cin2 * 4;
+    const long long wb = (long long)fgn_x3_image_bytes(K, cout_pad, 1);
+    if (xb >= 0x7fffff00ll || x2b >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = x; p.y = y; p.shift = shift;
+    p.x2 = x2; p.x2_bytes = (unsigned)x2b; p.kt1 = Cin1 / BK; p.cin2 = Cin2; p.x2_rows = x2_rows;
+    p.n_img = rows; p.Cin = Cin1; p.Cout = Cout; p.relu = relu; p.K = K;
+    p.kt_per_split = K / BK; p.x_bytes = (unsigned)xb;
+    p.w3 = w_x3; p.w3_bytes = (unsigned)wb; p.npad3 = cout_pad;
+    return launch_x3(p, rows, 0, 6, stream);
+}
+
+extern "C" int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const int32_t* n_img_dev, int n_img,
+                                        int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
+                                        hipStream_t stream) {
+    if (!V || !U_x3 || !Mo) return FGN_ERR_ARG;
+    if (n_img <= 0) return FGN_OK;
+    if (Cin % BK != 0 || Cin < 2 * BK || Cout % 4 != 0 || cout_pad % X3_BN != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
+        (n_groups != 16 && n_groups != 36) || (long long)n_img * tiles_per_img > t_pad)
+        return FGN_ERR_SHAPE;
+    const long long rows = (long long)n_groups * t_pad;
+    const long long xb = rows * Cin * 4, wb = (long long)fgn_x3_image_bytes(Cin, cout_pad, n_groups);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = V; p.y = Mo;
+    p.n_img = (int)rows; p.Cin = Cin; p.Cout = Cout; p.K = Cin; p.kt_per_split = Cin / BK; p.x_bytes = (unsigned)xb;
+    p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
+    p.grp_rows_per_item = tiles_per_img; p.grp_count_dev = n_img_dev;
+    p.w3 = U_x3; p.w3_bytes = (unsigned)wb; p.npad3 = cout_pad;
+    return launch_x3(p, (int)rows, 0, 6, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

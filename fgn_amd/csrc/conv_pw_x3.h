@@ -21,8 +21,13 @@
 // Tile: BM = 32 * WMW rows x 128 columns, 64 * 2 * WMW threads, wave tile 32 x 64 as two v_mfma_f32_32x32x16_bf16
 // blocks.  An output tile of 128 x 128 moves 0.078 B / MAC through L2 -> LDS against 0.125 for the 64 x 64 f32 tile:
 // at twice the MAC rate ~10 TB/s of L2 -> LDS traffic, which the XCD L2s deliver (17-19 TB/s measured by the guide).
-// LDS: 2 stages x (BM * 128 + 24576) bytes; the C tile of the epilogue (64 rows x 128 floats per pass) lives in stage 1
-// while stage 0 receives the first K-tile of the next output tile, as in conv_pw_persist_kernel.
+// LDS: NST stages x (BM * 128 + 24576) bytes in a ring that runs ACROSS output tiles: K-tile g of the workgroup's
+// sequence lives in stage g % NST, the LDS-DMA of K-tile g + NST - 1 (of this output tile or the next one) is issued
+// right after the barrier that ends the reads of K-tile g - 1, and is waited for with a counted vmcnt.  At 6/16 of
+// the f32 pipe's time per K-tile the L2 latency no longer hides behind ONE K-tile of compute (first form, 2 stages x
+// 2 workgroups per CU: 1.25-1.4x the f32 kernel; a 40 KB K-tile is multiplied in 0.64 us): BM = 128 runs 3 stages,
+// one 512-thread workgroup per CU.  The C tile of the epilogue (64 rows x 128 floats per pass) goes through the stage
+// the last K-tile was read from.
 #pragma once
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -55,13 +60,26 @@ __device__ __forceinline__ X3Frag x3_split(const float4& lo, const float4& hi) {
 constexpr int X3_BN = 128;
 constexpr int X3_B_STAGE = 3 * X3_BN * 64;       // bytes of one K-tile of the weight image for 128 columns
 
-template <int WMW, int NT>
-__global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kernel(const ConvParams p, const int total_tiles) {
+// phase clocks of one wave (tools/x3_probe.py --phases; -DX3_PHASES): cycles in [wait + barrier | issue | LDS reads
+// landed | split + MFMA | epilogue], written by wave 0 of workgroups 0 and 1 to p.ws
+#ifdef X3_PHASES
+#define X3_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define X3_T(i) do { } while (0)
+#endif
+
+template <int N> __device__ __forceinline__ void x3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WMW, int NT, int NST>
+__global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvParams p, const int total_tiles) {
     constexpr int BM = 32 * WMW, BN = X3_BN, NTHR = 128 * WMW, NW = 2 * WMW;
     constexpr int A_STAGE = BM * 128;                       // bytes
     constexpr int STAGE = A_STAGE + X3_B_STAGE;             // bytes
     constexpr int B_LD = 24 / NW;                           // weight wave-instructions per wave per K-tile
+    constexpr int PER = 2 + B_LD;                           // LDS-DMA wave-instructions per wave per K-tile
+    constexpr int D = NST - 1;                              // K-tiles in flight ahead of the one being multiplied
     constexpr int ROWS_PER_PASS = NTHR / 8;                 // A rows one pass of the workgroup's DMAs covers
+    static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
     const i32x4 w_rs = make_rsrc(p.w3, p.w3_bytes);
     const bool dual = p.x2 != nullptr;
     const i32x4 x2_rs = make_rsrc(dual ? p.x2 : p.x, dual ? p.x2_bytes : p.x_bytes);
-    const int KT = p.K / BK;
+    const int KT = p.K / BK;                                                  // >= D (checked by the launcher)
     const unsigned kt_bytes = (unsigned)(3 * p.npad3 * 64);          // one K-tile of the image, all planes, all rows
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem_x3));
     const unsigned wave_row_bytes = __builtin_amdgcn_readfirstlane(wv) * 8 * 128;
@@ -111,22 +129,21 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
         return -1;
     };
 
-    unsigned a_voff[2], a2_voff[2], b_voff[B_LD];
+    struct Offs { unsigned a[2], a2[2], b[B_LD]; };
     unsigned b_lds[B_LD];
-    {
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int q = wv + NW * i;                     // wave-instruction q of 24: plane q / 8, rows 16 * (q % 8) ..
-            b_lds[i] = __builtin_amdgcn_readfirstlane((unsigned)(A_STAGE + (q >> 3) * (BN * 64) + (q & 7) * 1024));
-        }
+    for (int i = 0; i < B_LD; ++i) {
+        const int q = wv + NW * i;                     // wave-instruction q of 24: plane q / 8, rows 16 * (q % 8) ..
+        b_lds[i] = __builtin_amdgcn_readfirstlane((unsigned)(A_STAGE + (q >> 3) * (BN * 64) + (q & 7) * 1024));
     }
-    auto set_offsets = [&](int m0, int n0) {
+    auto offsets = [&](int m0, int n0) -> Offs {
+        Offs o;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + row0 + ROWS_PER_PASS * i;
-            a_voff[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
-            a2_voff[i] = OOB;
-            if (dual && m < M) a2_voff[i] = (unsigned)(((p.x2_rows ? p.x2_rows[m] : m) * p.cin2 + src_c4 * 4) * 4);
+            o.a[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
+            o.a2[i] = OOB;
+            if (dual && m < M) o.a2[i] = (unsigned)(((p.x2_rows ? p.x2_rows[m] : m) * p.cin2 + src_c4 * 4) * 4);
         }
         unsigned g0 = 0;
         if (p.grp_rows) g0 = (unsigned)(m0 / p.grp_rows) * (unsigned)KT * kt_bytes;
@@ -134,39 +151,43 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
         for (int i = 0; i < B_LD; ++i) {
             const int q = wv + NW * i;
             const int plane = q >> 3, row = (q & 7) * 16 + (lane >> 2);
-            b_voff[i] = g0 + (unsigned)(((plane * p.npad3 + n0 + row) * 4 + (lane & 3)) * 16);
+            o.b[i] = g0 + (unsigned)(((plane * p.npad3 + n0 + row) * 4 + (lane & 3)) * 16);
         }
+        return o;
     };
-    auto issue_tile = [&](int kt, int stage) {
+    auto issue = [&](const Offs& o, int kt, int stage) {
         const unsigned st = lds_base + stage * STAGE;
         const unsigned sa = st + wave_row_bytes;
         const unsigned ko = (unsigned)(kt * BK * 4);
         if (dual && kt >= p.kt1) {
             const unsigned ko2 = (unsigned)((kt - p.kt1) * BK * 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, a2_voff[i], ko2);
+            for (int i = 0; i < 2; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, o.a2[i], ko2);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, a_voff[i], ko);
+            for (int i = 0; i < 2; ++i) lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, o.a[i], ko);
         }
         const unsigned kb = (unsigned)kt * kt_bytes;
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, st + b_lds[i], b_voff[i], kb);
+        for (int i = 0; i < B_LD; ++i) lds_dma16_s(w_rs, st + b_lds[i], o.b[i], kb);
     };
 
     // fragment addresses (bytes within a stage).  32x32x16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h + 7
     const int r32 = lane & 31, h = lane >> 5;
     const int a_row = wm * 32 + r32;
     const unsigned a_sw = (unsigned)((a_row >> 1) & 7);
-    const unsigned a_rd = (unsigned)(a_row * 128);
-    unsigned b_rd[2], b_sw[2];
+    unsigned a_rd[2][2], b_rd[2][2];              // [sub-step][chunk] / [sub-step][column block], swizzle applied
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = wn * 64 + 32 * j + r32;
-        b_rd[j] = (unsigned)(A_STAGE + n * 64);
-        b_sw[j] = (unsigned)((n >> 2) & 3);
+    for (int s = 0; s < 2; ++s) {
+        const unsigned ca = (unsigned)(4 * s + 2 * h);
+        a_rd[s][0] = (unsigned)(a_row * 128) + ((ca ^ a_sw) << 4);
+        a_rd[s][1] = (unsigned)(a_row * 128) + (((ca + 1) ^ a_sw) << 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = wn * 64 + 32 * j + r32;
+            b_rd[s][j] = (unsigned)(A_STAGE + n * 64) + ((((unsigned)(2 * s + h)) ^ (unsigned)((n >> 2) & 3)) << 4);
+        }
     }
-    float* const cbase = reinterpret_cast<float*>(smem_x3 + STAGE);          // stage 1
 
     if (p.stamp && t == 0 && blockIdx.x == 0) atomicExch(p.stamp, __builtin_amdgcn_s_memrealtime());
     auto leave = [&]() {
@@ -185,11 +206,36 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
         atomicMin(p.stamp + 4, d);
         atomicMax(p.stamp + 5, d);
     };
-    int m0, n0;
+
+    int m0, n0, nm0 = 0, nn0 = 0;
     int tile = next_active(blockIdx.x, m0, n0);
     if (tile < 0) { leave(); return; }
-    set_offsets(m0, n0);
-    issue_tile(0, 0);
+    Offs cur = offsets(m0, n0);
+    int ntile = next_active(tile + gridDim.x, nm0, nn0);
+    Offs nxt = cur;
+    if (ntile >= 0) nxt = offsets(nm0, nn0);
+    // issue cursor: the next K-tile to be requested is K-tile ic_kt of the current (ic_next = false) or the next output tile
+    int ic_kt = 0, ic_stage = 0, ahead = 0;
+    bool ic_next = false;
+    auto issue_one = [&]() {
+        if (!ic_next) {
+            issue(cur, ic_kt, ic_stage);
+            if (++ic_kt == KT) { ic_next = true; ic_kt = 0; }
+        } else {
+            if (ntile < 0 || ic_kt >= KT) return;
+            issue(nxt, ic_kt, ic_stage);
+            ++ic_kt;
+        }
+        ic_stage = ic_stage + 1 == NST ? 0 : ic_stage + 1;
+        ++ahead;
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) issue_one();
+    int stage = 0;                                  // stage of the K-tile being multiplied
+#ifdef X3_PHASES
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long begin_ = last_;
+#endif
 
     while (true) {
         f32x16 acc[2];
@@ -197,57 +243,67 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue_tile(kt + 1, cur ^ 1);
+            // K-tile `kt` has landed: everything (first K-tile of an output tile: the previous epilogue's stores share
+            // the counter and return in no fixed order with the loads), or all but the K-tile requested after it
+            if (D == 2 && kt > 0 && ahead == 2) x3_wait_vm<PER>(); else x3_wait_vm<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // ... for every wave; and every wave is done with the stage before
+            X3_T(0);
+            --ahead;
+            issue_one();
             asm volatile("" ::: "memory");
-            const unsigned char* const S = smem_x3 + cur * STAGE;
+            X3_T(1);
+            const unsigned char* const S = smem_x3 + stage * STAGE;
+            float4 alo[2], ahi[2];
+            bf16x8_t bq[2][2][3];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const unsigned ca = (unsigned)(4 * s + 2 * h);
-                const float4 alo = *reinterpret_cast<const float4*>(S + a_rd + ((ca ^ a_sw) << 4));
-                const float4 ahi = *reinterpret_cast<const float4*>(S + a_rd + (((ca + 1) ^ a_sw) << 4));
-                bf16x8_t b1[2], b2[2], b3[2];
+                alo[s] = *reinterpret_cast<const float4*>(S + a_rd[s][0]);
+                ahi[s] = *reinterpret_cast<const float4*>(S + a_rd[s][1]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned off = b_rd[j] + ((((unsigned)(2 * s + h)) ^ b_sw[j]) << 4);
-                    b1[j] = *reinterpret_cast<const bf16x8_t*>(S + off);
-                    b2[j] = *reinterpret_cast<const bf16x8_t*>(S + off + BN * 64);
-                    b3[j] = *reinterpret_cast<const bf16x8_t*>(S + off + 2 * BN * 64);
-                }
-                const X3Frag a = x3_split(alo, ahi);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bq[s][j][q] = *reinterpret_cast<const bf16x8_t*>(S + b_rd[s][j] + q * (BN * 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);       // all 16 reads of the K-tile in flight before the first split
+#ifdef X3_PHASES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            X3_T(2);
+#endif
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const X3Frag a = x3_split(alo[s], ahi[s]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (NT == 9) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b3[j], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b2[j], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b3[j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][2], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][1], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][2], acc[j], 0, 0, 0);
                     }
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b1[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b3[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b2[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b1[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b2[j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b1[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][0], acc[j], 0, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
+            stage = stage + 1 == NST ? 0 : stage + 1;
+#ifdef X3_PHASES
+            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
+            X3_T(3);
+            ++ph_[5];
+#endif
         }
+        // the stage of the last K-tile (the one before `stage` in the ring) takes the C tile once every wave has read it
+        float* const cbase = reinterpret_cast<float*>(smem_x3 + (stage == 0 ? NST - 1 : stage - 1) * STAGE);
         const int em0 = m0, en0 = n0;
-        int nm0 = 0, nn0 = 0;
-        const int next = next_active(tile + gridDim.x, nm0, nn0);
-        if (next >= 0) {
-            set_offsets(nm0, nn0);
-            issue_tile(0, 0);
-        }
         // 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 64 rows per pass
 #pragma unroll
         for (int pass = 0; pass < WMW / 2; ++pass) {
-            if (pass) __syncthreads();
+            __syncthreads();
             if ((wm >> 1) == pass) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -289,9 +345,23 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 4 : 2)) void conv_pw_x3_kern
                 }
             }
         }
-        if (next < 0) break;
-        tile = next; m0 = nm0; n0 = nn0;
+        X3_T(4);
+        if (ntile < 0) break;
+        // the next output tile becomes the current one (its first K-tiles are requested already: ic_kt of them)
+        tile = ntile; m0 = nm0; n0 = nn0;
+        cur = nxt;
+        ic_next = ic_kt >= KT;                       // (KT == D: the whole new current tile is requested already)
+        if (ic_next) ic_kt = 0;
+        ntile = next_active(tile + gridDim.x, nm0, nn0);
+        if (ntile >= 0) nxt = offsets(nm0, nn0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef X3_PHASES
+    if (p.ws && lane == 0 && wv == 0 && blockIdx.x < 2) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + 8 * blockIdx.x;
+        for (int i = 0; i < 6; ++i) o[i] = ph_[i];
+        o[6] = __builtin_amdgcn_s_memtime() - begin_;
+    }
+#endif
     leave();
 }

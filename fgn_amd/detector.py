@@ -653,7 +653,20 @@ class FGN(torch.nn.Module):
         if self._trainer_alive() is not None:      # the train-mode layers follow the same weights
             self._PT = None
 
+    def _head_math(self):
+        """Arithmetic of the trainable layers' GEMMs: f32 MFMA while a Trainer rewrites their weights every step
+        (``ops.gemm_math``), the build's default otherwise."""
+        return 'f32' if self._trainer_alive() is not None else None
+
     def _pack_shared(self, sd) -> dict:
+        with ops.gemm_math(self._head_math()):
+            return self._pack_shared_impl(sd)
+
+    def _pack_heads(self, sd) -> dict:
+        with ops.gemm_math(self._head_math()):
+            return self._pack_heads_impl(sd)
+
+    def _pack_shared_impl(self, sd) -> dict:
         """The shared head for INFERENCE (BatchNorm in eval mode, folded into the conv epilogues) from torch-layout
         weights and running statistics ``sd`` (CPU state dict, or a Trainer's device-resident masters + buffers)."""
         cfg = self.cfg
@@ -665,12 +678,13 @@ class FGN(torch.nn.Module):
         # (RoIAlign commutes with it); the shift is added after the pooling
         c1 = P['shared'][0].conv1
         P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
-                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False) \
+                                     c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False,
+                                     None if c1.w3 is None else c1.w3.clone()) \
             if self.use_roi_commute else None
         P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
         return P
 
-    def _pack_heads(self, sd) -> dict:
+    def _pack_heads_impl(self, sd) -> dict:
         """The packed AG-RPN / relation / box / mask head layers from torch-layout weights ``sd`` (CPU tensors of the
         state dict, or the device-resident master weights of ``fgn_amd.train.Trainer``: packing is torch ops only)."""
         cfg = self.cfg

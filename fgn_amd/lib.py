@@ -57,6 +57,11 @@ SIGNATURES = {
     'fgn_rpn_proposals_f32': (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f),
                                             _f, _i, _f, _f, _i, _p]),
     'fgn_conv1x1_dual_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_x3_image_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_conv1x1_x3_nhwc_f32': (_i, [_p] * 7 + [_i] * 7 + [_p]),
+    'fgn_conv1x1_dual_x3_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd_gemm_x3_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_gemm_x3_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_conv2d_pair_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p] + [_i] * 8 + [_p]),
     'fgn_det_post_scratch_bytes': (C.c_size_t, [_i, _i]),
     'fgn_det_post_f32': (_i, [_p] * 7 + [_i] + [_p] * 3 + [_i, _i, _i, _f, _f, C.POINTER(_f), C.POINTER(_f), _f, _f, _f, _i, _p]),
@@ -93,7 +98,7 @@ SIGNATURES = {
     'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 _lib = None
 
 

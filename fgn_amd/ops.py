@@ -31,6 +31,32 @@ PROFILE = None
 STEM_POOL_FUSION = os.environ.get('FGN_STEM_POOL', '0') != '0'
 # conv3 + shortcut conv of the first block of a stride-1 stage as one dual-operand K loop (conv1x1_dual).  A/B knob.
 FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
+# Arithmetic of the GEMM-shaped launches (1x1 / stride 1 convolutions, the fused conv3 + shortcut, the Winograd GEMMs):
+# 'x3' = conv_pw_x3_kernel, every f32 product as six bf16 MFMA products of exact three-way splits, f32 accumulation
+# (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels.
+GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'x3')
+X3_KERNEL = 'conv_pw_x3_kernel<2, 6, 2>'
+
+
+class gemm_math:
+    """``with ops.gemm_math('f32'):`` - the layers PACKED inside use that arithmetic (None: no change).  Training packs its
+    head layers under 'f32': the optimizer rewrites their weights in place every step and a bf16-plane image would have to
+    be re-derived each time."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global GEMM_MATH
+        self.prev = GEMM_MATH
+        if self.mode is not None:
+            GEMM_MATH = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_MATH
+        GEMM_MATH = self.prev
+        return False
 FUSED_SHORTCUT_STRIDES = tuple(int(v) for v in os.environ.get('FGN_FUSED_SHORTCUT_STRIDES', '1,2').split(','))
 
 _TILES = {1: (128, 128, 64, 64, 2), 2: (64, 128, 32, 64, 3), 3: (128, 64, 64, 32, 3), 4: (64, 64, 32, 32, 4)}
@@ -219,12 +245,18 @@ class ConvLayer:
     stride: int
     pad: int
     relu: bool
+    w3: Optional[torch.Tensor] = None      # bf16-plane image of w (pack_x3) for conv_pw_x3_kernel, or None
 
     def to(self, device):
         self.w = self.w.to(device)
         self.scale = None if self.scale is None else self.scale.to(device)
         self.shift = None if self.shift is None else self.shift.to(device)
+        self.w3 = None if self.w3 is None else self.w3.to(device)
         return self
+
+
+def _x3_ok(cin: int, cout: int) -> bool:
+    return GEMM_MATH == 'x3' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -259,9 +291,10 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Opt
             shift = shift + bias.float() * scale
     elif bias is not None:
         shift = bias.detach().float().clone()
+    w3 = pack_x3(w) if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and _x3_ok(cin, cout)) else None
     return ConvLayer(w.contiguous(), None if scale is None else scale.contiguous(),
                      None if shift is None else shift.contiguous(), cin, cout, cout_pad, kh, kw,
-                     stride, pad, relu)
+                     stride, pad, relu, w3)
 
 
 def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] = None,
@@ -299,6 +332,17 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
+    if layer.w3 is not None and in_scale is None and a_img_div == 1 and tile_hint == 0:
+        rc = L.fgn_conv1x1_x3_nhwc_f32(_ptr(x), layer.w3.data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
+                                       _ptr(residual), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad,
+                                       int(layer.relu), _stream())
+        _lib.check(rc, 'fgn_conv1x1_x3_nhwc_f32')
+        if prof is not None:
+            flop = 2.0 * ho * wo * layer.cout * cin
+            prof.append(dict(kind='conv', kernel=X3_KERNEL, math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+                             n_img=n_img, n_img_dev=n_img_dev, gemm=(1, ho * wo, layer.cout, cin),
+                             residual=residual is not None, shape=(n_img, H, W, cin, layer.cout, 1, 1)))
+        return out
     ws_bytes = L.fgn_conv2d_workspace_bytes(n_img, H, W, cin, layer.cout, layer.kh, layer.kw, layer.stride,
                                             layer.pad, tile_hint)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8) if ws_bytes else None
@@ -320,6 +364,55 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     return out
 
 
+def pack_x3(w: torch.Tensor) -> torch.Tensor:
+    """w [G, N, K] (or [N, K]) f32 -> the weight image of ``conv_pw_x3_kernel`` (csrc/conv_pw_x3.h): every value as the
+    EXACT sum of three bf16 values (p1 = w with the low 16 bits cleared, p2 the same of w - p1, p3 = w - p1 - p2), laid
+    out [G][K / 32][plane][Npad][32] bf16 with N padded to 128 and the four 16-byte chunks of a 64-byte row XOR-ed with
+    (n >> 2) & 3 - tile by tile the LDS image the kernel's LDS-DMA writes.  uint8 tensor on w's device."""
+    w = w.detach().float()
+    if w.dim() == 2:
+        w = w[None]
+    G, N, K = w.shape
+    if K % 32:
+        raise _lib.FgnHipError('pack_x3: K must be a multiple of 32')
+    npad = (N + 127) // 128 * 128
+    wp = w.new_zeros(G, npad, K)
+    wp[:, :N] = w
+    planes = []
+    r = wp
+    for _ in range(3):
+        hi = (r.contiguous().view(torch.int32) & -65536).view(torch.float32)
+        planes.append((hi.view(torch.int32) >> 16).to(torch.int16))
+        r = r - hi                                     # exact: hi holds the leading bits of r
+    pl = torch.stack(planes, 1)                        # [G, 3, npad, K] bf16 bit patterns
+    pl = pl.view(G, 3, npad, K // 32, 4, 8)            # K -> (K-tile, chunk, 8)
+    n = torch.arange(npad, device=w.device)
+    src = torch.arange(4, device=w.device)[None, :] ^ ((n[:, None] >> 2) & 3)          # physical chunk c holds logical c ^ swz
+    pl = torch.gather(pl, 4, src[None, None, :, None, :, None].expand(G, 3, npad, K // 32, 4, 8))
+    img = pl.permute(0, 3, 1, 2, 4, 5).contiguous()    # [G, KT, 3, npad, 4, 8]
+    return img.view(torch.uint8).reshape(-1)
+
+
+def gemm_x3(x: torch.Tensor, image: torch.Tensor, cout: int, shift: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, relu: bool = False, groups: int = 1, grp_valid: Optional[int] = None,
+            bm: int = 0, nterms: int = 6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, K] (grouped: [groups, grp_rows, K]) times the ``pack_x3`` image -> [rows, cout] on conv_pw_x3_kernel."""
+    _chk(x, 'x')
+    K = x.shape[-1]
+    rows = x.numel() // K
+    grp_rows = rows // groups
+    npad = (cout + 127) // 128 * 128
+    L = _lib.load()
+    if image.numel() != L.fgn_x3_image_bytes(K, npad, groups):
+        raise _lib.FgnHipError('gemm_x3: image size does not match K / cout / groups')
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (cout,), device=x.device, dtype=torch.float32)
+    rc = L.fgn_gemm_x3_f32(_ptr(x), image.data_ptr(), _ptr(out), _ptr(shift), _ptr(residual), rows, K, cout, npad, int(relu),
+                           grp_rows, grp_rows if grp_valid is None else grp_valid, groups, bm, nterms, _stream())
+    _lib.check(rc, 'fgn_gemm_x3_f32')
+    return out
+
+
 @dataclass
 class DualConvLayer:
     """Two 1x1 / stride 1 convolutions with their eval-mode BatchNorms, packed for ONE K loop (``conv1x1_dual``):
@@ -332,9 +425,11 @@ class DualConvLayer:
     cout: int
     cout_pad: int
     relu: bool
+    w3: Optional[torch.Tensor] = None
 
     def to(self, device):
         self.w, self.shift = self.w.to(device), self.shift.to(device)
+        self.w3 = None if self.w3 is None else self.w3.to(device)
         return self
 
 
@@ -352,7 +447,8 @@ def pack_conv_dual(w1: torch.Tensor, bn1: dict, w2: torch.Tensor, bn2: dict, rel
     cout_pad = (cout + 127) // 128 * 128
     wp = torch.zeros(cout_pad, cin1 + cin2, dtype=torch.float32)
     wp[:cout] = torch.cat(rows, 1).float()
-    return DualConvLayer(wp.contiguous(), shift.float().contiguous(), cin1, cin2, cout, cout_pad, relu)
+    return DualConvLayer(wp.contiguous(), shift.float().contiguous(), cin1, cin2, cout, cout_pad, relu,
+                         pack_x3(wp) if _x3_ok(cin1 + cin2, cout) else None)
 
 
 def strided_rows(shapes, stride: int, device) -> torch.Tensor:
@@ -395,13 +491,19 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, _ptr(layer.w), _ptr(out), _ptr(layer.shift),
-                                     rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
+    if layer.w3 is not None:
+        rc = L.fgn_conv1x1_dual_x3_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, layer.w3.data_ptr(), _ptr(out),
+                                            _ptr(layer.shift), rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad,
+                                            int(layer.relu), _stream())
+    else:
+        rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, _ptr(layer.w), _ptr(out), _ptr(layer.shift),
+                                         rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
     _lib.check(rc, 'fgn_conv1x1_dual_nhwc_f32')
     if prof is not None:
         k = layer.cin1 + layer.cin2
         flop = 2.0 * rows * layer.cout * k
-        prof.append(dict(kind='conv', kernel='conv_pw_persist_kernel', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+        prof.append(dict(kind='conv', kernel=X3_KERNEL if layer.w3 is not None else 'conv_pw_persist_kernel',
+                         math='x3' if layer.w3 is not None else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                          n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k), residual=False,
                          shape=(1, rows, 1, k, layer.cout, 1, 1)))
     return out
@@ -463,6 +565,7 @@ class WinogradLayer:
     cout_pad: int
     relu: bool
     m: int = 2
+    u3: Optional[torch.Tensor] = None      # bf16-plane image of u (pack_x3), or None
 
     @property
     def groups(self) -> int:
@@ -471,6 +574,7 @@ class WinogradLayer:
     def to(self, device):
         self.u = self.u.to(device)
         self.shift = None if self.shift is None else self.shift.to(device)
+        self.u3 = None if self.u3 is None else self.u3.to(device)
         return self
 
 
@@ -507,7 +611,7 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
     up = torch.zeros((m + 2) ** 2, cout_pad, cin, dtype=torch.float32, device=w.device)
     up[:, :cout] = u.reshape((m + 2) ** 2, cout, cin).float()
     return WinogradLayer(up.contiguous(), None if shift is None else shift.float().contiguous(), cin, cout,
-                         cout_pad, relu, m)
+                         cout_pad, relu, m, pack_x3(up) if _x3_ok(cin, cout) else None)
 
 
 _WG_G_DEV: dict = {}
@@ -526,6 +630,8 @@ def repack_conv_(layer: ConvLayer, weight: torch.Tensor, bias: Optional[torch.Te
         layer.w[:cout, :k].copy_(weight.detach().permute(0, 2, 3, 1).reshape(cout, k))
     if bias is not None:
         layer.shift.copy_(bias.detach())
+    if layer.w3 is not None:
+        layer.w3.copy_(pack_x3(layer.w))
     return layer
 
 
@@ -546,6 +652,8 @@ def repack_winograd_(layer: WinogradLayer, weight: torch.Tensor, bias: Optional[
     _lib.check(rc, 'fgn_winograd_pack_weights_f32')
     if bias is not None:
         layer.shift.copy_(bias.detach())
+    if layer.u3 is not None:
+        layer.u3.copy_(pack_x3(layer.u))
     return layer
 
 
@@ -604,8 +712,12 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
-    _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
-                                       layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_f32')
+    if layer.u3 is not None:
+        _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
+                                              layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
+    else:
+        _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
+                                           layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_f32')
     if ev is not None:
         ev.append(prof.arm())
     _lib.check(f_out(_ptr(Mo), _ptr(y), _ptr(layer.shift), _ptr(n_img_dev), n_img, H, W, layer.cout, t_pad,
@@ -624,7 +736,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
-        prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=X3_KERNEL if layer.u3 is not None else kernel_name(gid),
+                         math='x3' if layer.u3 is not None else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, gemm=(G, tiles, layer.cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
@@ -674,8 +787,12 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
-    _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
-                                       G, st), 'fgn_winograd_gemm_f32')
+    if layer.u3 is not None:
+        _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), None, 1, total, t_pad, cin, cout,
+                                              layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
+    else:
+        _lib.check(L.fgn_winograd_gemm_f32(_ptr(V), _ptr(layer.u), _ptr(Mo), None, 1, total, t_pad, cin, cout, layer.cout_pad,
+                                           G, st), 'fgn_winograd_gemm_f32')
     if prof is not None:
         ev.append(prof.arm())
     if pair:
@@ -695,7 +812,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
         prof.append(dict(kind='wg_in', kernel='wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false'),
                          e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
-        prof.append(dict(kind='wg_gemm', kernel=kernel_name(gid), e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=X3_KERNEL if layer.u3 is not None else kernel_name(gid),
+                         math='x3' if layer.u3 is not None else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin,
                          gemm=(G, total, cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel='wg4_output_kernel<%d>' % (vo // 10), e0=ev[2][0], e1=ev[2][1],

@@ -105,9 +105,9 @@ def pack_train(model, device, weights: Optional[dict] = None, buffers: Optional[
     src = model._sd if weights is None else weights
     anchors = model._PT['anchors'] if getattr(model, '_PT', None) else {}
     pinned = model._PT.get('pinned', {}) if getattr(model, '_PT', None) else {}
-    model._PT = {'shared': [_SharedBlockTrain(src, f'roi_head.shared_head.{b}', model.use_winograd, buffers).to(device)
-                            for b in range(nb)],
-                 'device': torch.device(device), 'anchors': anchors, 'pinned': pinned}
+    with ops.gemm_math('f32'):      # layers whose weights an optimizer rewrites in place: no bf16-plane image to keep in step
+        shared = [_SharedBlockTrain(src, f'roi_head.shared_head.{b}', model.use_winograd, buffers).to(device) for b in range(nb)]
+    model._PT = {'shared': shared, 'device': torch.device(device), 'anchors': anchors, 'pinned': pinned}
 
 
 def shared_head_train(model, x, momentum: float, tape: Optional[list] = None):
@@ -936,9 +936,10 @@ class Trainer:
         m = self.model
         m._tape = {}
         try:
-            losses = forward_train(m, perm_fn=perm_fn, bn_momentum=self.bn_momentum, **batch)
-            self._bn_calls += 1 + (m._tape.get('roi') is not None)
-            g = backward(m, self.W, m._tape)
+            with ops.gemm_math('f32'):      # the transposed-weight layers packed inside backward() live for one call
+                losses = forward_train(m, perm_fn=perm_fn, bn_momentum=self.bn_momentum, **batch)
+                self._bn_calls += 1 + (m._tape.get('roi') is not None)
+                g = backward(m, self.W, m._tape)
         finally:
             m._tape = None
         # a gradient for EVERY trainable tensor, zeros where this batch produced none (no positive RoI -> the mask

@@ -93,6 +93,33 @@ int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2
                               const float* w_packed, float* y, const float* shift, int rows, int Cin1, int Cin2, int Cout,
                               int cout_pad, int relu, void* stream);
 
+/* The GEMM-shaped launches of the path with their PRODUCTS on the bf16 matrix pipe (conv_pw_x3_kernel, csrc/conv_pw_x3.h;
+ * gfx950's f32-input MFMA runs at 1/16 of the bf16 MFMA's rate and has no xf32 / TF32 form).  An f32 value is the exact
+ * sum of three bf16 values (8 significant bits each); a product of two such sums is nine exact bf16 products, of which
+ * the six that reach 2^-23 of |a b| are issued as bf16 MFMAs and accumulated in f32 - the operands, the accumulation,
+ * the epilogue and the results are f32, and the error against fp64 is that of the f32 MFMA kernels
+ * (tests/test_hip_conv.py::test_x3_*).  The same call sites as their f32 counterparts (fgn_conv2d_nhwc_f32 with a 1x1 /
+ * stride 1 / unpadded kernel, fgn_conv1x1_dual_nhwc_f32, fgn_winograd_gemm_f32), same arguments, except that the weights
+ * are given as their bf16-plane IMAGE (host-packed once: fgn_amd/ops.py::pack_x3):
+ *   w_x3 [groups][K / 32][3 planes][cout_pad][32] bf16, plane 0 = w with the low 16 bits cleared, plane 1 the same of
+ *   w - plane 0, plane 2 = w - plane 0 - plane 1; the four 16-byte chunks of a 64-byte row XOR-ed with (n >> 2) & 3.
+ * fgn_x3_image_bytes = its size.  K >= 64, K % 32 == 0, Cout % 4 == 0, cout_pad % 128 == 0.
+ * fgn_gemm_x3_f32: y[rows, Cout] = relu?(x[rows, K] W^T + shift + residual) directly (grouped: rows = n_groups *
+ * grp_rows, image g for group g, first grp_valid rows of a group computed); bm 0 / 64 / 128 and nterms 6 / 9 choose the
+ * kernel instance (tests, tools/x3_probe.py). */
+size_t fgn_x3_image_bytes(int K, int npad, int n_groups);
+int fgn_gemm_x3_f32(const float* x, const void* w_x3, float* y, const float* shift, const float* residual, int rows, int K,
+                    int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups, int bm, int nterms,
+                    void* stream);
+int fgn_conv1x1_x3_nhwc_f32(const float* x, const void* w_x3, float* y, const float* scale, const float* shift,
+                            const float* residual, const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
+                            int cout_pad, int relu, void* stream);
+int fgn_conv1x1_dual_x3_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                                 const void* w_x3, float* y, const float* shift, int rows, int Cin1, int Cin2, int Cout,
+                                 int cout_pad, int relu, void* stream);
+int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const int32_t* n_img_dev, int n_img,
+                             int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
+
 /* The same convolution (w_packed, scale, shift, relu as in fgn_conv2d_nhwc_f32) on TWO NHWC tensors of different
  * geometry in one launch: x0 [n_img0,H0,W0,Cin] -> y0, x1 [n_img1,H1,W1,Cin] -> y1.  For the backbone layers that
  * stride over the spatial structure when the query image and the support crops go through the backbone together

@@ -164,13 +164,16 @@ def test_repeated_runs_are_bit_identical_at_full_occupancy():
 @pytest.mark.parametrize('rows,cin,cout,res,relu', [(49 * 300, 512, 1024, True, True), (103664, 64, 256, True, True),
                                                     (26016, 128, 512, False, True), (49 * 300 + 17, 1024, 1024, False, False),
                                                     (4200 * 5, 96, 260, True, False)])
-def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, cin, cout, res, relu):
+@pytest.mark.parametrize('math', ['f32', 'x3'])
+def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, cin, cout, res, relu, math):
     """conv_pw_persist_kernel (the dominant kernel of an episode: 1x1 / stride 1 launches with more 64x64 output tiles
     than its 1024 persistent workgroups) at the episode's own shapes and at ragged ones (a last row tile of 17 rows, a
     channel count that is not a multiple of 64), with residual / BN / ReLU epilogues: against fp64, and against the
     one-tile-per-workgroup kernel of the same tile on pieces of the launch (fewer than 1024 tiles each, split-K off):
     the two differ only in the order of the K sum inside a 16-deep step (16x16x4 vs 32x32x2 MFMA: 2e-6 of the range),
-    and every output element must be covered exactly once (a tile walked twice or skipped shows at once)."""
+    and every output element must be covered exactly once (a tile walked twice or skipped shows at once).
+    math = 'x3': the same launches on conv_pw_x3_kernel (six bf16 MFMA products per f32 product, the build's default) -
+    the same bound against fp64, and within 4e-6 of the range of the f32 one-tile kernel's pieces."""
     from fgn_amd import lib, ops
     g = torch.Generator().manual_seed(rows + cin)
     x = torch.randn(rows, cin, generator=g)
@@ -178,7 +181,9 @@ def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, 
     bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
               running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
     r = torch.randn(rows, cout, generator=g) if res else None
-    layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
+    with ops.gemm_math(math):
+        layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
+    assert (layer.w3 is not None) == (math == 'x3')
     xc = x.cuda().view(1, rows, 1, cin)
     rc = None if r is None else r.cuda().view(1, rows, 1, cout)
     L = lib.load()
@@ -199,7 +204,7 @@ def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, 
         piece = ops.conv2d(xc[:, m0:m1].contiguous(), layer, residual=None if rc is None else rc[:, m0:m1].contiguous(),
                            tile_hint=-4)
         assert L.fgn_conv2d_kernel_id(1, m1 - m0, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, int(res), -4) % 10 == 1
-        assert (piece - y[:, m0:m1]).abs().max().item() <= 2e-6 * ref.abs().max().item(), (m0, m1)
+        assert (piece - y[:, m0:m1]).abs().max().item() <= (2e-6 if math == 'f32' else 4e-6) * ref.abs().max().item(), (m0, m1)
 
 
 @pytest.mark.parametrize('cin,cout,k,stride', [(128, 128, 3, 2), (256, 512, 1, 2), (64, 64, 3, 1), (4, 64, 7, 2)])
@@ -237,7 +242,8 @@ def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
 
 
 @pytest.mark.parametrize('rows,cin1,cin2,cout', [(103664, 64, 64, 256), (5000, 32, 96, 132), (777, 128, 32, 64)])
-def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, cout):
+@pytest.mark.parametrize('math', ['f32', 'x3'])
+def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, cout, math):
     """``conv1x1_dual`` (fgn_conv1x1_dual_nhwc_f32): relu(bn3(conv3(y)) + bn_d(conv_d(x))) of the first Bottleneck of a
     stride-1 stage as ONE K loop over [y | x] with the BatchNorm scales folded into the weights - against fp64, and
     against the two-launch form it replaces (shortcut conv, then conv3 with the residual in its epilogue), at the cfg3
@@ -255,19 +261,23 @@ def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, co
         return v * sc + (bn['bias'].double() - bn['running_mean'].double() * sc)
     ref = torch.relu(affine(y.double() @ w3.reshape(cout, cin1).double().T, bn3) +
                      affine(x.double() @ wd.reshape(cout, cin2).double().T, bnd))
-    layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
+    with ops.gemm_math(math):
+        layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
+    assert (layer.w3 is not None) == (math == 'x3')
     yc, xc = y.cuda().view(1, rows, 1, cin1), x.cuda().view(1, rows, 1, cin2)
     got = ops.conv1x1_dual(yc, xc, layer)
     assert tuple(got.shape) == (1, rows, 1, cout)
     assert (got.view(rows, cout).cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'),
-                     residual=ops.conv2d(xc, ops.pack_conv(wd, bn=bnd).to('cuda')))
+    with ops.gemm_math('f32'):
+        two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'),
+                         residual=ops.conv2d(xc, ops.pack_conv(wd, bn=bnd).to('cuda')))
     assert (got - two).abs().max().item() <= 4e-6 * ref.abs().max().item()
     again = ops.conv1x1_dual(yc, xc, layer)
     assert torch.equal(got, again)
 
 
-def test_dual_operand_conv_with_a_strided_shortcut():
+@pytest.mark.parametrize('math', ['f32', 'x3'])
+def test_dual_operand_conv_with_a_strided_shortcut(math):
     """The 1x1 / stride 2 shortcut of layer2.0 / layer3.0 inside conv3's K loop: output row m reads row x2_rows[m] of the
     stage's input (``ops.strided_rows`` over the query map and the support maps lying one behind the other) - against the
     two-launch form (strided shortcut conv, then conv3 with the residual in its epilogue) and fp64."""
@@ -284,12 +294,90 @@ def test_dual_operand_conv_with_a_strided_shortcut():
     mk = lambda: dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
                       running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
     bn3, bnd = mk(), mk()
-    layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
+    with ops.gemm_math(math):
+        layer = ops.pack_conv_dual(w3, bn3, wd, bnd, relu=True).to('cuda')
     yc = y.cuda().view(1, rows, 1, cin1)
     got = ops.conv1x1_dual(yc, buf.view(1, -1, 1, cin2), layer, x2_rows=rows_tab)
-    down = ops.pack_conv(wd, bn=bnd, stride=2).to('cuda')
-    idt = torch.cat([ops.conv2d(q.cuda(), down).reshape(-1, cout), ops.conv2d(s_.cuda(), down).reshape(-1, cout)])
-    two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'), residual=idt.view(1, rows, 1, cout))
+    with ops.gemm_math('f32'):
+        down = ops.pack_conv(wd, bn=bnd, stride=2).to('cuda')
+        idt = torch.cat([ops.conv2d(q.cuda(), down).reshape(-1, cout), ops.conv2d(s_.cuda(), down).reshape(-1, cout)])
+        two = ops.conv2d(yc, ops.pack_conv(w3, bn=bn3, relu=True).to('cuda'), residual=idt.view(1, rows, 1, cout))
     assert (got - two).abs().max().item() <= 4e-6 * two.abs().max().item()
     with pytest.raises(Exception):
         ops.conv1x1_dual(yc, buf.view(1, -1, 1, cin2), layer)                 # rows differ and no table
+
+
+@pytest.mark.parametrize('groups,grp_rows,valid,K,N', [(1, 14700, 14700, 1024, 1024), (1, 3001, 3001, 64, 76), (1, 130, 130, 96, 260),
+                                                       (36, 256, 201, 128, 132), (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256)])
+def test_x3_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, valid, K, N):
+    """conv_pw_x3_kernel through its direct entry (fgn_gemm_x3_f32): f32 operands, every product as six (nterms 9: nine)
+    bf16 MFMA products of exact three-way splits, f32 accumulation.  Against fp64 on post-ReLU activations x random
+    weights: within 2e-6 of the range like the f32 MFMA kernels, and no further from fp64 than 1.6x the f32 MFMA kernel on
+    the same operands (measured r05: 1.2x, for six terms and for nine alike - the difference is the accumulation order
+    inside the matrix pipe, not the dropped terms).  Both row tiles (64 rows x 2 stages, 128 rows x 3 stages) give the
+    same bits; ragged rows / channels, grouped launches with fewer valid rows than a group holds, K of 2 and 3 K-tiles
+    (the ring is as deep as the whole K loop)."""
+    from fgn_amd import lib, ops
+    g = torch.Generator().manual_seed(groups * 1000 + K + N)
+    x = torch.randn(groups, grp_rows, K, generator=g).relu_().cuda()
+    w = (torch.randn(groups, N, K, generator=g) / K ** 0.5).cuda()
+    shift = torch.randn(N, generator=g).cuda()
+    ref = torch.einsum('grk,gnk->grn', x[:, :valid].double(), w.double()) + shift.double()
+    rng = ref.abs().max().item()
+    img = ops.pack_x3(w)
+    outs = {}
+    for bm in (64, 128):
+        if groups > 1 and grp_rows % bm:
+            continue
+        for nt in (6, 9):
+            out = torch.full((groups, grp_rows, N), float('nan'), device='cuda')
+            ops.gemm_x3(x, img, N, shift=shift, groups=groups, grp_valid=valid, bm=bm, nterms=nt, out=out)
+            outs[(bm, nt)] = out
+            err = (out[:, :valid].double() - ref).abs().max().item()
+            assert err <= 2e-6 * rng, (bm, nt, err / rng)
+            # rows of whole tiles past the last valid one of a group are not written
+            last = -(-valid // bm) * bm
+            assert torch.isnan(out[:, last:]).all()
+    if (64, 6) in outs and (128, 6) in outs:
+        assert torch.equal(outs[(64, 6)][:, :valid], outs[(128, 6)][:, :valid])
+    # the f32 MFMA kernel on the same operands
+    if groups == 1:
+        with ops.gemm_math('f32'):
+            layer = ops.pack_conv(w[0].reshape(N, K, 1, 1), bias=shift).to('cuda')
+        f32 = ops.conv2d(x.view(1, grp_rows, 1, K), layer).view(1, grp_rows, N)
+    else:
+        L = lib.load()
+        cout_pad = (N + 127) // 128 * 128
+        u = torch.zeros(groups, cout_pad, K, device='cuda')
+        u[:, :N] = w
+        f32 = torch.zeros(groups, grp_rows, N, device='cuda')
+        lib.check(L.fgn_winograd_gemm_f32(x.data_ptr(), u.data_ptr(), f32.data_ptr(), None, 1, valid, grp_rows, K, N, cout_pad,
+                                          groups, torch.cuda.current_stream().cuda_stream), 'wg')
+        f32 = f32 + shift
+    e32 = (f32[:, :valid].double() - ref).abs()
+    e6 = (outs[(64, 6)][:, :valid].double() - ref).abs()
+    assert e6.max().item() <= 1.6 * e32.max().item() + 1e-7 * rng
+    assert e6.mean().item() <= 1.6 * e32.mean().item() + 1e-8 * rng
+
+
+def test_x3_gemm_epilogue_and_special_values():
+    """Residual + ReLU in the epilogue; operands with zeros, tiny and huge magnitudes (the split is exact from 2^-100 up:
+    below that the third plane underflows, far under any activation); rows past M untouched."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, K, N = 1000, 128, 64
+    x = torch.randn(rows, K, generator=g)
+    x[::7] = 0.0
+    x[1::7] *= 1e-20
+    x[2::7] *= 1e15
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    w[:, ::5] *= 1e-12
+    res = torch.randn(rows, N, generator=g)
+    ref = torch.relu(x.double() @ w.double().T + res.double())
+    out = torch.full((rows + 64, N), -7.0, device='cuda')
+    ops.gemm_x3(x.cuda(), ops.pack_x3(w.cuda()), N, residual=res.cuda(), relu=True, out=out[:rows])
+    got = out[:rows].cpu().double()
+    assert torch.isfinite(got).all() and (out[rows:] == -7.0).all()
+    # per row: relative to that row's own scale (rows differ by 35 orders of magnitude)
+    scale = (x.double().abs() @ w.double().abs().T).max(1, keepdim=True).values + res.double().abs()
+    assert ((got - ref).abs() / scale).max().item() <= 2e-6

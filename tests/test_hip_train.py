@@ -833,11 +833,13 @@ def test_in_place_repack_equals_a_fresh_pack():
     # Adagrad's first steps move a weight by ~lr whatever the size of its gradient, so a last-bit difference of a Winograd
     # weight that flips one ReLU changes single elements by up to a step (5e-4 under roi_head) in each of the steps that
     # follow the first re-pack (two of the three); all but a handful agree to 1e-5, none is further apart than those two
-    # steps (which element flips depends on the last bits of the frozen backbone's kernels: round 5's fused shortcuts
-    # moved it from one step to two)
+    # steps.  A flipped ReLU of an output channel that is alive at a few RoI positions only changes that channel's whole
+    # weight ROW (its gradient is a sum over those positions): which rows, and how many, depends on the last bits of the
+    # frozen backbone's kernels (round 4: one row, <= 0.2 % of a tensor; round 5's fused shortcuts: ten rows, 2 %)
     for k in res['1'][0]:
         d = (res['1'][0][k] - res['0'][0][k]).abs()
-        assert d.max().item() <= 1.05e-3 and (d > 1e-5).float().mean().item() <= 2e-3, (k, d.max().item())
+        rows = (d.reshape(d.shape[0], -1) > 1e-5).any(1).float().mean().item() if d.dim() > 1 else 0.0
+        assert d.max().item() <= 1.05e-3 and (d > 1e-5).float().mean().item() <= 5e-2, (k, d.max().item(), rows)
     for k in res['1'][1]:
         a, b_ = res['1'][1][k], res['0'][1][k]
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= 1.05e-3, k

@@ -868,3 +868,28 @@ def test_episodic_sampler_matches_the_reference_on_its_own_databag(golden_dir):
             # the category of every support instance is the category it was drawn for, class-major (index = n * K + k)
             assert [int(bag.inst_cat[i]) for i in s['spp_insts_ids']] == \
                 [int(c) for c in s['cats_ids_to_sample_real'] for _ in range(cfg['k_shots'])]
+
+
+def test_x3_weight_image_is_an_exact_three_way_split():
+    """``ops.pack_x3``: every f32 weight is the exact sum of its three bf16 planes (the low 16 bits of each plane's f32
+    form are zero, plane by plane the leading bits of what the planes before left), laid out [G][K/32][3][Npad][32] with
+    the 16-byte chunks of a row XOR-ed by (n >> 2) & 3 and zero rows up to a multiple of 128."""
+    import torch
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(2, 200, 96, generator=g) * torch.logspace(-30, 20, 96)[None, None, :]
+    w[0, 5, 7] = 0.0
+    img = ops.pack_x3(w)
+    G, N, K = w.shape
+    npad = 256
+    assert img.dtype == torch.uint8 and img.numel() == G * K * npad * 6
+    pl = img.view(torch.int16).view(G, K // 32, 3, npad, 4, 8).permute(0, 2, 3, 1, 4, 5)       # G, plane, n, kt, chunk, 8
+    n = torch.arange(npad)
+    idx = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)                                  # logical chunk -> physical
+    pl = torch.gather(pl, 4, idx[None, None, :, None, :, None].expand(G, 3, npad, K // 32, 4, 8))
+    planes = (pl.to(torch.int32) << 16).view(torch.float32).reshape(G, 3, npad, K)
+    assert torch.equal(planes.double().sum(1)[:, :N], w.double())                             # exact
+    assert (planes[:, :, N:] == 0).all()
+    p1, p2, p3 = planes[:, 0, :N], planes[:, 1, :N], planes[:, 2, :N]
+    assert ((p2.abs() <= p1.abs() * 2.0 ** -7) | (p1 == 0)).all() and ((p3.abs() <= p1.abs() * 2.0 ** -15) | (p1 == 0)).all()
+    assert (torch.sign(p2) * torch.sign(p1) >= 0).all() and (torch.sign(p3) * torch.sign(p1) >= 0).all()

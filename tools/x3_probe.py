@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""conv_pw_x3_kernel (three-bf16-plane products) against the f32-MFMA kernels: error against fp64 and time per launch on
+the GEMM shapes of a cfg3 episode.  python tools/x3_probe.py [--reps 30]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fgn_amd import ops  # noqa: E402
+
+SHAPES = [   # name, groups, rows per group (allocated), valid rows, K, N
+    ('relq 14700x1024>1024', 1, 14700, 14700, 1024, 1024),
+    ('sh conv3 15141x512>1024', 1, 15141, 15141, 512, 1024),
+    ('sh conv1 15141x1024>512', 1, 15141, 15141, 1024, 512),
+    ('wino sh300 36x1236 512>512', 36, 1280, 1236, 512, 512),
+    ('wino agrpn 36x819 1024>1024', 36, 896, 819, 1024, 1024),
+    ('wino mask 36x400 512>512', 36, 512, 400, 512, 512),
+    ('layer1 conv3 103664x64>256', 1, 103664, 103664, 64, 256),
+    ('layer2 conv3 25916x128>512', 1, 25916, 25916, 128, 512),
+    ('layer2 conv1 25916x512>128', 1, 25916, 25916, 512, 128),
+    ('layer3 conv1 6504x1024>256', 1, 6504, 6504, 1024, 256),
+    ('layer3 conv3 6504x256>1024', 1, 6504, 6504, 256, 1024),
+]
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--phases', action='store_true', help='phase clocks (FGN_HIP_LIB=tools/micro/libfgn_hip_x3ph.so)')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1)
+    for name, G, gr, valid, K, N in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn(G, gr, K, generator=g).relu_().to(dev)          # post-ReLU activations
+        w = (torch.randn(G, N, K, generator=g) * (1.0 / K ** 0.5)).to(dev)
+        shift = torch.randn(N, generator=g).to(dev)
+        ref = torch.einsum('grk,gnk->grn', x[:, :valid].double(), w.double()) + shift.double()
+        scale = ref.abs().max().item()
+        img = ops.pack_x3(w)
+        rec = dict(shape=name, gflop=2.0 * G * valid * K * N / 1e9)
+        outs = {}
+        for tag, bm, nt in (('x6_bm128', 128, 6), ('x6_bm64', 64, 6), ('x9_bm128', 128, 9), ('x9_bm64', 64, 9)):
+            if G > 1 and gr % bm:
+                continue
+            out = torch.zeros(G, gr, N, device=dev)
+            fn = lambda: ops.gemm_x3(x, img, N, shift=shift, groups=G, grp_valid=valid, bm=bm, nterms=nt, out=out)  # noqa: E731
+            fn()
+            torch.cuda.synchronize()
+            d = (out[:, :valid].double() - ref).abs()
+            outs[tag] = out
+            rec[tag] = dict(us=round(timed(fn, args.reps), 1), max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
+            rec[tag]['tflops_f32_equiv'] = round(rec['gflop'] / rec[tag]['us'] * 1e-3, 1)
+            if args.phases:
+                import ctypes
+                raw = ctypes.CDLL(ops._lib.LIB_PATH)
+                buf = (ctypes.c_ulonglong * 16)()
+                raw.fgn_x3_phases(buf)                      # clear
+                fn()
+                if raw.fgn_x3_phases(buf) == 0:
+                    for b in (0, 1):
+                        v = list(buf[8 * b:8 * b + 7])
+                        steps = max(v[5], 1)
+                        rec[tag]['wg%d_cycles_per_ktile' % b] = dict(
+                            wait_barrier=round(v[0] / steps), issue=round(v[1] / steps), lds_landed=round(v[2] / steps),
+                            split_mfma=round(v[3] / steps), epilogue_per_ktile=round(v[4] / steps), ktiles=v[5],
+                            kernel_cycles=v[6])
+        # the f32 MFMA path: a 1x1 convolution (or the Winograd grouped GEMM entry) on the same operands
+        if G == 1:
+            layer = ops.pack_conv(w[0].reshape(N, K, 1, 1), bias=shift).to(dev)
+            xin = x[0].reshape(1, gr, 1, K)
+            out = torch.zeros(1, gr, 1, N, device=dev)
+            fn = lambda: ops.conv2d(xin, layer, out=out)  # noqa: E731
+            fn()
+            torch.cuda.synchronize()
+            d = (out.reshape(gr, N)[:valid].double() - ref[0]).abs()
+        else:
+            L = ops._lib.load()
+            cout_pad = (N + 127) // 128 * 128
+            u = torch.zeros(G, cout_pad, K, device=dev)
+            u[:, :N] = w
+            out = torch.zeros(G, gr, N, device=dev)
+            fn = lambda: ops._lib.check(L.fgn_winograd_gemm_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), None, 1, valid, gr, K, N,  # noqa: E731
+                                                                cout_pad, G, torch.cuda.current_stream().cuda_stream), 'wg')
+            fn()
+            torch.cuda.synchronize()
+            d = (out[:, :valid].double() - (ref - shift.double())).abs()
+        rec['f32_mfma'] = dict(us=round(timed(fn, args.reps), 1), max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
+        rec['f32_mfma']['tflops'] = round(rec['gflop'] / rec['f32_mfma']['us'] * 1e-3, 1)
+        if 'x6_bm128' in outs and 'x6_bm64' in outs:
+            rec['bm128_equals_bm64'] = bool(torch.equal(outs['x6_bm128'][:, :valid], outs['x6_bm64'][:, :valid]))
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == '__main__':
+    main()
