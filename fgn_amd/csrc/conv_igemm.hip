@@ -1469,16 +1469,25 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
 // carries the bf16-plane image of its weights (w3, w3_bytes, npad3).  bm: 0 = choose, 64 / 128 = force the row tile;
 // nterms 6 (default) or 9.  The persistent grid is 2 workgroups per CU (LDS: 64 / 80 KB per workgroup).
 // ------------------------------------------------------------------------------------------------
+constexpr bool X3_DEFAULT_SH16 = false;      // MFMA shape of the default instances (tools/x3_probe.py decides)
 static int x3_pick_bm(long long M, int Cout, int grp_rows, int bm) {
     if (bm == 64 || bm == 128) return (grp_rows && grp_rows % bm) ? 0 : bm;
-    // (measured, r05 call 10: 128 rows x 3 stages at one workgroup per CU is 4-25 % slower than 64 rows x 2 stages at two
-    // on every GEMM of a cfg3 episode - its eight waves run their phases in lockstep: tools/x3_probe.py --phases)
-    return (grp_rows && grp_rows % 64) ? 0 : 64;
+    // Automatic choice (bm = 0): 64 rows, or 0 = leave the launch to the f32 MFMA kernels.  Measured per launch of a cfg3
+    // episode, both forms on one box (r05 call 15, tools/per_launch.py): the 128-column tile loses where half of it is
+    // padding (Cout 64: 37 -> 48-53 us; Cout 76: 35.6 -> 39.0), and a launch of a few dozen tiles loses to the f32
+    // path's split-K (441 x 512 x 1024: 9.6 -> 30.6 us; 147 x 1024 x 1024: 10.1 -> 32.0); from ~200 tiles on it wins
+    // (204 tiles: 35.9 -> 32.4; 264: 53.0 -> 45.0).  The 128-row tiles (4 waves of 64 x 64, or 8 waves x 3 stages) measure
+    // equal on the large GEMMs and slower on the small ones (tools/x3_probe.py): not chosen.
+    if (grp_rows && grp_rows % 64) return 0;
+    const int nt = cdiv(Cout, X3_BN);
+    if (Cout * 10 < nt * X3_BN * 7) return 0;
+    if (((M + 63) / 64) * nt < 192) return 0;
+    return 64;
 }
 
-template <int WMW, int NT, int NST>
+template <int WMW, int RB, int NT, int NST, bool SH16>
 static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
-    constexpr int BM = 32 * WMW;
+    constexpr int BM = 32 * RB * WMW;
     const int m_tiles = cdiv(M_max, BM);
     {   // banded raster: <= 2 MB of weight image per band (see ConvParams::band_nt)
         const long long per_nt = (long long)X3_BN * p.K * 6;
@@ -1492,29 +1501,41 @@ static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     }
     const int tiles = m_tiles * p.n_tiles_n;
     static unsigned long long ok = 0ull;
-    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_x3_kernel<WMW, NT, NST>), &ok);
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_x3_kernel<WMW, RB, NT, NST, SH16>), &ok);
     if (attr != hipSuccess) return (int)attr;
     const size_t lds = (size_t)NST * (BM * 128 + X3_B_STAGE);
     const int per_cu = (int)(160 * 1024 / lds);                       // resident workgroups per CU (LDS-bound)
     const int grid = std::min(256 * per_cu, (tiles + 7) / 8 * 8);
     p.stamp = fgn_next_stamp_record();
-    FGN_LAUNCH_TIMED((conv_pw_x3_kernel<WMW, NT, NST>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
+    FGN_LAUNCH_TIMED((conv_pw_x3_kernel<WMW, RB, NT, NST, SH16>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
 
+// bm: 0 = choose; 64 = 64 rows (4 waves of 32 x 64, 2 stages, 2 workgroups per CU); 128 = 128 rows as 4 waves of 64 x 64
+// (2 stages, 2 per CU); 129 = 128 rows as 8 waves of 32 x 64 (3 stages, 1 per CU: measured slower, kept for the probe);
+// + 1000: the v_mfma_f32_16x16x32_bf16 form of the 64 / 128 instances
 static int launch_x3(const ConvParams& p0, int M_max, int bm, int nterms, hipStream_t stream) {
     ConvParams p = p0;
     if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
     p.n_tiles_n = cdiv(p.Cout, X3_BN);
-    const int BM = x3_pick_bm(M_max, p.Cout, p.grp_rows, bm);
+    const bool sh16 = bm >= 1000 ? true : bm == 0 ? X3_DEFAULT_SH16 : false;
+    if (bm >= 1000) bm -= 1000;
+    const int BM = x3_pick_bm(M_max, p.Cout, p.grp_rows, bm == 129 ? 128 : bm);
     if (BM == 0) return FGN_ERR_SHAPE;
+    if (bm == 129)
+        return nterms == 9 ? launch_x3_cfg<4, 1, 9, 3, false>(p, M_max, stream) : launch_x3_cfg<4, 1, 6, 3, false>(p, M_max, stream);
     if (nterms == 9)
-        return BM == 128 ? launch_x3_cfg<4, 9, 3>(p, M_max, stream) : launch_x3_cfg<2, 9, 2>(p, M_max, stream);
-    return BM == 128 ? launch_x3_cfg<4, 6, 3>(p, M_max, stream) : launch_x3_cfg<2, 6, 2>(p, M_max, stream);
+        return BM == 128 ? launch_x3_cfg<2, 2, 9, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 9, 2, false>(p, M_max, stream);
+    if (sh16)
+        return BM == 128 ? launch_x3_cfg<2, 2, 6, 2, true>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, true>(p, M_max, stream);
+    return BM == 128 ? launch_x3_cfg<2, 2, 6, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, false>(p, M_max, stream);
 }
 
 extern "C" size_t fgn_x3_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * K * npad * 6; }
+// the row tile launch_x3 chooses for a GEMM of M rows (grouped: grp_rows per group): 64, or 0 = not supported / not
+// profitable: the caller then uses the f32 MFMA entry point (the x3 entry points return FGN_ERR_SHAPE for such a launch)
+extern "C" int fgn_x3_row_tile(long long M, int Cout, int grp_rows) { return x3_pick_bm(M, Cout, grp_rows, 0); }
 
 #ifdef X3_PHASES        // tools/micro/build_x3_phases.sh: phase clocks of wave 0 of workgroups 0 / 1 (conv_pw_x3.h)
 static unsigned long long* g_x3_ph = nullptr;

@@ -18,8 +18,8 @@
 // time (fgn_amd/ops.py::pack_x3) into an image that is the LDS image tile by tile: [group][K-tile][plane][Npad][32]
 // bf16, 64 bytes per row, the row's four 16-byte chunks XOR-ed with (n >> 2) & 3 - a K-tile of one plane for 128
 // output columns is 8 KB of contiguous memory, fetched by 8 wave-instructions.
-// Tile: BM = 32 * WMW rows x 128 columns, 64 * 2 * WMW threads, wave tile 32 x 64 as two v_mfma_f32_32x32x16_bf16
-// blocks.  An output tile of 128 x 128 moves 0.078 B / MAC through L2 -> LDS against 0.125 for the 64 x 64 f32 tile:
+// Tile: BM = 32 * RB * WMW rows x 128 columns, 64 * 2 * WMW threads, wave tile 32 RB x 64 as RB x 2 blocks of
+// v_mfma_f32_32x32x16_bf16.  An output tile of 128 x 128 moves 0.078 B / MAC through L2 -> LDS against 0.125 for the 64 x 64 f32 tile:
 // at twice the MAC rate ~10 TB/s of L2 -> LDS traffic, which the XCD L2s deliver (17-19 TB/s measured by the guide).
 // LDS: NST stages x (BM * 128 + 24576) bytes in a ring that runs ACROSS output tiles: K-tile g of the workgroup's
 // sequence lives in stage g % NST, the LDS-DMA of K-tile g + NST - 1 (of this output tile or the next one) is issued
@@ -70,13 +70,18 @@ constexpr int X3_B_STAGE = 3 * X3_BN * 64;       // bytes of one K-tile of the w
 
 template <int N> __device__ __forceinline__ void x3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WMW, int NT, int NST>
+template <int WMW, int RB, int NT, int NST, bool SH16>
 __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvParams p, const int total_tiles) {
-    constexpr int BM = 32 * WMW, BN = X3_BN, NTHR = 128 * WMW, NW = 2 * WMW;
+    // WMW waves along M x 2 along N; a wave's tile is 32 RB rows x 64 columns: RB x 2 blocks of v_mfma_f32_32x32x16_bf16
+    // (two 16-deep sub-steps per K-tile), or (SH16) 2 RB x 4 blocks of v_mfma_f32_16x16x32_bf16 (one MFMA spans the
+    // K-tile) - the same cycles per FLOP; which shape the chip clocks higher under load is measured (MI355X_MICROARCH.md,
+    // DVFS give-back item 7)
+    constexpr int BM = 32 * RB * WMW, BN = X3_BN, NTHR = 128 * WMW, NW = 2 * WMW;
+    constexpr int A_LD = BM / 8 / NW;                       // activation wave-instructions per wave per K-tile (8 rows each)
     constexpr int A_STAGE = BM * 128;                       // bytes
     constexpr int STAGE = A_STAGE + X3_B_STAGE;             // bytes
     constexpr int B_LD = 24 / NW;                           // weight wave-instructions per wave per K-tile
-    constexpr int PER = 2 + B_LD;                           // LDS-DMA wave-instructions per wave per K-tile
+    constexpr int PER = A_LD + B_LD;                        // LDS-DMA wave-instructions per wave per K-tile
     constexpr int D = NST - 1;                              // K-tiles in flight ahead of the one being multiplied
     constexpr int ROWS_PER_PASS = NTHR / 8;                 // A rows one pass of the workgroup's DMAs covers
     static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
         return -1;
     };
 
-    struct Offs { unsigned a[2], a2[2], b[B_LD]; };
+    struct Offs { unsigned a[A_LD], a2[A_LD], b[B_LD]; };
     unsigned b_lds[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
     auto offsets = [&](int m0, int n0) -> Offs {
         Offs o;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A_LD; ++i) {
             const int m = m0 + row0 + ROWS_PER_PASS * i;
             o.a[i] = m < M ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
             o.a2[i] = OOB;
@@ -162,10 +167,10 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
         if (dual && kt >= p.kt1) {
             const unsigned ko2 = (unsigned)((kt - p.kt1) * BK * 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, o.a2[i], ko2);
+            for (int i = 0; i < A_LD; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, o.a2[i], ko2);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, o.a[i], ko);
+            for (int i = 0; i < A_LD; ++i) lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, o.a[i], ko);
         }
         const unsigned kb = (unsigned)kt * kt_bytes;
 #pragma unroll
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
 
     // fragment addresses (bytes within a stage).  32x32x16: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h + 7
     const int r32 = lane & 31, h = lane >> 5;
-    const int a_row = wm * 32 + r32;
+    const int a_row = wm * 32 * RB + r32;         // (+ 32 i for row block i: the swizzle term (row >> 1) & 7 is the same)
     const unsigned a_sw = (unsigned)((a_row >> 1) & 7);
     unsigned a_rd[2][2], b_rd[2][2];              // [sub-step][chunk] / [sub-step][column block], swizzle applied
 #pragma unroll
@@ -188,6 +193,15 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
             b_rd[s][j] = (unsigned)(A_STAGE + n * 64) + ((((unsigned)(2 * s + h)) ^ (unsigned)((n >> 2) & 3)) << 4);
         }
     }
+
+    // 16x16x32: lane (r = lane & 15, g = lane >> 4) holds k = 8g .. 8g + 7 of row / column r of its block
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int a16_row = wm * 32 * RB + r16;       // (+ 16 i for row block i: (row >> 1) & 7 is the same)
+    const unsigned a16_sw = (unsigned)((a16_row >> 1) & 7);
+    const unsigned a16_rd0 = (unsigned)(a16_row * 128) + ((((unsigned)(2 * g4)) ^ a16_sw) << 4);
+    const unsigned a16_rd1 = (unsigned)(a16_row * 128) + ((((unsigned)(2 * g4 + 1)) ^ a16_sw) << 4);
+    const int n16 = wn * 64 + r16;                // (+ 16 j for column block j: (n >> 2) & 3 is the same)
+    const unsigned b16_rd = (unsigned)(A_STAGE + n16 * 64) + ((((unsigned)g4) ^ (unsigned)((n16 >> 2) & 3)) << 4);
 
     if (p.stamp && t == 0 && blockIdx.x == 0) atomicExch(p.stamp, __builtin_amdgcn_s_memrealtime());
     auto leave = [&]() {
@@ -238,11 +252,18 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
 #endif
 
     while (true) {
-        f32x16 acc[2];
+        f32x16 acc[RB][2];
+        f32x4 acc16[2 * RB][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * RB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT; ++kt) {
             // K-tile `kt` has landed: everything (first K-tile of an output tile: the previous epilogue's stores share
             // the counter and return in no fixed order with the loads), or all but the K-tile requested after it
@@ -255,12 +276,54 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
             asm volatile("" ::: "memory");
             X3_T(1);
             const unsigned char* const S = smem_x3 + stage * STAGE;
-            float4 alo[2], ahi[2];
+            if constexpr (SH16) {
+                float4 alo[2 * RB], ahi[2 * RB];
+                bf16x8_t bq[4][3];
+#pragma unroll
+                for (int i = 0; i < 2 * RB; ++i) {
+                    alo[i] = *reinterpret_cast<const float4*>(S + a16_rd0 + i * (16 * 128));
+                    ahi[i] = *reinterpret_cast<const float4*>(S + a16_rd1 + i * (16 * 128));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bq[j][q] = *reinterpret_cast<const bf16x8_t*>(S + b16_rd + j * (16 * 64) + q * (BN * 64));
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef X3_PHASES
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                X3_T(2);
+#endif
+#pragma unroll
+                for (int i = 0; i < 2 * RB; ++i) {
+                    const X3Frag a = x3_split(alo[i], ahi[i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 c = acc16[i][j];
+                        if (NT == 9) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p3, bq[j][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p3, bq[j][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p2, bq[j][2], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p3, bq[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p1, bq[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p2, bq[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p2, bq[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p1, bq[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p1, bq[j][0], c, 0, 0, 0);
+                        acc16[i][j] = c;
+                    }
+                }
+            } else {
+            float4 alo[2][RB], ahi[2][RB];
             bf16x8_t bq[2][2][3];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                alo[s] = *reinterpret_cast<const float4*>(S + a_rd[s][0]);
-                ahi[s] = *reinterpret_cast<const float4*>(S + a_rd[s][1]);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    alo[s][i] = *reinterpret_cast<const float4*>(S + a_rd[s][0] + i * (32 * 128));
+                    ahi[s][i] = *reinterpret_cast<const float4*>(S + a_rd[s][1] + i * (32 * 128));
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -274,25 +337,32 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
 #endif
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const X3Frag a = x3_split(alo[s], ahi[s]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (NT == 9) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][2], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][1], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][2], acc[j], 0, 0, 0);
+                for (int i = 0; i < RB; ++i) {
+                    const X3Frag a = x3_split(alo[s][i], ahi[s][i]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x16 c = acc[i][j];
+                        if (NT == 9) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][2], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][0], c, 0, 0, 0);
+                        acc[i][j] = c;
                     }
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, bq[s][j][0], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][2], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][1], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, bq[s][j][0], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][1], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, bq[s][j][0], acc[j], 0, 0, 0);
                 }
+            }
             }
             stage = stage + 1 == NST ? 0 : stage + 1;
 #ifdef X3_PHASES
-            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
+            if constexpr (SH16) asm volatile("s_nop 0" ::"v"(acc16[0][0][0]), "v"(acc16[2 * RB - 1][3][3]));
+            else asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[RB - 1][1][15]));
             X3_T(3);
             ++ph_[5];
 #endif
@@ -302,14 +372,27 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_x3_kernel(const ConvPara
         const int em0 = m0, en0 = n0;
         // 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 64 rows per pass
 #pragma unroll
-        for (int pass = 0; pass < WMW / 2; ++pass) {
+        for (int pass = 0; pass < BM / 64; ++pass) {
             __syncthreads();
-            if ((wm >> 1) == pass) {
+            if ((wm * RB) / 2 == pass) {
+                if constexpr (SH16) {            // 16x16 C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float* cw = cbase + ((wm & 1) * 32 + 4 * h) * BN + wn * 64 + 32 * j + r32;
+                    for (int i = 0; i < 2 * RB; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * BN] = acc[j][r];
+                        for (int j = 0; j < 4; ++j) {
+                            float* cw = cbase + (((wm * RB) & 1) * 32 + 16 * i + 4 * g4) * BN + wn * 64 + 16 * j + r16;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cw[r * BN] = acc16[i][j][r];
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float* cw = cbase + ((((wm * RB) & 1) + i) * 32 + 4 * h) * BN + wn * 64 + 32 * j + r32;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * BN] = acc[i][j][r];
+                        }
                 }
             }
             __syncthreads();

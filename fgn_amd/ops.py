@@ -35,7 +35,12 @@ FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 # 'x3' = conv_pw_x3_kernel, every f32 product as six bf16 MFMA products of exact three-way splits, f32 accumulation
 # (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels.
 GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'x3')
-X3_KERNEL = 'conv_pw_x3_kernel<2, 6, 2>'
+X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2>', 128: 'conv_pw_x3_kernel<2, 2, 6, 2>'}    # by row tile (fgn_x3_row_tile)
+
+
+def x3_kernel(rows: int, cout: int, grp_rows: int = 0) -> str:
+    """Name (as rocprofv3 reports it) of the conv_pw_x3_kernel instance a GEMM of this shape is launched on."""
+    return X3_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, grp_rows), 'conv_pw_x3_kernel<?>')
 
 
 class gemm_math:
@@ -256,7 +261,10 @@ class ConvLayer:
 
 
 def _x3_ok(cin: int, cout: int) -> bool:
-    return GEMM_MATH == 'x3' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0
+    """Whether a layer gets a bf16-plane image: the shapes conv_pw_x3_kernel takes and wins on (fgn_x3_row_tile decides per
+    launch; a layer whose 128-column tiles would be under 70 % real channels never passes it)."""
+    npad = (cout + 127) // 128 * 128
+    return GEMM_MATH == 'x3' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout * 10 >= npad * 7
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -332,14 +340,15 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    if layer.w3 is not None and in_scale is None and a_img_div == 1 and tile_hint == 0:
+    if layer.w3 is not None and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
+            L.fgn_x3_row_tile(n_img * ho * wo, layer.cout, 0) > 0:
         rc = L.fgn_conv1x1_x3_nhwc_f32(_ptr(x), layer.w3.data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
                                        _ptr(residual), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad,
                                        int(layer.relu), _stream())
         _lib.check(rc, 'fgn_conv1x1_x3_nhwc_f32')
         if prof is not None:
             flop = 2.0 * ho * wo * layer.cout * cin
-            prof.append(dict(kind='conv', kernel=X3_KERNEL, math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+            prof.append(dict(kind='conv', kernel=x3_kernel(n_img * ho * wo, layer.cout), math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                              n_img=n_img, n_img_dev=n_img_dev, gemm=(1, ho * wo, layer.cout, cin),
                              residual=residual is not None, shape=(n_img, H, W, cin, layer.cout, 1, 1)))
         return out
@@ -491,7 +500,8 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    if layer.w3 is not None:
+    use_x3 = layer.w3 is not None and L.fgn_x3_row_tile(rows, layer.cout, 0) > 0
+    if use_x3:
         rc = L.fgn_conv1x1_dual_x3_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, layer.w3.data_ptr(), _ptr(out),
                                             _ptr(layer.shift), rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad,
                                             int(layer.relu), _stream())
@@ -502,8 +512,8 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     if prof is not None:
         k = layer.cin1 + layer.cin2
         flop = 2.0 * rows * layer.cout * k
-        prof.append(dict(kind='conv', kernel=X3_KERNEL if layer.w3 is not None else 'conv_pw_persist_kernel',
-                         math='x3' if layer.w3 is not None else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+        prof.append(dict(kind='conv', kernel=x3_kernel(rows, layer.cout) if use_x3 else 'conv_pw_persist_kernel',
+                         math='x3' if use_x3 else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                          n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k), residual=False,
                          shape=(1, rows, 1, k, layer.cout, 1, 1)))
     return out
@@ -712,7 +722,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
-    if layer.u3 is not None:
+    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, layer.cout, t_pad) > 0
+    if use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
                                               layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
     else:
@@ -736,8 +747,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
-        prof.append(dict(kind='wg_gemm', kernel=X3_KERNEL if layer.u3 is not None else kernel_name(gid),
-                         math='x3' if layer.u3 is not None else 'f32', e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, layer.cout, t_pad) if use_x3 else kernel_name(gid),
+                         math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, gemm=(G, tiles, layer.cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
@@ -787,7 +798,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
-    if layer.u3 is not None:
+    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, cout, t_pad) > 0
+    if use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), None, 1, total, t_pad, cin, cout,
                                               layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
     else:
@@ -812,8 +824,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
         prof.append(dict(kind='wg_in', kernel='wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false'),
                          e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
-        prof.append(dict(kind='wg_gemm', kernel=X3_KERNEL if layer.u3 is not None else kernel_name(gid),
-                         math='x3' if layer.u3 is not None else 'f32', e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, cout, t_pad) if use_x3 else kernel_name(gid),
+                         math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin,
                          gemm=(G, total, cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel='wg4_output_kernel<%d>' % (vo // 10), e0=ev[2][0], e1=ev[2][1],

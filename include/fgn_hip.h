@@ -108,6 +108,7 @@ int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2
  * grp_rows, image g for group g, first grp_valid rows of a group computed); bm 0 / 64 / 128 and nterms 6 / 9 choose the
  * kernel instance (tests, tools/x3_probe.py). */
 size_t fgn_x3_image_bytes(int K, int npad, int n_groups);
+int fgn_x3_row_tile(long long M, int Cout, int grp_rows);   /* 64 / 128: the kernel instance a launch of this shape runs on */
 int fgn_gemm_x3_f32(const float* x, const void* w_x3, float* y, const float* shift, const float* residual, int rows, int K,
                     int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups, int bm, int nterms,
                     void* stream);

@@ -1,6 +1,6 @@
 """Per-launch roofline table of one cfg3 episode (profiles/rNN_per_launch.csv): every convolution-family launch in
 launch order - kind, device kernel, GEMM shape (groups, rows, N, K), 64x64-tile equivalents, duration, issued GFLOP,
-TF/s, fraction of the 157.3 TF/s fp32 MFMA peak.  The episode runs eagerly on ONE stream with the support branch on the
+TF/s (f32 products), fraction of the 157.3 TF/s f32 MFMA peak and of the pipe the kernel runs on.  The episode runs eagerly on ONE stream with the support branch on the
 caller's stream too, so every launch has the chip to itself (the durations a rocprofv3 kernel trace shows); each launch is
 stamped by its own start / stop events (fgn_profile_next_launch); medians over `reps` episodes.
 usage: per_launch.py out.csv [reps]"""
@@ -41,9 +41,14 @@ for i in range(n):
     g, rows_per, N, K = rec.get('gemm', (0, 0, 0, 0))
     M = rows_per * (cnt if rec['kind'] in ('conv', 'wg_gemm') else 1)
     tiles = g * ((M + 63) // 64) * ((N + 63) // 64) if g else 0
+    # frac: f32 products per second against the f32-input MFMA peak (conv_pw_x3_kernel can exceed 1: it does not run on
+    # that pipe); frac_of_pipe: against the pipe the kernel runs on (x3: six bf16 MFMA products per f32 product / 2500)
+    x3 = rec.get('math') == 'x3'
     rows.append(dict(i=i, kind=rec['kind'], kernel=rec['kernel'], groups=g, M=M, N=N, K=K, tiles64=tiles, us=round(us, 1),
                      gflop=round(fl / 1e9, 2), tflops=round(fl / us / 1e6, 1) if fl else '',
-                     frac=round(fl / us / 1e6 / 157.3, 3) if fl else '', layer_shape='x'.join(str(v) for v in rec['shape'])))
+                     frac=round(fl / us / 1e6 / 157.3, 3) if fl else '',
+                     frac_of_pipe=(round(fl / us / 1e6 * (6 / 2500.0 if x3 else 1 / 157.3), 3) if fl else ''),
+                     layer_shape='x'.join(str(v) for v in rec['shape'])))
     tot_us += us
     tot_fl += fl
 with open(out_csv, 'w', newline='') as fh:

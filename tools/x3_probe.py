@@ -26,22 +26,32 @@ SHAPES = [   # name, groups, rows per group (allocated), valid rows, K, N
 ]
 
 
-def timed(fn, reps):
-    for _ in range(3):
+def timed_round_robin(fns: dict, reps: int, rounds: int = 5) -> dict:
+    """Median over `rounds` of the time per launch of every variant, the variants taking turns (the clock the chip holds
+    depends on what ran just before: one variant after the other ranks them by their place in the queue)."""
+    for fn in fns.values():
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1000.0 / reps
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, fn in fns.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[k].append(e0.elapsed_time(e1) * 1000.0 / reps)
+    return {k: round(sorted(v)[len(v) // 2], 1) for k, v in res.items()}
+
+
+VARIANTS = (('x6_bm64', 64, 6), ('x6_bm64_sh16', 1064, 6), ('x6_bm128', 128, 6), ('x6_bm128_sh16', 1128, 6), ('x9_bm64', 64, 9))
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
     ap.add_argument('--phases', action='store_true', help='phase clocks (FGN_HIP_LIB=tools/micro/libfgn_hip_x3ph.so)')
     args = ap.parse_args()
@@ -57,18 +67,17 @@ def main():
         scale = ref.abs().max().item()
         img = ops.pack_x3(w)
         rec = dict(shape=name, gflop=2.0 * G * valid * K * N / 1e9)
-        outs = {}
-        for tag, bm, nt in (('x6_bm128', 128, 6), ('x6_bm64', 64, 6), ('x9_bm128', 128, 9), ('x9_bm64', 64, 9)):
-            if G > 1 and gr % bm:
+        fns, outs = {}, {}
+        for tag, bm, nt in VARIANTS:
+            if G > 1 and gr % (128 if bm % 1000 >= 128 else 64):
                 continue
             out = torch.zeros(G, gr, N, device=dev)
-            fn = lambda: ops.gemm_x3(x, img, N, shift=shift, groups=G, grp_valid=valid, bm=bm, nterms=nt, out=out)  # noqa: E731
+            fn = (lambda bm=bm, nt=nt, out=out: ops.gemm_x3(x, img, N, shift=shift, groups=G, grp_valid=valid, bm=bm, nterms=nt, out=out))
             fn()
             torch.cuda.synchronize()
             d = (out[:, :valid].double() - ref).abs()
-            outs[tag] = out
-            rec[tag] = dict(us=round(timed(fn, args.reps), 1), max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
-            rec[tag]['tflops_f32_equiv'] = round(rec['gflop'] / rec[tag]['us'] * 1e-3, 1)
+            outs[tag], fns[tag] = out, fn
+            rec[tag] = dict(max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
             if args.phases:
                 import ctypes
                 raw = ctypes.CDLL(ops._lib.LIB_PATH)
@@ -76,16 +85,15 @@ def main():
                 raw.fgn_x3_phases(buf)                      # clear
                 fn()
                 if raw.fgn_x3_phases(buf) == 0:
-                    for b in (0, 1):
-                        v = list(buf[8 * b:8 * b + 7])
-                        steps = max(v[5], 1)
-                        rec[tag]['wg%d_cycles_per_ktile' % b] = dict(
-                            wait_barrier=round(v[0] / steps), issue=round(v[1] / steps), lds_landed=round(v[2] / steps),
-                            split_mfma=round(v[3] / steps), epilogue_per_ktile=round(v[4] / steps), ktiles=v[5],
-                            kernel_cycles=v[6])
-        # the f32 MFMA path: a 1x1 convolution (or the Winograd grouped GEMM entry) on the same operands
+                    v = list(buf[0:7])
+                    steps = max(v[5], 1)
+                    rec[tag]['wg0_cycles_per_ktile'] = dict(
+                        wait_barrier=round(v[0] / steps), issue=round(v[1] / steps), lds_landed=round(v[2] / steps),
+                        split_mfma=round(v[3] / steps), epilogue_per_ktile=round(v[4] / steps), ktiles=v[5], kernel_cycles=v[6])
+        # the f32 MFMA path: a 1x1 convolution packed for it (or the Winograd grouped GEMM entry) on the same operands
         if G == 1:
-            layer = ops.pack_conv(w[0].reshape(N, K, 1, 1), bias=shift).to(dev)
+            with ops.gemm_math('f32'):
+                layer = ops.pack_conv(w[0].reshape(N, K, 1, 1), bias=shift).to(dev)
             xin = x[0].reshape(1, gr, 1, K)
             out = torch.zeros(1, gr, 1, N, device=dev)
             fn = lambda: ops.conv2d(xin, layer, out=out)  # noqa: E731
@@ -103,10 +111,12 @@ def main():
             fn()
             torch.cuda.synchronize()
             d = (out[:, :valid].double() - (ref - shift.double())).abs()
-        rec['f32_mfma'] = dict(us=round(timed(fn, args.reps), 1), max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
-        rec['f32_mfma']['tflops'] = round(rec['gflop'] / rec['f32_mfma']['us'] * 1e-3, 1)
-        if 'x6_bm128' in outs and 'x6_bm64' in outs:
-            rec['bm128_equals_bm64'] = bool(torch.equal(outs['x6_bm128'][:, :valid], outs['x6_bm64'][:, :valid]))
+        rec['f32_mfma'] = dict(max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
+        fns['f32_mfma'] = fn
+        for k, us in timed_round_robin(fns, args.reps).items():
+            rec[k]['us'] = us
+            rec[k]['tflops_f32_equiv'] = round(rec['gflop'] / us * 1e-3, 1)
+        rec['all_x6_equal'] = bool(all(torch.equal(outs['x6_bm64'][:, :valid], o[:, :valid]) for k, o in outs.items() if k.startswith('x6')))
         print(json.dumps(rec), flush=True)
 
 
