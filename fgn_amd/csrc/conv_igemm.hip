@@ -1119,7 +1119,6 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
 // 7 / 3 / 3 % of the pipelined step), a multiple of 8 (XCDs)
 static constexpr int persist_blocks() { return 1024; }
 
-
 // split-K plan for the 64x64 tile: used when the plain grid would leave most of the 256 CUs idle
 static int plan_splits(long long M, int Cout, int KT, int tile_hint, bool pw = false) {
     if (tile_hint < 0) return 1;                         // negative hint: never split (tests)
@@ -1469,7 +1468,6 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
 // carries the bf16-plane image of its weights (w3, w3_bytes, npad3).  bm: 0 = choose, 64 / 128 = force the row tile;
 // nterms 6 (default) or 9.  The persistent grid is 2 workgroups per CU (LDS: 64 / 80 KB per workgroup).
 // ------------------------------------------------------------------------------------------------
-constexpr bool X3_DEFAULT_SH16 = false;      // MFMA shape of the default instances (tools/x3_probe.py decides)
 static int x3_pick_bm(long long M, int Cout, int grp_rows, int bm) {
     if (bm == 64 || bm == 128) return (grp_rows && grp_rows % bm) ? 0 : bm;
     // Automatic choice (bm = 0): 64 rows, or 0 = leave the launch to the f32 MFMA kernels.  Measured per launch of a cfg3
@@ -1512,24 +1510,26 @@ static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     return FGN_OK;
 }
 
-// bm: 0 = choose; 64 = 64 rows (4 waves of 32 x 64, 2 stages, 2 workgroups per CU); 128 = 128 rows as 4 waves of 64 x 64
-// (2 stages, 2 per CU); 129 = 128 rows as 8 waves of 32 x 64 (3 stages, 1 per CU: measured slower, kept for the probe);
-// + 1000: the v_mfma_f32_16x16x32_bf16 form of the 64 / 128 instances
+// bm: 0 = choose (fgn_x3_row_tile), 64 = force the 64-row tile; nterms 6 or 9.  The experiments build (tools/micro/
+// build_experiments.sh) adds the instances that were measured and not chosen (DESIGN Appendix A rows 45-47): 128 = 128
+// rows as 4 waves of 64 x 64, 129 = 128 rows as 8 waves x 3 stages, + 1000 = the v_mfma_f32_16x16x32_bf16 form.
 static int launch_x3(const ConvParams& p0, int M_max, int bm, int nterms, hipStream_t stream) {
     ConvParams p = p0;
     if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
     p.n_tiles_n = cdiv(p.Cout, X3_BN);
-    const bool sh16 = bm >= 1000 ? true : bm == 0 ? X3_DEFAULT_SH16 : false;
-    if (bm >= 1000) bm -= 1000;
-    const int BM = x3_pick_bm(M_max, p.Cout, p.grp_rows, bm == 129 ? 128 : bm);
-    if (BM == 0) return FGN_ERR_SHAPE;
-    if (bm == 129)
-        return nterms == 9 ? launch_x3_cfg<4, 1, 9, 3, false>(p, M_max, stream) : launch_x3_cfg<4, 1, 6, 3, false>(p, M_max, stream);
-    if (nterms == 9)
-        return BM == 128 ? launch_x3_cfg<2, 2, 9, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 9, 2, false>(p, M_max, stream);
-    if (sh16)
-        return BM == 128 ? launch_x3_cfg<2, 2, 6, 2, true>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, true>(p, M_max, stream);
-    return BM == 128 ? launch_x3_cfg<2, 2, 6, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, false>(p, M_max, stream);
+#ifdef FGN_EXPERIMENTS
+    const bool sh16 = bm >= 1000;
+    if (sh16) bm -= 1000;
+    if (bm == 128 || bm == 129) {
+        if (x3_pick_bm(M_max, p.Cout, p.grp_rows, 128) != 128) return FGN_ERR_SHAPE;
+        if (bm == 129) return nterms == 9 ? launch_x3_cfg<4, 1, 9, 3, false>(p, M_max, stream) : launch_x3_cfg<4, 1, 6, 3, false>(p, M_max, stream);
+        return sh16 ? launch_x3_cfg<2, 2, 6, 2, true>(p, M_max, stream) : launch_x3_cfg<2, 2, 6, 2, false>(p, M_max, stream);
+    }
+    if (sh16 && bm == 64 && x3_pick_bm(M_max, p.Cout, p.grp_rows, 64) == 64) return launch_x3_cfg<2, 1, 6, 2, true>(p, M_max, stream);
+#endif
+    if (bm != 0 && bm != 64) return FGN_ERR_SHAPE;
+    if (x3_pick_bm(M_max, p.Cout, p.grp_rows, bm) != 64) return FGN_ERR_SHAPE;
+    return nterms == 9 ? launch_x3_cfg<2, 1, 9, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, false>(p, M_max, stream);
 }
 
 extern "C" size_t fgn_x3_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * K * npad * 6; }

@@ -314,9 +314,10 @@ def test_x3_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     bf16 MFMA products of exact three-way splits, f32 accumulation.  Against fp64 on post-ReLU activations x random
     weights: within 2e-6 of the range like the f32 MFMA kernels, and no further from fp64 than 1.6x the f32 MFMA kernel on
     the same operands (measured r05: 1.2x, for six terms and for nine alike - the difference is the accumulation order
-    inside the matrix pipe, not the dropped terms).  Both row tiles (64 rows x 2 stages, 128 rows x 3 stages) give the
-    same bits; ragged rows / channels, grouped launches with fewer valid rows than a group holds, K of 2 and 3 K-tiles
-    (the ring is as deep as the whole K loop)."""
+    inside the matrix pipe, not the dropped terms).  Ragged rows / channels, grouped launches with fewer valid rows than a
+    group holds, K of 2 and 3 K-tiles.  With FGN_HIP_LIB = the experiments build (tools/micro/build_experiments.sh) the
+    instances that were measured and not chosen run too: the 128-row tiles give the same bits, the 16x16x32 MFMA shape
+    its own; the product library refuses them."""
     from fgn_amd import lib, ops
     g = torch.Generator().manual_seed(groups * 1000 + K + N)
     x = torch.randn(groups, grp_rows, K, generator=g).relu_().cuda()
@@ -331,7 +332,11 @@ def test_x3_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
             continue
         for nt in (6, 9):
             out = torch.full((groups, grp_rows, N), float('nan'), device='cuda')
-            ops.gemm_x3(x, img, N, shift=shift, groups=groups, grp_valid=valid, bm=bm, nterms=nt, out=out)
+            try:
+                ops.gemm_x3(x, img, N, shift=shift, groups=groups, grp_valid=valid, bm=bm, nterms=nt, out=out)
+            except lib.FgnHipError:
+                assert bm != 64          # the instances that were measured and not chosen live in the experiments build only
+                continue
             outs[(bm, nt)] = out
             err = (out[:, :valid].double() - ref).abs().max().item()
             assert err <= 2e-6 * rng, (bm, nt, err / rng)

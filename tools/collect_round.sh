@@ -43,7 +43,7 @@ timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch.csv" 7 > "$OU
 FGN_GEMM_MATH=f32 timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch_f32_mfma.csv" 7 > "$OUT/per_launch_f32.txt" 2>&1; head -8 "$OUT/per_launch_f32.txt" | tail -6
 timeout -k 10 200 tools/micro/gemm_clock 2.5 0 > "$OUT/${R}_gemm_clock.jsonl" 2> "$OUT/gemm_clock.err"; cut -c1-260 "$OUT/${R}_gemm_clock.jsonl"
 # 6. conv_pw_x3_kernel beside the f32 MFMA kernels on the GEMM shapes of an episode (variants take turns), and its phase clocks
-timeout -k 10 400 python tools/x3_probe.py --reps 10 > "$OUT/${R}_x3_probe.jsonl" 2> "$OUT/x3_probe.err"; echo "x3 probe rc $?"
+FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_exp.so timeout -k 10 400 python tools/x3_probe.py --reps 10 > "$OUT/${R}_x3_probe.jsonl" 2> "$OUT/x3_probe.err"; echo "x3 probe rc $?"
 [ -f tools/micro/libfgn_hip_x3ph.so ] && FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_x3ph.so timeout -k 10 300 python tools/x3_probe.py --reps 3 --phases > "$OUT/${R}_x3_phases.jsonl" 2> "$OUT/x3_phases.err"
 # 7. one training step (forward_train + backward of the heads + Adagrad + re-pack; the frozen backbone on the default arithmetic)
 timeout -k 10 400 python tools/train_bench.py --steps 10 --out "$OUT/${R}_train_step.json" > "$OUT/train_bench.log" 2>&1; tail -2 "$OUT/train_bench.log" | cut -c1-300

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """conv_pw_x3_kernel (three-bf16-plane products) against the f32-MFMA kernels: error against fp64 and time per launch on
-the GEMM shapes of a cfg3 episode.  python tools/x3_probe.py [--reps 30]"""
+the GEMM shapes of a cfg3 episode, the variants taking turns.  python tools/x3_probe.py [--reps 10]
+FGN_HIP_LIB=tools/micro/libfgn_hip_exp.so adds the instances that were measured and not chosen (128-row tiles, 16x16x32
+MFMA); FGN_HIP_LIB=tools/micro/libfgn_hip_x3ph.so --phases the phase clocks of one wave."""
 import argparse
 import json
 import os
@@ -73,7 +75,10 @@ def main():
                 continue
             out = torch.zeros(G, gr, N, device=dev)
             fn = (lambda bm=bm, nt=nt, out=out: ops.gemm_x3(x, img, N, shift=shift, groups=G, grp_valid=valid, bm=bm, nterms=nt, out=out))
-            fn()
+            try:
+                fn()
+            except ops._lib.FgnHipError:        # an instance of the experiments build (FGN_HIP_LIB=tools/micro/libfgn_hip_exp.so)
+                continue
             torch.cuda.synchronize()
             d = (out[:, :valid].double() - ref).abs()
             outs[tag], fns[tag] = out, fn
