@@ -655,13 +655,18 @@ def main():
 
     # ---- the dominant kernel over the WHOLE timed window: the launch records inside the captured graphs --------------
     window = None
-    sites = [rec for rec in records_med if rec['kernel'] == dom_name]
+    # launch records are handed out in launch order to every launch of the two persistent GEMM kernels (f32 and x3)
+    takes_record = lambda rec: rec['kernel'] == 'conv_pw_persist_kernel' or rec['kernel'].startswith('conv_pw_x3_kernel')
+    rec_sites = [rec for rec in records_med if takes_record(rec)]
+    keep = [i for i, rec in enumerate(rec_sites) if rec['kernel'] == dom_name]
+    sites = [rec_sites[i] for i in keep]
     if model.use_graphs and sites and (dom_name == 'conv_pw_persist_kernel' or dom_x3):
         per_site = [dict(executions=0, total_us=0.0, min_us=None, max_us=None) for _ in sites]
         # (a graph whose captured launch sequence does not have the isolated step's launch sites cannot be matched)
-        ok = bool(graphs) and all(ge.stamps is not None and ge.stamp_count == len(sites) for ge in graphs)
+        ok = bool(graphs) and all(ge.stamps is not None and ge.stamp_count == len(rec_sites) for ge in graphs)
         for ge in graphs if ok else []:
-            for a, b in zip(per_site, ops.read_stamps(ge.stamps, ge.stamp_count)):
+            all_recs = ops.read_stamps(ge.stamps, ge.stamp_count)
+            for a, b in zip(per_site, [all_recs[i] for i in keep]):
                 a['executions'] += b['executions']
                 a['total_us'] += b['total_us']
                 if b['executions']:

@@ -35,7 +35,7 @@ FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 # 'x3' = conv_pw_x3_kernel, every f32 product as six bf16 MFMA products of exact three-way splits, f32 accumulation
 # (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels.
 GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'x3')
-X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2>', 128: 'conv_pw_x3_kernel<2, 2, 6, 2>'}    # by row tile (fgn_x3_row_tile)
+X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2, false>'}    # by row tile (fgn_x3_row_tile); <waves along M, row blocks, terms, stages, 16x16x32>
 
 
 def x3_kernel(rows: int, cout: int, grp_rows: int = 0) -> str:
