@@ -1468,18 +1468,25 @@ extern "C" int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const 
 // carries the bf16-plane image of its weights (w3, w3_bytes, npad3).  bm: 0 = choose, 64 / 128 = force the row tile;
 // nterms 6 (default) or 9.  The persistent grid is 2 workgroups per CU (LDS: 64 / 80 KB per workgroup).
 // ------------------------------------------------------------------------------------------------
-static int x3_pick_bm(long long M, int Cout, int grp_rows, int bm) {
+// Row tile of a launch: M rows in all (grouped: `groups` x grp_rows, the first `valid` rows of a group computed), K deep.
+// bm 64 / 128: forced (tests, tools); 0: chosen - 128, 64, or 0 = leave the launch to the f32 MFMA kernels.  Measured per
+// launch of a cfg3 episode, both arithmetics on one box (tools/per_launch.py, tools/x3_probe.py):
+//  * the 128-column tile loses where much of it is padding (Cout 64: 37 -> 48-53 us; Cout 76: 35.6 -> 39.0), and a launch of
+//    a few dozen tiles loses to the f32 path's split-K (441 x 512 x 1024: 9.6 -> 30.6 us); from ~200 tiles on it wins;
+//  * 128 rows (4 waves of 64 x 64) beat 64 rows by 5-8 % on the large, deep GEMMs (relation Q 173 -> 162.5 us, the 300-RoI
+//    Winograd GEMM 143.7 -> 132.7) and lose 5-50 % where the launch has few tiles, a shallow K loop or rows that fill
+//    128-row tiles badly (400 valid rows: 59.8 -> 66.8).
+static int x3_pick_bm(long long M, int Cout, int K, int grp_rows, int grp_valid, int bm) {
     if (bm == 64 || bm == 128) return (grp_rows && grp_rows % bm) ? 0 : bm;
-    // Automatic choice (bm = 0): 64 rows, or 0 = leave the launch to the f32 MFMA kernels.  Measured per launch of a cfg3
-    // episode, both forms on one box (r05 call 15, tools/per_launch.py): the 128-column tile loses where half of it is
-    // padding (Cout 64: 37 -> 48-53 us; Cout 76: 35.6 -> 39.0), and a launch of a few dozen tiles loses to the f32
-    // path's split-K (441 x 512 x 1024: 9.6 -> 30.6 us; 147 x 1024 x 1024: 10.1 -> 32.0); from ~200 tiles on it wins
-    // (204 tiles: 35.9 -> 32.4; 264: 53.0 -> 45.0).  The 128-row tiles (4 waves of 64 x 64, or 8 waves x 3 stages) measure
-    // equal on the large GEMMs and slower on the small ones (tools/x3_probe.py): not chosen.
     if (grp_rows && grp_rows % 64) return 0;
     const int nt = cdiv(Cout, X3_BN);
     if (Cout * 10 < nt * X3_BN * 7) return 0;
     if (((M + 63) / 64) * nt < 192) return 0;
+    const long long groups = grp_rows ? M / grp_rows : 1;
+    const long long valid = grp_rows ? std::min<long long>(grp_valid > 0 ? grp_valid : grp_rows, grp_rows) : M;
+    const long long rows64 = (valid + 63) / 64 * 64, rows128 = (valid + 127) / 128 * 128;
+    if (K >= 256 && (!grp_rows || grp_rows % 128 == 0) && rows128 * 100 <= rows64 * 108 && groups * (rows128 / 128) * nt >= 400)
+        return 128;
     return 64;
 }
 
@@ -1510,32 +1517,39 @@ static int launch_x3_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     return FGN_OK;
 }
 
-// bm: 0 = choose (fgn_x3_row_tile), 64 = force the 64-row tile; nterms 6 or 9.  The experiments build (tools/micro/
-// build_experiments.sh) adds the instances that were measured and not chosen (DESIGN Appendix A rows 45-47): 128 = 128
-// rows as 4 waves of 64 x 64, 129 = 128 rows as 8 waves x 3 stages, + 1000 = the v_mfma_f32_16x16x32_bf16 form.
+// bm: 0 = choose (fgn_x3_row_tile), 64 / 128 = force the row tile; nterms 6 or 9 (nine: 64-row tile only).  The product
+// instances use v_mfma_f32_16x16x32_bf16 (weight image of ops.pack_x3).  The experiments build (tools/micro/
+// build_experiments.sh) adds what was measured and not chosen (DESIGN Appendix A rows 45-47): bm + 2000 = the
+// v_mfma_f32_32x32x16_bf16 form of the 64 / 128-row tiles (image of ops.pack_x3(mfma32=True)), 2129 = 128 rows as 8 waves
+// x 3 stages in that form.
 static int launch_x3(const ConvParams& p0, int M_max, int bm, int nterms, hipStream_t stream) {
     ConvParams p = p0;
     if (!p.w3 || p.npad3 % X3_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
     p.n_tiles_n = cdiv(p.Cout, X3_BN);
 #ifdef FGN_EXPERIMENTS
-    const bool sh16 = bm >= 1000;
-    if (sh16) bm -= 1000;
-    if (bm == 128 || bm == 129) {
-        if (x3_pick_bm(M_max, p.Cout, p.grp_rows, 128) != 128) return FGN_ERR_SHAPE;
-        if (bm == 129) return nterms == 9 ? launch_x3_cfg<4, 1, 9, 3, false>(p, M_max, stream) : launch_x3_cfg<4, 1, 6, 3, false>(p, M_max, stream);
-        return sh16 ? launch_x3_cfg<2, 2, 6, 2, true>(p, M_max, stream) : launch_x3_cfg<2, 2, 6, 2, false>(p, M_max, stream);
+    if (bm >= 2000) {
+        const int b = bm - 2000;
+        if (x3_pick_bm(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, b == 129 ? 128 : b) == 0) return FGN_ERR_SHAPE;
+        if (b == 129) return nterms == 9 ? launch_x3_cfg<4, 1, 9, 3, false>(p, M_max, stream) : launch_x3_cfg<4, 1, 6, 3, false>(p, M_max, stream);
+        if (b == 128) return launch_x3_cfg<2, 2, 6, 2, false>(p, M_max, stream);
+        if (b == 64) return nterms == 9 ? launch_x3_cfg<2, 1, 9, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, false>(p, M_max, stream);
+        return FGN_ERR_SHAPE;
     }
-    if (sh16 && bm == 64 && x3_pick_bm(M_max, p.Cout, p.grp_rows, 64) == 64) return launch_x3_cfg<2, 1, 6, 2, true>(p, M_max, stream);
 #endif
-    if (bm != 0 && bm != 64) return FGN_ERR_SHAPE;
-    if (x3_pick_bm(M_max, p.Cout, p.grp_rows, bm) != 64) return FGN_ERR_SHAPE;
-    return nterms == 9 ? launch_x3_cfg<2, 1, 9, 2, false>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, false>(p, M_max, stream);
+    if (bm != 0 && bm != 64 && bm != 128) return FGN_ERR_SHAPE;
+    const int BM = x3_pick_bm(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, bm);
+    if (BM == 0) return FGN_ERR_SHAPE;
+    if (nterms == 9) return BM == 64 ? launch_x3_cfg<2, 1, 9, 2, true>(p, M_max, stream) : FGN_ERR_SHAPE;
+    return BM == 128 ? launch_x3_cfg<2, 2, 6, 2, true>(p, M_max, stream) : launch_x3_cfg<2, 1, 6, 2, true>(p, M_max, stream);
 }
 
 extern "C" size_t fgn_x3_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * K * npad * 6; }
-// the row tile launch_x3 chooses for a GEMM of M rows (grouped: grp_rows per group): 64, or 0 = not supported / not
-// profitable: the caller then uses the f32 MFMA entry point (the x3 entry points return FGN_ERR_SHAPE for such a launch)
-extern "C" int fgn_x3_row_tile(long long M, int Cout, int grp_rows) { return x3_pick_bm(M, Cout, grp_rows, 0); }
+// the row tile launch_x3 chooses for a GEMM of M rows x K (grouped: grp_rows per group, grp_valid of them computed; 0, 0
+// otherwise): 64 / 128, or 0 = not supported / not profitable: the caller then uses the f32 MFMA entry point (the x3 entry
+// points return FGN_ERR_SHAPE for such a launch)
+extern "C" int fgn_x3_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid) {
+    return x3_pick_bm(M, Cout, K, grp_rows, grp_valid, 0);
+}
 
 #ifdef X3_PHASES        // tools/micro/build_x3_phases.sh: phase clocks of wave 0 of workgroups 0 / 1 (conv_pw_x3.h)
 static unsigned long long* g_x3_ph = nullptr;
@@ -1660,11 +1674,11 @@ extern "C" int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float*
 // The 16 / 36 GEMMs of a Winograd F(2x2,3x3) / F(4x4,3x3) convolution (winograd.hip holds the transforms):
 //   Mo[g][t][n] = sum_c V[g][t][c] * U[g][n][c],   g = position in the 4x4 / 6x6 transformed tile
 // run as ONE launch of the 64x64 kernel in point-wise mode over the stacked rows [n_groups * t_pad] with a
-// per-group weight matrix.  t_pad is a multiple of the 64-row tile so no tile straddles two groups; 1600 tiles
-// (100 RoIs x 16) and 4800 (300 RoIs) need no padding at all.  (A grouped 128x128 persistent variant measured
+// per-group weight matrix.  t_pad is a multiple of 128 rows so no 64- or 128-row tile straddles two groups (rows past the
+// valid count of a group are skipped tile-wise).  (A grouped 128x128 persistent variant measured
 // equal on the AG-RPN GEMM and 5 % slower on the 300-RoI one, and much slower on everything smaller.)
 // ------------------------------------------------------------------------------------------------
-extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 63) / 64 * 64; }
+extern "C" int fgn_winograd_t_pad(int tiles_total) { return (tiles_total + 127) / 128 * 128; }   // whole 64- and 128-row tiles per group
 
 extern "C" int fgn_winograd_gemm_f32(const float* V, const float* U, float* Mo, const int32_t* n_img_dev, int n_img,
                                      int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,

@@ -58,7 +58,7 @@ SIGNATURES = {
                                             _f, _i, _f, _f, _i, _p]),
     'fgn_conv1x1_dual_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_x3_image_bytes': (C.c_size_t, [_i, _i, _i]),
-    'fgn_x3_row_tile': (_i, [C.c_longlong, _i, _i]),
+    'fgn_x3_row_tile': (_i, [C.c_longlong, _i, _i, _i, _i]),
     'fgn_conv1x1_x3_nhwc_f32': (_i, [_p] * 7 + [_i] * 7 + [_p]),
     'fgn_conv1x1_dual_x3_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_gemm_x3_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -99,7 +99,7 @@ SIGNATURES = {
     'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 _lib = None
 
 

@@ -35,12 +35,13 @@ FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 # 'x3' = conv_pw_x3_kernel, every f32 product as six bf16 MFMA products of exact three-way splits, f32 accumulation
 # (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels.
 GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'x3')
-X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2, false>'}    # by row tile (fgn_x3_row_tile); <waves along M, row blocks, terms, stages, 16x16x32>
+# by row tile (fgn_x3_row_tile); template arguments: waves along M, 32-row blocks per wave, terms, LDS stages, 16x16x32 MFMA
+X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2, true>', 128: 'conv_pw_x3_kernel<2, 2, 6, 2, true>'}
 
 
-def x3_kernel(rows: int, cout: int, grp_rows: int = 0) -> str:
+def x3_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0) -> str:
     """Name (as rocprofv3 reports it) of the conv_pw_x3_kernel instance a GEMM of this shape is launched on."""
-    return X3_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, grp_rows), 'conv_pw_x3_kernel<?>')
+    return X3_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_x3_kernel<?>')
 
 
 class gemm_math:
@@ -341,14 +342,14 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     if prof is not None:
         e0, e1 = prof.arm()
     if layer.w3 is not None and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
-            L.fgn_x3_row_tile(n_img * ho * wo, layer.cout, 0) > 0:
+            x.numel() * 4 < 0x7fffff00 and out.numel() < (1 << 31) and L.fgn_x3_row_tile(n_img * ho * wo, layer.cout, cin, 0, 0) > 0:
         rc = L.fgn_conv1x1_x3_nhwc_f32(_ptr(x), layer.w3.data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
                                        _ptr(residual), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad,
                                        int(layer.relu), _stream())
         _lib.check(rc, 'fgn_conv1x1_x3_nhwc_f32')
         if prof is not None:
             flop = 2.0 * ho * wo * layer.cout * cin
-            prof.append(dict(kind='conv', kernel=x3_kernel(n_img * ho * wo, layer.cout), math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+            prof.append(dict(kind='conv', kernel=x3_kernel(n_img * ho * wo, layer.cout, cin), math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                              n_img=n_img, n_img_dev=n_img_dev, gemm=(1, ho * wo, layer.cout, cin),
                              residual=residual is not None, shape=(n_img, H, W, cin, layer.cout, 1, 1)))
         return out
@@ -373,11 +374,14 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     return out
 
 
-def pack_x3(w: torch.Tensor) -> torch.Tensor:
+def pack_x3(w: torch.Tensor, mfma32: bool = False) -> torch.Tensor:
     """w [G, N, K] (or [N, K]) f32 -> the weight image of ``conv_pw_x3_kernel`` (csrc/conv_pw_x3.h): every value as the
     EXACT sum of three bf16 values (p1 = w with the low 16 bits cleared, p2 the same of w - p1, p3 = w - p1 - p2), laid
-    out [G][K / 32][plane][Npad][32] bf16 with N padded to 128 and the four 16-byte chunks of a 64-byte row XOR-ed with
-    (n >> 2) & 3 - tile by tile the LDS image the kernel's LDS-DMA writes.  uint8 tensor on w's device."""
+    out [G][K / 32][plane][Npad][32] bf16 with N padded to 128, the k order inside a K-tile that of the kernel's MFMA
+    operand (chunk g = k 4g..4g+3, 16+4g..16+4g+3) and the four 16-byte chunks of a 64-byte row XOR-ed with
+    tau[(n >> 2) & 3], tau = (0, 3, 2, 1) - tile by tile the LDS image the kernel's LDS-DMA writes, conflict-free for its
+    ds_read_b128.  ``mfma32``: the image of the v_mfma_f32_32x32x16_bf16 instances of the experiments build (k in order,
+    XOR with (n >> 2) & 3).  uint8 tensor on w's device."""
     w = w.detach().float()
     if w.dim() == 2:
         w = w[None]
@@ -394,9 +398,17 @@ def pack_x3(w: torch.Tensor) -> torch.Tensor:
         planes.append((hi.view(torch.int32) >> 16).to(torch.int16))
         r = r - hi                                     # exact: hi holds the leading bits of r
     pl = torch.stack(planes, 1)                        # [G, 3, npad, K] bf16 bit patterns
-    pl = pl.view(G, 3, npad, K // 32, 4, 8)            # K -> (K-tile, chunk, 8)
+    sh16 = not mfma32
+    if sh16:      # v_mfma_f32_16x16x32_bf16: lane group g reads the f32 chunks g and g + 4 of an activation row (conflict-free
+        # in ds_read_b128's lane groups), so chunk g of a weight row holds k = 4g..4g+3, 16+4g..16+4g+3 of the K-tile
+        korder = torch.tensor([4 * g + j if j < 4 else 16 + 4 * g + j - 4 for g in range(4) for j in range(8)], device=w.device)
+        pl = pl.view(G, 3, npad, K // 32, 32)[..., korder]
+    pl = pl.reshape(G, 3, npad, K // 32, 4, 8)         # K -> (K-tile, chunk, 8)
     n = torch.arange(npad, device=w.device)
-    src = torch.arange(4, device=w.device)[None, :] ^ ((n[:, None] >> 2) & 3)          # physical chunk c holds logical c ^ swz
+    swz = (n >> 2) & 3
+    if sh16:
+        swz = torch.tensor([0, 3, 2, 1], device=w.device)[swz]
+    src = torch.arange(4, device=w.device)[None, :] ^ swz[:, None]                       # physical chunk c holds logical c ^ swz
     pl = torch.gather(pl, 4, src[None, None, :, None, :, None].expand(G, 3, npad, K // 32, 4, 8))
     img = pl.permute(0, 3, 1, 2, 4, 5).contiguous()    # [G, KT, 3, npad, 4, 8]
     return img.view(torch.uint8).reshape(-1)
@@ -500,7 +512,7 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    use_x3 = layer.w3 is not None and L.fgn_x3_row_tile(rows, layer.cout, 0) > 0
+    use_x3 = layer.w3 is not None and max(x1.numel(), x2.numel()) * 4 < 0x7fffff00 and L.fgn_x3_row_tile(rows, layer.cout, layer.cin1 + layer.cin2, 0, 0) > 0
     if use_x3:
         rc = L.fgn_conv1x1_dual_x3_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, layer.w3.data_ptr(), _ptr(out),
                                             _ptr(layer.shift), rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad,
@@ -512,7 +524,7 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     if prof is not None:
         k = layer.cin1 + layer.cin2
         flop = 2.0 * rows * layer.cout * k
-        prof.append(dict(kind='conv', kernel=x3_kernel(rows, layer.cout) if use_x3 else 'conv_pw_persist_kernel',
+        prof.append(dict(kind='conv', kernel=x3_kernel(rows, layer.cout, layer.cin1 + layer.cin2) if use_x3 else 'conv_pw_persist_kernel',
                          math='x3' if use_x3 else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                          n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k), residual=False,
                          shape=(1, rows, 1, k, layer.cout, 1, 1)))
@@ -722,7 +734,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
-    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, layer.cout, t_pad) > 0
+    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) > 0
     if use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
                                               layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
@@ -747,7 +759,7 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
-        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, layer.cout, t_pad) if use_x3 else kernel_name(gid),
+        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) if use_x3 else kernel_name(gid),
                          math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, gemm=(G, tiles, layer.cout, cin), **common))
@@ -798,7 +810,7 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
-    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, cout, t_pad) > 0
+    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, cout, cin, t_pad, total) > 0
     if use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), None, 1, total, t_pad, cin, cout,
                                               layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
@@ -824,7 +836,7 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
         prof.append(dict(kind='wg_in', kernel='wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false'),
                          e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
-        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, cout, t_pad) if use_x3 else kernel_name(gid),
+        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, cout, cin, t_pad, total) if use_x3 else kernel_name(gid),
                          math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin,
                          gemm=(G, total, cout, cin), **common))

@@ -108,7 +108,7 @@ int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2
  * grp_rows, image g for group g, first grp_valid rows of a group computed); bm 0 / 64 / 128 and nterms 6 / 9 choose the
  * kernel instance (tests, tools/x3_probe.py). */
 size_t fgn_x3_image_bytes(int K, int npad, int n_groups);
-int fgn_x3_row_tile(long long M, int Cout, int grp_rows);   /* 64 / 128: the kernel instance a launch of this shape runs on */
+int fgn_x3_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid);   /* 64 / 128: the kernel instance a launch of this shape runs on; 0: use the f32 entry point */
 int fgn_gemm_x3_f32(const float* x, const void* w_x3, float* y, const float* shift, const float* residual, int rows, int K,
                     int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups, int bm, int nterms,
                     void* stream);
@@ -138,7 +138,7 @@ int fgn_conv2d_pair_nhwc_f32(const float* x0, float* y0, int n_img0, int H0, int
  *   fgn_winograd_gemm_f32    Mo[g] = V[g] U[g]^T for the 16 tile positions, one MFMA launch (64x64 kernel,
  *                            per-group weights); U [16][cout_pad][Cin] = G w G^T (host-packed, BN scale folded)
  *   fgn_winograd_output_f32  y = A^T Mo A + shift (ReLU), y [n_img,H,W,Cout]
- * tiles per image = ceil(H/2)*ceil(W/2); t_pad = fgn_winograd_t_pad(n_img*tiles) (multiple of the 64-row tile).
+ * tiles per image = ceil(H/2)*ceil(W/2); t_pad = fgn_winograd_t_pad(n_img*tiles) (a multiple of 128 rows: whole GEMM tiles per group).
  * Image i reads x[i / a_img_div]; in_scale [n_img][C] optional (AG-RPN guidance, fgn_ag_rpn_head.py:44; mask
  * guidance, fgn_roi_head.py:379). */
 int fgn_winograd_input_f32(const float* x, const float* in_scale, float* V, const int32_t* n_img_dev, int n_img,

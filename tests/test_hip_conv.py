@@ -315,9 +315,9 @@ def test_x3_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     weights: within 2e-6 of the range like the f32 MFMA kernels, and no further from fp64 than 1.6x the f32 MFMA kernel on
     the same operands (measured r05: 1.2x, for six terms and for nine alike - the difference is the accumulation order
     inside the matrix pipe, not the dropped terms).  Ragged rows / channels, grouped launches with fewer valid rows than a
-    group holds, K of 2 and 3 K-tiles.  With FGN_HIP_LIB = the experiments build (tools/micro/build_experiments.sh) the
-    instances that were measured and not chosen run too: the 128-row tiles give the same bits, the 16x16x32 MFMA shape
-    its own; the product library refuses them."""
+    group holds, K of 2 and 3 K-tiles; the 64- and the 128-row tile give the same bits.  With FGN_HIP_LIB = the experiments
+    build (tools/micro/build_experiments.sh) the 32x32x16 MFMA instances run too (their own bits, their own weight image);
+    the product library refuses them."""
     from fgn_amd import lib, ops
     g = torch.Generator().manual_seed(groups * 1000 + K + N)
     x = torch.randn(groups, grp_rows, K, generator=g).relu_().cuda()
@@ -325,29 +325,32 @@ def test_x3_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     shift = torch.randn(N, generator=g).cuda()
     ref = torch.einsum('grk,gnk->grn', x[:, :valid].double(), w.double()) + shift.double()
     rng = ref.abs().max().item()
-    img = ops.pack_x3(w)
+    img16, img32 = ops.pack_x3(w), ops.pack_x3(w, mfma32=True)
     outs = {}
-    for bm in (64, 128, 129, 1064, 1128):           # 129: eight waves x three stages (probe form); + 1000: 16x16x32 MFMA
-        if groups > 1 and grp_rows % min(bm % 1000, 128):
+    for bm in (64, 128, 2064, 2128, 2129):          # + 2000: the 32x32x16 MFMA form (experiments build); 129: 8 waves x 3 stages
+        img = img32 if bm >= 2000 else img16
+        tile = min(bm % 1000, 128)
+        if groups > 1 and grp_rows % tile:
             continue
         for nt in (6, 9):
             out = torch.full((groups, grp_rows, N), float('nan'), device='cuda')
             try:
                 ops.gemm_x3(x, img, N, shift=shift, groups=groups, grp_valid=valid, bm=bm, nterms=nt, out=out)
             except lib.FgnHipError:
-                assert bm != 64          # the instances that were measured and not chosen live in the experiments build only
+                # the 32x32x16 instances live in the experiments build only; nine terms exist for the 64-row tile
+                assert bm >= 2000 or (bm == 128 and nt == 9)
                 continue
             outs[(bm, nt)] = out
             err = (out[:, :valid].double() - ref).abs().max().item()
             assert err <= 2e-6 * rng, (bm, nt, err / rng)
             # rows of whole tiles past the last valid one of a group are not written
-            last = -(-valid // min(bm % 1000, 128)) * min(bm % 1000, 128)
+            last = -(-valid // tile) * tile
             assert torch.isnan(out[:, last:]).all()
-    for bm in (128, 129):                           # the same MFMA shape: the same bits whatever the tile
+    if (128, 6) in outs:                            # one MFMA shape: the same bits whatever the row tile
+        assert torch.equal(outs[(64, 6)][:, :valid], outs[(128, 6)][:, :valid])
+    for bm in (2128, 2129):
         if (bm, 6) in outs:
-            assert torch.equal(outs[(64, 6)][:, :valid], outs[(bm, 6)][:, :valid])
-    if (1128, 6) in outs:
-        assert torch.equal(outs[(1064, 6)][:, :valid], outs[(1128, 6)][:, :valid])
+            assert torch.equal(outs[(2064, 6)][:, :valid], outs[(bm, 6)][:, :valid])
     # the f32 MFMA kernel on the same operands
     if groups == 1:
         with ops.gemm_math('f32'):
@@ -373,7 +376,7 @@ def test_x3_gemm_epilogue_and_special_values():
     below that the third plane underflows, far under any activation); rows past M untouched.  (bm = 64: the automatic
     choice leaves a launch this small, half of whose 128 columns are padding, to the f32 kernels.)"""
     from fgn_amd import lib
-    assert lib.load().fgn_x3_row_tile(1000, 64, 0) == 0 and lib.load().fgn_x3_row_tile(14700, 1024, 0) == 64
+    assert lib.load().fgn_x3_row_tile(1000, 64, 128, 0, 0) == 0 and lib.load().fgn_x3_row_tile(14700, 1024, 1024, 0, 0) == 128
     from fgn_amd import ops
     g = torch.Generator().manual_seed(3)
     rows, K, N = 1000, 128, 64

@@ -873,23 +873,55 @@ def test_episodic_sampler_matches_the_reference_on_its_own_databag(golden_dir):
 def test_x3_weight_image_is_an_exact_three_way_split():
     """``ops.pack_x3``: every f32 weight is the exact sum of its three bf16 planes (the low 16 bits of each plane's f32
     form are zero, plane by plane the leading bits of what the planes before left), laid out [G][K/32][3][Npad][32] with
-    the 16-byte chunks of a row XOR-ed by (n >> 2) & 3 and zero rows up to a multiple of 128."""
+    zero rows up to a multiple of 128; inside a K-tile chunk g holds k = 4g..4g+3, 16+4g..16+4g+3 and the 16-byte chunks of
+    a row are XOR-ed with tau[(n >> 2) & 3], tau = (0, 3, 2, 1) (the 32x32x16 form of the experiments build: k in order,
+    XOR with (n >> 2) & 3)."""
     import torch
     from fgn_amd import ops
     g = torch.Generator().manual_seed(0)
     w = torch.randn(2, 200, 96, generator=g) * torch.logspace(-30, 20, 96)[None, None, :]
     w[0, 5, 7] = 0.0
-    img = ops.pack_x3(w)
     G, N, K = w.shape
     npad = 256
-    assert img.dtype == torch.uint8 and img.numel() == G * K * npad * 6
-    pl = img.view(torch.int16).view(G, K // 32, 3, npad, 4, 8).permute(0, 2, 3, 1, 4, 5)       # G, plane, n, kt, chunk, 8
     n = torch.arange(npad)
-    idx = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)                                  # logical chunk -> physical
-    pl = torch.gather(pl, 4, idx[None, None, :, None, :, None].expand(G, 3, npad, K // 32, 4, 8))
-    planes = (pl.to(torch.int32) << 16).view(torch.float32).reshape(G, 3, npad, K)
-    assert torch.equal(planes.double().sum(1)[:, :N], w.double())                             # exact
-    assert (planes[:, :, N:] == 0).all()
-    p1, p2, p3 = planes[:, 0, :N], planes[:, 1, :N], planes[:, 2, :N]
-    assert ((p2.abs() <= p1.abs() * 2.0 ** -7) | (p1 == 0)).all() and ((p3.abs() <= p1.abs() * 2.0 ** -15) | (p1 == 0)).all()
-    assert (torch.sign(p2) * torch.sign(p1) >= 0).all() and (torch.sign(p3) * torch.sign(p1) >= 0).all()
+    for mfma32 in (False, True):
+        img = ops.pack_x3(w, mfma32=mfma32)
+        assert img.dtype == torch.uint8 and img.numel() == G * K * npad * 6
+        pl = img.view(torch.int16).view(G, K // 32, 3, npad, 4, 8).permute(0, 2, 3, 1, 4, 5)       # G, plane, n, kt, chunk, 8
+        swz = (n >> 2) & 3
+        if not mfma32:
+            swz = torch.tensor([0, 3, 2, 1])[swz]
+        idx = torch.arange(4)[None, :] ^ swz[:, None]                                             # logical chunk -> physical
+        pl = torch.gather(pl, 4, idx[None, None, :, None, :, None].expand(G, 3, npad, K // 32, 4, 8))
+        pl = pl.reshape(G, 3, npad, K // 32, 32)
+        if not mfma32:          # position 8g + j of a K-tile holds k = 4g + j (j < 4), 16 + 4g + j - 4 (j >= 4)
+            korder = torch.tensor([4 * q + j if j < 4 else 16 + 4 * q + j - 4 for q in range(4) for j in range(8)])
+            inv = torch.empty(32, dtype=torch.long)
+            inv[korder] = torch.arange(32)
+            pl = pl[..., inv]
+        planes = (pl.reshape(G, 3, npad, K).to(torch.int32) << 16).view(torch.float32)
+        assert torch.equal(planes.double().sum(1)[:, :N], w.double())                             # exact
+        assert (planes[:, :, N:] == 0).all()
+        p1, p2, p3 = planes[:, 0, :N], planes[:, 1, :N], planes[:, 2, :N]
+        assert ((p2.abs() <= p1.abs() * 2.0 ** -7) | (p1 == 0)).all() and ((p3.abs() <= p1.abs() * 2.0 ** -15) | (p1 == 0)).all()
+        assert (torch.sign(p2) * torch.sign(p1) >= 0).all() and (torch.sign(p3) * torch.sign(p1) >= 0).all()
+
+
+def test_x3_routing_rule_is_host_logic():
+    """``fgn_x3_row_tile`` (no GPU involved): which GEMM-shaped launches go to conv_pw_x3_kernel and on which row tile - at
+    least 192 tiles of 64 x 128 and at least 70 % real channels in its 128-column tiles; the 128-row tile for the large,
+    deep GEMMs whose rows fill it (measured per launch of a cfg3 episode, both arithmetics on one box)."""
+    from fgn_amd import lib
+    L = lib.load()
+    assert L.fgn_x3_row_tile(14700, 1024, 1024, 0, 0) == 128             # relation Q
+    assert L.fgn_x3_row_tile(36 * 1280, 512, 512, 1280, 1236) == 128     # Winograd GEMM of 300 + 9 RoIs
+    assert L.fgn_x3_row_tile(36 * 896, 1024, 1024, 896, 819) == 128      # AG-RPN: 819 rows fill seven 128-row tiles to 91 %
+    assert L.fgn_x3_row_tile(36 * 512, 512, 512, 512, 400) == 64         # mask head: 400 rows would waste a quarter of four
+    assert L.fgn_x3_row_tile(25916, 512, 128, 0, 0) == 64                # a shallow K loop
+    assert L.fgn_x3_row_tile(103664, 64, 256, 0, 0) == 0                 # layer1 conv1: half of every tile would be padding
+    assert L.fgn_x3_row_tile(12600, 76, 1024, 0, 0) == 0                 # RPN head: 76 of 128 columns
+    assert L.fgn_x3_row_tile(441, 512, 1024, 0, 0) == 0                  # 9 support RoIs: 28 tiles - the f32 path splits K instead
+    assert L.fgn_x3_row_tile(6504, 256, 1024, 0, 0) == 64                # 204 tiles
+    assert L.fgn_x3_row_tile(36 * 100, 512, 512, 100, 100) == 0          # a group that is not a whole number of 64-row tiles
+    assert L.fgn_x3_image_bytes(1024, 1024, 36) == 36 * 1024 * 1024 * 6
+    assert L.fgn_winograd_t_pad(819) == 896 and L.fgn_winograd_t_pad(1280) == 1280

@@ -48,7 +48,9 @@ def timed_round_robin(fns: dict, reps: int, rounds: int = 5) -> dict:
     return {k: round(sorted(v)[len(v) // 2], 1) for k, v in res.items()}
 
 
-VARIANTS = (('x6_bm64', 64, 6), ('x6_bm64_sh16', 1064, 6), ('x6_bm128', 128, 6), ('x6_bm128_sh16', 1128, 6), ('x9_bm64', 64, 9))
+# default instances (16x16x32 MFMA): 64 / 128 rows, nine terms; + 2000: the 32x32x16 form (experiments build)
+VARIANTS = (('x6_bm64', 64, 6), ('x6_bm128', 128, 6), ('x9_bm64', 64, 9), ('x6_bm64_mfma32', 2064, 6), ('x6_bm128_mfma32', 2128, 6),
+            ('x6_bm129_mfma32', 2129, 6))
 
 
 def main():
@@ -68,13 +70,15 @@ def main():
         ref = torch.einsum('grk,gnk->grn', x[:, :valid].double(), w.double()) + shift.double()
         scale = ref.abs().max().item()
         img = ops.pack_x3(w)
+        img32 = ops.pack_x3(w, mfma32=True)
         rec = dict(shape=name, gflop=2.0 * G * valid * K * N / 1e9)
         fns, outs = {}, {}
         for tag, bm, nt in VARIANTS:
             if G > 1 and gr % (128 if bm % 1000 >= 128 else 64):
                 continue
             out = torch.zeros(G, gr, N, device=dev)
-            fn = (lambda bm=bm, nt=nt, out=out: ops.gemm_x3(x, img, N, shift=shift, groups=G, grp_valid=valid, bm=bm, nterms=nt, out=out))
+            fn = (lambda bm=bm, nt=nt, out=out: ops.gemm_x3(x, img32 if bm >= 2000 else img, N, shift=shift, groups=G, grp_valid=valid,
+                                                            bm=bm, nterms=nt, out=out))
             try:
                 fn()
             except ops._lib.FgnHipError:        # an instance of the experiments build (FGN_HIP_LIB=tools/micro/libfgn_hip_exp.so)
@@ -121,7 +125,8 @@ def main():
         for k, us in timed_round_robin(fns, args.reps).items():
             rec[k]['us'] = us
             rec[k]['tflops_f32_equiv'] = round(rec['gflop'] / us * 1e-3, 1)
-        rec['all_x6_equal'] = bool(all(torch.equal(outs['x6_bm64'][:, :valid], o[:, :valid]) for k, o in outs.items() if k.startswith('x6')))
+        rec['row_tiles_equal'] = bool('x6_bm128' not in outs or torch.equal(outs['x6_bm64'][:, :valid], outs['x6_bm128'][:, :valid]))
+        rec['auto_row_tile'] = ops._lib.load().fgn_x3_row_tile(G * gr, N, K, gr if G > 1 else 0, valid if G > 1 else 0)
         print(json.dumps(rec), flush=True)
 
 
