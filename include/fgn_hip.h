@@ -102,11 +102,13 @@ int fgn_conv1x1_dual_nhwc_f32(const float* x, const float* x2, const int32_t* x2
  * stride 1 / unpadded kernel, fgn_conv1x1_dual_nhwc_f32, fgn_winograd_gemm_f32), same arguments, except that the weights
  * are given as their bf16-plane IMAGE (host-packed once: fgn_amd/ops.py::pack_x3):
  *   w_x3 [groups][K / 32][3 planes][cout_pad][32] bf16, plane 0 = w with the low 16 bits cleared, plane 1 the same of
- *   w - plane 0, plane 2 = w - plane 0 - plane 1; the four 16-byte chunks of a 64-byte row XOR-ed with (n >> 2) & 3.
+ *   w - plane 0, plane 2 = w - plane 0 - plane 1; inside a K-tile chunk g (8 values) holds k = 4g..4g+3, 16+4g..16+4g+3 -
+ *   the operand order of v_mfma_f32_16x16x32_bf16 under which ds_read_b128's lane groups read both operands without bank
+ *   conflicts -, and the four 16-byte chunks of a 64-byte row are XOR-ed with tau[(n >> 2) & 3], tau = (0, 3, 2, 1).
  * fgn_x3_image_bytes = its size.  K >= 64, K % 32 == 0, Cout % 4 == 0, cout_pad % 128 == 0.
  * fgn_gemm_x3_f32: y[rows, Cout] = relu?(x[rows, K] W^T + shift + residual) directly (grouped: rows = n_groups *
- * grp_rows, image g for group g, first grp_valid rows of a group computed); bm 0 / 64 / 128 and nterms 6 / 9 choose the
- * kernel instance (tests, tools/x3_probe.py). */
+ * grp_rows, image g for group g, first grp_valid rows of a group computed); bm 0 (= fgn_x3_row_tile) / 64 / 128 and
+ * nterms 6 / 9 choose the kernel instance (tests, tools/x3_probe.py). */
 size_t fgn_x3_image_bytes(int K, int npad, int n_groups);
 int fgn_x3_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid);   /* 64 / 128: the kernel instance a launch of this shape runs on; 0: use the f32 entry point */
 int fgn_gemm_x3_f32(const float* x, const void* w_x3, float* y, const float* shift, const float* residual, int rows, int K,

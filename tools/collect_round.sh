@@ -45,6 +45,7 @@ timeout -k 10 200 tools/micro/gemm_clock 2.5 0 > "$OUT/${R}_gemm_clock.jsonl" 2>
 # 6. conv_pw_x3_kernel beside the f32 MFMA kernels on the GEMM shapes of an episode (variants take turns), and its phase clocks
 FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_exp.so timeout -k 10 400 python tools/x3_probe.py --reps 10 > "$OUT/${R}_x3_probe.jsonl" 2> "$OUT/x3_probe.err"; echo "x3 probe rc $?"
 [ -f tools/micro/libfgn_hip_x3ph.so ] && FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_x3ph.so timeout -k 10 300 python tools/x3_probe.py --reps 3 --phases > "$OUT/${R}_x3_phases.jsonl" 2> "$OUT/x3_phases.err"
+timeout -k 10 200 bash tools/pmc_x3.sh relq 0 "gpurun_out/collect_$R/${R}_pmc_x3_relq.json" > "$OUT/pmc_x3.log" 2>&1; echo "pmc x3 rc $?"
 # 7. one training step (forward_train + backward of the heads + Adagrad + re-pack; the frozen backbone on the default arithmetic)
 timeout -k 10 400 python tools/train_bench.py --steps 10 --out "$OUT/${R}_train_step.json" > "$OUT/train_bench.log" 2>&1; tail -2 "$OUT/train_bench.log" | cut -c1-300
 ls "$OUT"
