@@ -36,6 +36,16 @@ DATASET = {'cfg1': 'MNISTISEG', 'cfg2': 'OMNIISEG', 'cfg3': 'COCO2VOC', 'cfg4': 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # the same table, "Peak BF16/FP16 MFMA" (dense): 16x the f32-input MFMA
 X3_TERMS = 6                       # bf16 MFMA products conv_pw_x3_kernel issues per f32 product (csrc/conv_pw_x3.h)
+H2_TERMS = 3                       # f16 MFMA products conv_pw_h2_kernel issues per f32 product (csrc/conv_pw_h2.h)
+
+
+def mfma_terms(kernel: str):
+    """(16-bit MFMA products per f32 product, peak of the pipe the kernel runs on in TFLOP/s)."""
+    if kernel.startswith('conv_pw_x3_kernel'):
+        return X3_TERMS, PEAK_BF16_MFMA_TFLOPS
+    if kernel.startswith('conv_pw_h2_kernel'):
+        return H2_TERMS, PEAK_BF16_MFMA_TFLOPS
+    return 1, PEAK_FP32_MFMA_TFLOPS
 
 
 def algorithmic_gflop(cfg, H, W, S, R, D):
@@ -605,7 +615,7 @@ def main():
         can make it faster than its output stream."""
         out = {'mfma_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0), 'hbm_bound': dict(launches=0, ms=0.0, flop=0.0, bytes=0.0)}
         # f32-equivalent MFMA ceiling of the kernel: the f32 pipe, or the bf16 pipe at six products per f32 product
-        peak_eq = PEAK_BF16_MFMA_TFLOPS / X3_TERMS if kernel.startswith('conv_pw_x3_kernel') else PEAK_FP32_MFMA_TFLOPS
+        peak_eq = mfma_terms(kernel)[1] / mfma_terms(kernel)[0]
         for rec in records:
             if rec['kernel'] != kernel or 'gemm' not in rec:
                 continue
@@ -644,8 +654,8 @@ def main():
     tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # conv_pw_x3_kernel issues X3_TERMS bf16 MFMA products per f32 product of its GEMM: its roofline is the bf16 pipe,
     # `achieved` the bf16 MFMA FLOPs it issued per second; the f32 products per second are reported beside it
-    dom_x3 = dom_name.startswith('conv_pw_x3_kernel')
-    dom_terms, dom_peak = (X3_TERMS, PEAK_BF16_MFMA_TFLOPS) if dom_x3 else (1, PEAK_FP32_MFMA_TFLOPS)
+    dom_terms, dom_peak = mfma_terms(dom_name)
+    dom_x3 = dom_terms > 1               # a kernel on the 16-bit matrix pipe (conv_pw_x3_kernel / conv_pw_h2_kernel)
     achieved = tf(dom['issued'], dom['ms']) * dom_terms
     iso_table = [dict(step=i, kernel_ms=round(iso[i][dom_name]['ms'], 4), launches=iso[i][dom_name]['launches'],
                       avg_launch_us=round(iso[i][dom_name]['ms'] * 1e3 / max(iso[i][dom_name]['launches'], 1), 2),
@@ -656,7 +666,7 @@ def main():
     # ---- the dominant kernel over the WHOLE timed window: the launch records inside the captured graphs --------------
     window = None
     # launch records are handed out in launch order to every launch of the two persistent GEMM kernels (f32 and x3)
-    takes_record = lambda rec: rec['kernel'] == 'conv_pw_persist_kernel' or rec['kernel'].startswith('conv_pw_x3_kernel')
+    takes_record = lambda rec: rec['kernel'] == 'conv_pw_persist_kernel' or mfma_terms(rec['kernel'])[0] > 1
     rec_sites = [rec for rec in records_med if takes_record(rec)]
     keep = [i for i, rec in enumerate(rec_sites) if rec['kernel'] == dom_name]
     sites = [rec_sites[i] for i in keep]
@@ -730,9 +740,10 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
-            # operands, accumulation, epilogues and results are f32 in both settings; 'x3' computes the GEMM-shaped launches'
-            # products as six bf16 MFMA products of exact three-way splits (same error against fp64 as the f32 MFMA kernels:
-            # tests/test_hip_conv.py::test_x3_*), 'f32' (FGN_GEMM_MATH=f32) on the f32-input MFMA
+            # operands, accumulation, epilogues and results are f32 in every setting; 'h2' (default) computes the GEMM-shaped
+            # launches' products as three f16 MFMA products of two-way splits of the power-of-two scaled operands, 'x3' as
+            # six bf16 MFMA products of exact three-way splits (both: the error against fp64 of the f32 MFMA kernels,
+            # tests/test_hip_conv.py::test_h2_* / test_x3_*), 'f32' (FGN_GEMM_MATH=f32) on the f32-input MFMA
             'gemm_math': ops.GEMM_MATH,
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {DATASET.get(args.workload, "synthetic")} {shape["n_ways"]}-way {shape["k_shots"]}-shot, '
@@ -784,7 +795,10 @@ def main():
                          'achieved': round(achieved, 2), 'peak': dom_peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / dom_peak, 4),
                          'traffic': traffic,
-                         'mfma': ('v_mfma_f32_32x32x16_bf16: %d bf16 products per f32 product of the GEMM (exact 3-way splits of '
+                         'mfma': ('v_mfma_f32_16x16x32_f16: %d f16 products per f32 product of the GEMM (two-way splits of the '
+                                  'power-of-two scaled f32 operands, f32 accumulation); achieved / peak are f16 MFMA FLOP/s' % H2_TERMS)
+                                 if dom_name.startswith('conv_pw_h2_kernel') else
+                                 ('v_mfma_f32_16x16x32_bf16: %d bf16 products per f32 product of the GEMM (exact 3-way splits of '
                                   'both f32 operands, f32 accumulation); achieved / peak are bf16 MFMA FLOP/s' % X3_TERMS) if dom_x3
                                  else 'v_mfma_f32_16x16x4_f32 (f32 operands)',
                          # the GEMM's own (f32) products per second, and against the f32-input MFMA peak this kernel no

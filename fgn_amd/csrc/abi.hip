@@ -1,6 +1,6 @@
 // ABI version of libfgn_hip.so (bumped whenever include/fgn_hip.h changes incompatibly) and the profiler hook.
 #include "common.h"
-extern "C" int fgn_abi_version(void) { return 28; }
+extern "C" int fgn_abi_version(void) { return 29; }
 
 thread_local hipEvent_t fgn_prof_start = nullptr;
 thread_local hipEvent_t fgn_prof_stop = nullptr;

@@ -83,6 +83,9 @@ struct ConvParams {
     const void* w3 = nullptr;
     unsigned w3_bytes = 0;
     int npad3 = 0;
+    // conv_pw_h2_kernel (conv_pw_h2.h): w3 holds two f16 planes of the column-scaled weights, w_inv the inverse column
+    // scales [group][npad3]
+    const float* w_inv = nullptr;
 };
 
 #ifndef CONV_DMA_STAGES
@@ -1074,6 +1077,7 @@ __global__ __launch_bounds__(256, 5) void conv_pw_persist_kernel(const ConvParam
 }
 
 #include "conv_pw_x3.h"
+#include "conv_pw_h2.h"
 
 #ifdef FGN_EXPERIMENTS
 #define FGN_EXP_PART 1       // kernels and tuning state
@@ -1668,6 +1672,140 @@ extern "C" int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float*
     p.grp_rows_per_item = tiles_per_img; p.grp_count_dev = n_img_dev;
     p.w3 = U_x3; p.w3_bytes = (unsigned)wb; p.npad3 = cout_pad;
     return launch_x3(p, (int)rows, 0, 6, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw_h2_kernel launches (conv_pw_h2.h): the same GEMMs with three f16 MFMA products per f32 product.  p carries the
+// two-plane f16 image of the column-scaled weights (ops.pack_h2: image, then the inverse column scales).  Row tile:
+// x3_pick_bm's rule (0 = leave the launch to the f32 kernels).
+// ------------------------------------------------------------------------------------------------
+template <int WMW, int RB, int NST>
+static int launch_h2_cfg(ConvParams& p, int M_max, hipStream_t stream) {
+    constexpr int BM = 32 * RB * WMW;
+    const int m_tiles = cdiv(M_max, BM);
+    {   // banded raster: <= 2 MB of weight image per band (see ConvParams::band_nt)
+        const long long per_nt = (long long)H2_BN * p.K * 4;
+        p.band_nt = 0; p.band_mt = 0;
+        if (per_nt * p.n_tiles_n > 2048 * 1024) {
+            int nb = (int)std::max<long long>(1, 2048 * 1024 / per_nt);
+            while (nb > 1 && p.n_tiles_n % nb) --nb;
+            const int mt = p.grp_rows ? p.grp_rows / BM : m_tiles;
+            if (nb < p.n_tiles_n && mt > 0 && m_tiles % mt == 0) { p.band_nt = nb; p.band_mt = mt; }
+        }
+    }
+    const int tiles = m_tiles * p.n_tiles_n;
+    static unsigned long long ok = 0ull;
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_h2_kernel<WMW, RB, NST>), &ok);
+    if (attr != hipSuccess) return (int)attr;
+    const size_t lds = (size_t)NST * (BM * 128 + H2_B_STAGE);
+    const int per_cu = std::min(3, (int)(160 * 1024 / lds));         // resident workgroups per CU (LDS-bound)
+    const int grid = std::min(256 * per_cu, (tiles + 7) / 8 * 8);
+    p.stamp = fgn_next_stamp_record();
+    FGN_LAUNCH_TIMED((conv_pw_h2_kernel<WMW, RB, NST>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
+    FGN_LAUNCH_CHECK();
+    return FGN_OK;
+}
+
+extern "C" size_t fgn_h2_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * npad * ((size_t)K * 4 + 4); }
+
+// bm: 0 = choose, 64 / 128 = force the row tile (two LDS stages), 364 = 64 rows with three stages (measured, not chosen)
+static int launch_h2(const ConvParams& p0, int M_max, int n_groups, int bm, hipStream_t stream) {
+    ConvParams p = p0;
+    if (!p.w3 || p.npad3 % H2_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
+    p.n_tiles_n = cdiv(p.Cout, H2_BN);
+    const size_t img = (size_t)n_groups * p.K * p.npad3 * 4;
+    p.w3_bytes = (unsigned)img;
+    p.w_inv = reinterpret_cast<const float*>(static_cast<const char*>(p.w3) + img);
+    if (bm == 364) {
+        if (p.K < 3 * BK || (p.grp_rows && p.grp_rows % 64)) return FGN_ERR_SHAPE;
+        return launch_h2_cfg<2, 1, 3>(p, M_max, stream);
+    }
+    if (bm != 0 && bm != 64 && bm != 128) return FGN_ERR_SHAPE;
+    const int BM = x3_pick_bm(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, bm);
+    if (BM == 0) return FGN_ERR_SHAPE;
+    return BM == 128 ? launch_h2_cfg<2, 2, 2>(p, M_max, stream) : launch_h2_cfg<2, 1, 2>(p, M_max, stream);
+}
+
+// y[rows, Cout] = relu?(x[rows, K] * W^T + shift + residual) with W given as its two-plane f16 image (ops.pack_h2);
+// grouped as fgn_gemm_x3_f32.  The direct entry of conv_pw_h2_kernel (tests, tools).
+extern "C" int fgn_gemm_h2_f32(const float* x, const void* w_h2, float* y, const float* shift, const float* residual,
+                               int rows, int K, int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups,
+                               int bm, hipStream_t stream) {
+    if (!x || !w_h2 || !y) return FGN_ERR_ARG;
+    if (rows <= 0) return FGN_OK;
+    if (K % BK || K <= 0 || (Cout & 3) || npad % H2_BN || npad < Cout || n_groups < 1) return FGN_ERR_SHAPE;
+    if (n_groups > 1 && (grp_rows <= 0 || (long long)n_groups * grp_rows != rows || grp_valid > grp_rows)) return FGN_ERR_SHAPE;
+    const long long xb = (long long)rows * K * 4, wb = (long long)fgn_h2_image_bytes(K, npad, n_groups);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = x; p.y = y; p.shift = shift; p.residual = residual;
+    p.n_img = rows; p.Cin = K; p.Cout = Cout; p.relu = relu; p.K = K; p.kt_per_split = K / BK; p.x_bytes = (unsigned)xb;
+    p.grp_rows = n_groups > 1 ? grp_rows : 0; p.grp_valid = grp_valid;
+    p.w3 = w_h2; p.npad3 = npad;
+    return launch_h2(p, rows, n_groups, bm, stream);
+}
+
+// The three GEMM-shaped entry points of the detector on conv_pw_h2_kernel: arguments as fgn_winograd_gemm_x3_f32 /
+// fgn_conv1x1_x3_nhwc_f32 / fgn_conv1x1_dual_x3_nhwc_f32, the weights as their two-plane f16 image (ops.pack_h2)
+extern "C" int fgn_winograd_gemm_h2_f32(const float* V, const void* U_h2, float* Mo, const int32_t* n_img_dev, int n_img,
+                                        int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups,
+                                        hipStream_t stream) {
+    if (!V || !U_h2 || !Mo) return FGN_ERR_ARG;
+    if (n_img <= 0) return FGN_OK;
+    if (Cin % BK != 0 || Cin < 2 * BK || Cout % 4 != 0 || cout_pad % H2_BN != 0 || cout_pad < Cout || t_pad % 64 != 0 ||
+        (n_groups != 16 && n_groups != 36) || (long long)n_img * tiles_per_img > t_pad)
+        return FGN_ERR_SHAPE;
+    const long long rows = (long long)n_groups * t_pad;
+    const long long xb = rows * Cin * 4, wb = (long long)fgn_h2_image_bytes(Cin, cout_pad, n_groups);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = V; p.y = Mo;
+    p.n_img = (int)rows; p.Cin = Cin; p.Cout = Cout; p.K = Cin; p.kt_per_split = Cin / BK; p.x_bytes = (unsigned)xb;
+    p.grp_rows = t_pad; p.grp_valid = n_img * tiles_per_img; p.grp_items = n_img;
+    p.grp_rows_per_item = tiles_per_img; p.grp_count_dev = n_img_dev;
+    p.w3 = U_h2; p.npad3 = cout_pad;
+    return launch_h2(p, (int)rows, n_groups, 0, stream);
+}
+
+extern "C" int fgn_conv1x1_h2_nhwc_f32(const float* x, const void* w_h2, float* y, const float* scale, const float* shift,
+                                       const float* residual, const int32_t* n_img_dev, int n_img, int H, int W, int Cin,
+                                       int Cout, int cout_pad, int relu, hipStream_t stream) {
+    if (!x || !w_h2 || !y) return FGN_ERR_ARG;
+    if (n_img <= 0) return FGN_OK;
+    if (Cin % BK || Cin < 2 * BK || (Cout & 3) || cout_pad % H2_BN || cout_pad < Cout || H <= 0 || W <= 0) return FGN_ERR_SHAPE;
+    const long long M = (long long)n_img * H * W;
+    const long long xb = M * Cin * 4, wb = (long long)fgn_h2_image_bytes(Cin, cout_pad, 1);
+    if (xb >= 0x7fffff00ll || wb >= 0x7fffff00ll || M * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = x; p.y = y; p.scale = scale; p.shift = shift; p.residual = residual; p.n_img_dev = n_img_dev;
+    p.n_img = n_img; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.K = Cin;
+    p.kt_per_split = Cin / BK; p.x_bytes = (unsigned)xb;
+    p.w3 = w_h2; p.npad3 = cout_pad;
+    return launch_h2(p, (int)M, 1, 0, stream);
+}
+
+extern "C" int fgn_conv1x1_dual_h2_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                                            const void* w_h2, float* y, const float* shift, int rows, int Cin1, int Cin2,
+                                            int Cout, int cout_pad, int relu, hipStream_t stream) {
+    if (!x || !x2 || !w_h2 || !y) return FGN_ERR_ARG;
+    if (rows <= 0) return FGN_OK;
+    if (Cin1 % BK || Cin2 % BK || Cin1 <= 0 || Cin2 <= 0 || (Cout & 3) || cout_pad % H2_BN || cout_pad < Cout) return FGN_ERR_SHAPE;
+    if ((!x2_rows && x2_total_rows != rows) || x2_total_rows < 1) return FGN_ERR_ARG;
+    const int K = Cin1 + Cin2;
+    const long long xb = (long long)rows * Cin1 * 4, x2b = (long long)x2_total_rows * Cin2 * 4;
+    const long long wb = (long long)fgn_h2_image_bytes(K, cout_pad, 1);
+    if (xb >= 0x7fffff00ll || x2b >= 0x7fffff00ll || wb >= 0x7fffff00ll || (long long)rows * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = x; p.y = y; p.shift = shift;
+    p.x2 = x2; p.x2_bytes = (unsigned)x2b; p.kt1 = Cin1 / BK; p.cin2 = Cin2; p.x2_rows = x2_rows;
+    p.n_img = rows; p.Cin = Cin1; p.Cout = Cout; p.relu = relu; p.K = K;
+    p.kt_per_split = K / BK; p.x_bytes = (unsigned)xb;
+    p.w3 = w_h2; p.npad3 = cout_pad;
+    return launch_h2(p, rows, 1, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -472,9 +472,6 @@ class FGN(torch.nn.Module):
         # r04: B = 1 189.9-191.3 vs 188.6-190.9 img/s, B = 4 211.1-211.8 vs 209.2-211.0, B = 8 214.6 vs 215.5): on since
         # round 4 for the launch count.  False = the separate pass, byte-identical to `encode_supports`.
         self.use_merged_support_head = True
-        # stem 7x7/2 + BN + ReLU with the 3x3/2 max-pool in its epilogue (csrc/stem_pool.hip): the 64-channel stem map
-        # (106 MB at cfg3) is never written; False = the two launches of rounds 1-4 (identical bytes)
-        self.use_stem_pool_fusion = ops.STEM_POOL_FUSION
         self.transfer_mode = 0                    # 0: upload + copy stream per caller; 1 / 2: see transfer_stream()
         # one device-to-host copy per batch (every output lands in one `_ResultRecord`) and, under graph replay with the
         # transfers on the caller stream, host inputs copied straight into the graph's static buffers (round 5: 15 -> 6
@@ -679,7 +676,7 @@ class FGN(torch.nn.Module):
         c1 = P['shared'][0].conv1
         P['sh0_lin'] = ops.ConvLayer(c1.w.clone(), None if c1.scale is None else c1.scale.clone(), None, c1.cin,
                                      c1.cout, c1.cout_pad, c1.kh, c1.kw, c1.stride, c1.pad, False,
-                                     None if c1.w3 is None else c1.w3.clone()) \
+                                     None if c1.w3 is None else c1.w3.clone(), None if c1.wh is None else c1.wh.clone()) \
             if self.use_roi_commute else None
         P['sh0_shift'] = c1.shift.clone() if (self.use_roi_commute and c1.shift is not None) else None
         return P
@@ -1089,7 +1086,7 @@ class FGN(torch.nn.Module):
         mark = None if (phase_counter is None or not self.phase_point) else (phase_counter.data_ptr(), self.phase_point)
         return (main.cuda_stream, dev.index, hw, support_code is not None, bool(self.use_merged_backbone),
                 bool(self.use_merged_support_head), self.paste_semantics, int(self.transfer_mode), mark,
-                bool(self.use_side_stream), bool(self.use_stem_pool_fusion), bool(self.use_packed_transfers)) + \
+                bool(self.use_side_stream), bool(self.use_packed_transfers)) + \
             tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items() if v is not None)
 
     def _detect_graphed(self, ins: dict, img_shape, support_code, phase_counter=None):

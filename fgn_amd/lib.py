@@ -62,6 +62,11 @@ SIGNATURES = {
     'fgn_conv1x1_x3_nhwc_f32': (_i, [_p] * 7 + [_i] * 7 + [_p]),
     'fgn_conv1x1_dual_x3_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_gemm_x3_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_h2_image_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_gemm_h2_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_conv1x1_h2_nhwc_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_conv1x1_dual_h2_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'fgn_winograd_gemm_h2_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_gemm_x3_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_conv2d_pair_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p] + [_i] * 8 + [_p]),
     'fgn_det_post_scratch_bytes': (C.c_size_t, [_i, _i]),
@@ -99,7 +104,7 @@ SIGNATURES = {
     'fgn_adagrad_multi_f32': (_i, [_p, _p, _p, _p, _p, _i, _f, _f, _p]),
 }
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 _lib = None
 
 

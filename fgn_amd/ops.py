@@ -27,16 +27,17 @@ from . import lib as _lib
 #   flop_*      per image: direct-convolution FLOPs of the layer / MFMA FLOPs actually issued (0 for the transforms)
 PROFILE = None
 
-# stem 7x7/2 + BN + ReLU + 3x3/2 max-pool as ONE kernel (csrc/stem_pool.hip; detector.FGN.use_stem_pool_fusion).  A/B knob.
-STEM_POOL_FUSION = os.environ.get('FGN_STEM_POOL', '0') != '0'
 # conv3 + shortcut conv of the first block of a stride-1 stage as one dual-operand K loop (conv1x1_dual).  A/B knob.
 FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 # Arithmetic of the GEMM-shaped launches (1x1 / stride 1 convolutions, the fused conv3 + shortcut, the Winograd GEMMs):
 # 'x3' = conv_pw_x3_kernel, every f32 product as six bf16 MFMA products of exact three-way splits, f32 accumulation
-# (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels.
-GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'x3')
+# (csrc/conv_pw_x3.h; the packers below then also build the weights' bf16-plane image); 'f32' = the f32-input MFMA kernels;
+# 'h2' (default) = conv_pw_h2_kernel: three f16 MFMA products of two-way splits of the power-of-two scaled operands per f32
+# product (csrc/conv_pw_h2.h; the packers then build the weights' f16-plane image instead), on the same launches.
+GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'h2')
 # by row tile (fgn_x3_row_tile); template arguments: waves along M, 32-row blocks per wave, terms, LDS stages, 16x16x32 MFMA
 X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2, true>', 128: 'conv_pw_x3_kernel<2, 2, 6, 2, true>'}
+H2_KERNELS = {64: 'conv_pw_h2_kernel<2, 1, 2>', 128: 'conv_pw_h2_kernel<2, 2, 2>'}     # waves along M, row blocks per wave, LDS stages
 
 
 def x3_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0) -> str:
@@ -44,9 +45,14 @@ def x3_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 
     return X3_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_x3_kernel<?>')
 
 
+def h2_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0) -> str:
+    """The same for conv_pw_h2_kernel (it takes conv_pw_x3_kernel's row tile rule)."""
+    return H2_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_h2_kernel<?>')
+
+
 class gemm_math:
     """``with ops.gemm_math('f32'):`` - the layers PACKED inside use that arithmetic (None: no change).  Training packs its
-    head layers under 'f32': the optimizer rewrites their weights in place every step and a bf16-plane image would have to
+    head layers under 'f32': the optimizer rewrites their weights in place every step and a plane image would have to
     be re-derived each time."""
 
     def __init__(self, mode):
@@ -252,12 +258,14 @@ class ConvLayer:
     pad: int
     relu: bool
     w3: Optional[torch.Tensor] = None      # bf16-plane image of w (pack_x3) for conv_pw_x3_kernel, or None
+    wh: Optional[torch.Tensor] = None      # f16-plane image of w (pack_h2) for conv_pw_h2_kernel, or None
 
     def to(self, device):
         self.w = self.w.to(device)
         self.scale = None if self.scale is None else self.scale.to(device)
         self.shift = None if self.shift is None else self.shift.to(device)
         self.w3 = None if self.w3 is None else self.w3.to(device)
+        self.wh = None if self.wh is None else self.wh.to(device)
         return self
 
 
@@ -266,6 +274,12 @@ def _x3_ok(cin: int, cout: int) -> bool:
     launch; a layer whose 128-column tiles would be under 70 % real channels never passes it)."""
     npad = (cout + 127) // 128 * 128
     return GEMM_MATH == 'x3' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout * 10 >= npad * 7
+
+
+def _h2_ok(cin: int, cout: int) -> bool:
+    """The same for the f16-plane image of conv_pw_h2_kernel (GEMM_MATH 'h2': it takes the launches 'x3' would)."""
+    npad = (cout + 127) // 128 * 128
+    return GEMM_MATH == 'h2' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout * 10 >= npad * 7
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -300,10 +314,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Opt
             shift = shift + bias.float() * scale
     elif bias is not None:
         shift = bias.detach().float().clone()
-    w3 = pack_x3(w) if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and _x3_ok(cin, cout)) else None
+    pw = kh == 1 and kw == 1 and stride == 1 and pad == 0
+    w3 = pack_x3(w) if (pw and _x3_ok(cin, cout)) else None
+    wh = pack_h2(w) if (pw and _h2_ok(cin, cout)) else None
     return ConvLayer(w.contiguous(), None if scale is None else scale.contiguous(),
                      None if shift is None else shift.contiguous(), cin, cout, cout_pad, kh, kw,
-                     stride, pad, relu, w3)
+                     stride, pad, relu, w3, wh)
 
 
 def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] = None,
@@ -341,15 +357,17 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    if layer.w3 is not None and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
+    if (layer.w3 is not None or layer.wh is not None) and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
             x.numel() * 4 < 0x7fffff00 and out.numel() < (1 << 31) and L.fgn_x3_row_tile(n_img * ho * wo, layer.cout, cin, 0, 0) > 0:
-        rc = L.fgn_conv1x1_x3_nhwc_f32(_ptr(x), layer.w3.data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
-                                       _ptr(residual), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad,
-                                       int(layer.relu), _stream())
-        _lib.check(rc, 'fgn_conv1x1_x3_nhwc_f32')
+        h2 = layer.wh is not None
+        f = L.fgn_conv1x1_h2_nhwc_f32 if h2 else L.fgn_conv1x1_x3_nhwc_f32
+        rc = f(_ptr(x), (layer.wh if h2 else layer.w3).data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
+               _ptr(residual), _ptr(n_img_dev), n_img, H, W, cin, layer.cout, layer.cout_pad, int(layer.relu), _stream())
+        _lib.check(rc, 'fgn_conv1x1_h2_nhwc_f32' if h2 else 'fgn_conv1x1_x3_nhwc_f32')
         if prof is not None:
             flop = 2.0 * ho * wo * layer.cout * cin
-            prof.append(dict(kind='conv', kernel=x3_kernel(n_img * ho * wo, layer.cout, cin), math='x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+            prof.append(dict(kind='conv', kernel=(h2_kernel if h2 else x3_kernel)(n_img * ho * wo, layer.cout, cin),
+                             math='h2' if h2 else 'x3', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                              n_img=n_img, n_img_dev=n_img_dev, gemm=(1, ho * wo, layer.cout, cin),
                              residual=residual is not None, shape=(n_img, H, W, cin, layer.cout, 1, 1)))
         return out
@@ -434,6 +452,61 @@ def gemm_x3(x: torch.Tensor, image: torch.Tensor, cout: int, shift: Optional[tor
     return out
 
 
+def pack_h2(w: torch.Tensor) -> torch.Tensor:
+    """w [G, N, K] (or [N, K]) f32 -> the weight image of ``conv_pw_h2_kernel`` (csrc/conv_pw_h2.h): every output column n of
+    a group scaled by the power of two that puts its largest |w| into [2^14, 2^15) (an all-zero column: 1), then every value
+    as two f16 planes, hi = f16(w s) and lo = f16(w s - hi) (round to nearest; hi + lo = w s to within 2^-24 |w s|), laid
+    out [G][K / 32][plane][Npad][32] f16 with ``pack_x3``'s k order and chunk swizzle, followed by the inverse scales
+    [G][Npad] f32.  uint8 tensor on w's device."""
+    w = w.detach().float()
+    if w.dim() == 2:
+        w = w[None]
+    G, N, K = w.shape
+    if K % 32:
+        raise _lib.FgnHipError('pack_h2: K must be a multiple of 32')
+    npad = (N + 127) // 128 * 128
+    wp = w.new_zeros(G, npad, K)
+    wp[:, :N] = w
+    amax = wp.abs().amax(dim=2)                                              # [G, npad]
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)).double()))
+    e = torch.where((amax > 0) & torch.isfinite(amax), e, torch.full_like(e, 14.0)).clamp_(-100.0, 100.0)
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=w.device), 14.0 - e).float()
+    inv = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=w.device), e - 14.0).float()
+    ws = wp * scale[:, :, None]                                              # exact (power of two)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    pl = torch.stack((hi, lo), 1).view(torch.int16)                          # [G, 2, npad, K] f16 bit patterns
+    korder = torch.tensor([4 * g + j if j < 4 else 16 + 4 * g + j - 4 for g in range(4) for j in range(8)], device=w.device)
+    pl = pl.view(G, 2, npad, K // 32, 32)[..., korder]
+    pl = pl.reshape(G, 2, npad, K // 32, 4, 8)                               # K -> (K-tile, chunk, 8)
+    n = torch.arange(npad, device=w.device)
+    swz = torch.tensor([0, 3, 2, 1], device=w.device)[(n >> 2) & 3]
+    src = torch.arange(4, device=w.device)[None, :] ^ swz[:, None]           # physical chunk c holds logical c ^ swz
+    pl = torch.gather(pl, 4, src[None, None, :, None, :, None].expand(G, 2, npad, K // 32, 4, 8))
+    img = pl.permute(0, 3, 1, 2, 4, 5).contiguous()                          # [G, KT, 2, npad, 4, 8]
+    return torch.cat((img.view(torch.uint8).reshape(-1), inv.contiguous().view(torch.uint8).reshape(-1)))
+
+
+def gemm_h2(x: torch.Tensor, image: torch.Tensor, cout: int, shift: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, relu: bool = False, groups: int = 1, grp_valid: Optional[int] = None,
+            bm: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, K] (grouped: [groups, grp_rows, K]) times the ``pack_h2`` image -> [rows, cout] on conv_pw_h2_kernel."""
+    _chk(x, 'x')
+    K = x.shape[-1]
+    rows = x.numel() // K
+    grp_rows = rows // groups
+    npad = (cout + 127) // 128 * 128
+    L = _lib.load()
+    if image.numel() != L.fgn_h2_image_bytes(K, npad, groups):
+        raise _lib.FgnHipError('gemm_h2: image size does not match K / cout / groups')
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (cout,), device=x.device, dtype=torch.float32)
+    rc = L.fgn_gemm_h2_f32(_ptr(x), image.data_ptr(), _ptr(out), _ptr(shift), _ptr(residual), rows, K, cout, npad, int(relu),
+                           grp_rows, grp_rows if grp_valid is None else grp_valid, groups, bm, _stream())
+    _lib.check(rc, 'fgn_gemm_h2_f32')
+    return out
+
+
 @dataclass
 class DualConvLayer:
     """Two 1x1 / stride 1 convolutions with their eval-mode BatchNorms, packed for ONE K loop (``conv1x1_dual``):
@@ -447,10 +520,12 @@ class DualConvLayer:
     cout_pad: int
     relu: bool
     w3: Optional[torch.Tensor] = None
+    wh: Optional[torch.Tensor] = None
 
     def to(self, device):
         self.w, self.shift = self.w.to(device), self.shift.to(device)
         self.w3 = None if self.w3 is None else self.w3.to(device)
+        self.wh = None if self.wh is None else self.wh.to(device)
         return self
 
 
@@ -469,7 +544,7 @@ def pack_conv_dual(w1: torch.Tensor, bn1: dict, w2: torch.Tensor, bn2: dict, rel
     wp = torch.zeros(cout_pad, cin1 + cin2, dtype=torch.float32)
     wp[:cout] = torch.cat(rows, 1).float()
     return DualConvLayer(wp.contiguous(), shift.float().contiguous(), cin1, cin2, cout, cout_pad, relu,
-                         pack_x3(wp) if _x3_ok(cin1 + cin2, cout) else None)
+                         pack_x3(wp) if _x3_ok(cin1 + cin2, cout) else None, pack_h2(wp) if _h2_ok(cin1 + cin2, cout) else None)
 
 
 def strided_rows(shapes, stride: int, device) -> torch.Tensor:
@@ -512,11 +587,13 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    use_x3 = layer.w3 is not None and max(x1.numel(), x2.numel()) * 4 < 0x7fffff00 and L.fgn_x3_row_tile(rows, layer.cout, layer.cin1 + layer.cin2, 0, 0) > 0
+    use_x3 = (layer.w3 is not None or layer.wh is not None) and max(x1.numel(), x2.numel()) * 4 < 0x7fffff00 and \
+        L.fgn_x3_row_tile(rows, layer.cout, layer.cin1 + layer.cin2, 0, 0) > 0
+    use_h2 = use_x3 and layer.wh is not None
     if use_x3:
-        rc = L.fgn_conv1x1_dual_x3_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, layer.w3.data_ptr(), _ptr(out),
-                                            _ptr(layer.shift), rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad,
-                                            int(layer.relu), _stream())
+        f = L.fgn_conv1x1_dual_h2_nhwc_f32 if use_h2 else L.fgn_conv1x1_dual_x3_nhwc_f32
+        rc = f(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, (layer.wh if use_h2 else layer.w3).data_ptr(), _ptr(out),
+               _ptr(layer.shift), rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
     else:
         rc = L.fgn_conv1x1_dual_nhwc_f32(_ptr(x1), _ptr(x2), _ptr(x2_rows), x2_total, _ptr(layer.w), _ptr(out), _ptr(layer.shift),
                                          rows, layer.cin1, layer.cin2, layer.cout, layer.cout_pad, int(layer.relu), _stream())
@@ -524,8 +601,8 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     if prof is not None:
         k = layer.cin1 + layer.cin2
         flop = 2.0 * rows * layer.cout * k
-        prof.append(dict(kind='conv', kernel=x3_kernel(rows, layer.cout, layer.cin1 + layer.cin2) if use_x3 else 'conv_pw_persist_kernel',
-                         math='x3' if use_x3 else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
+        prof.append(dict(kind='conv', kernel=h2_kernel(rows, layer.cout, k) if use_h2 else x3_kernel(rows, layer.cout, k) if use_x3 else 'conv_pw_persist_kernel',
+                         math='h2' if use_h2 else 'x3' if use_x3 else 'f32', e0=e0, e1=e1, flop_direct=flop, flop_issued=flop,
                          n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k), residual=False,
                          shape=(1, rows, 1, k, layer.cout, 1, 1)))
     return out
@@ -588,6 +665,7 @@ class WinogradLayer:
     relu: bool
     m: int = 2
     u3: Optional[torch.Tensor] = None      # bf16-plane image of u (pack_x3), or None
+    uh: Optional[torch.Tensor] = None      # f16-plane image of u (pack_h2), or None
 
     @property
     def groups(self) -> int:
@@ -597,6 +675,7 @@ class WinogradLayer:
         self.u = self.u.to(device)
         self.shift = None if self.shift is None else self.shift.to(device)
         self.u3 = None if self.u3 is None else self.u3.to(device)
+        self.uh = None if self.uh is None else self.uh.to(device)
         return self
 
 
@@ -633,7 +712,7 @@ def pack_winograd(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn:
     up = torch.zeros((m + 2) ** 2, cout_pad, cin, dtype=torch.float32, device=w.device)
     up[:, :cout] = u.reshape((m + 2) ** 2, cout, cin).float()
     return WinogradLayer(up.contiguous(), None if shift is None else shift.float().contiguous(), cin, cout,
-                         cout_pad, relu, m, pack_x3(up) if _x3_ok(cin, cout) else None)
+                         cout_pad, relu, m, pack_x3(up) if _x3_ok(cin, cout) else None, pack_h2(up) if _h2_ok(cin, cout) else None)
 
 
 _WG_G_DEV: dict = {}
@@ -654,6 +733,8 @@ def repack_conv_(layer: ConvLayer, weight: torch.Tensor, bias: Optional[torch.Te
         layer.shift.copy_(bias.detach())
     if layer.w3 is not None:
         layer.w3.copy_(pack_x3(layer.w))
+    if layer.wh is not None:
+        layer.wh.copy_(pack_h2(layer.w))
     return layer
 
 
@@ -676,6 +757,8 @@ def repack_winograd_(layer: WinogradLayer, weight: torch.Tensor, bias: Optional[
         layer.shift.copy_(bias.detach())
     if layer.u3 is not None:
         layer.u3.copy_(pack_x3(layer.u))
+    if layer.uh is not None:
+        layer.uh.copy_(pack_h2(layer.u))
     return layer
 
 
@@ -730,12 +813,17 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     ev = [] if prof is not None else None
     if ev is not None:
         ev.append(prof.arm())
+    use_x3 = (layer.u3 is not None or layer.uh is not None) and L.fgn_x3_row_tile(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) > 0
+    use_h2 = use_x3 and layer.uh is not None
+    use_x3 = use_x3 and not use_h2
     _lib.check(f_in(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W, cin, t_pad, st),
                'fgn_winograd_input_f32')
     if ev is not None:
         ev.append(prof.arm())
-    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) > 0
-    if use_x3:
+    if use_h2:
+        _lib.check(L.fgn_winograd_gemm_h2_f32(_ptr(V), layer.uh.data_ptr(), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
+                                              layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_h2_f32')
+    elif use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), _ptr(n_img_dev), n_img, tiles, t_pad, cin,
                                               layer.cout, layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
     else:
@@ -759,8 +847,9 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
                          **common))
         # the grouped GEMM is a point-wise launch over [groups * t_pad] rows
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, layer.cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)   # 64x64 tile
-        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) if use_x3 else kernel_name(gid),
-                         math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=h2_kernel(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) if use_h2 else
+                         x3_kernel(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) if use_x3 else kernel_name(gid),
+                         math='h2' if use_h2 else 'x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * H * W * layer.cout * 9 * cin,
                          flop_issued=2.0 * G * tiles * layer.cout * cin, gemm=(G, tiles, layer.cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel=kout, e0=ev[2][0], e1=ev[2][1], flop_direct=0.0,
@@ -797,6 +886,9 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
     ev = []
     if prof is not None:
         ev.append(prof.arm())
+    use_x3 = (layer.u3 is not None or layer.uh is not None) and L.fgn_x3_row_tile(G * t_pad, cout, cin, t_pad, total) > 0
+    use_h2 = use_x3 and layer.uh is not None
+    use_x3 = use_x3 and not use_h2
     if pair:
         (n0, h0, w0, _), (n1, h1, w1, _) = xs[0].shape, xs[1].shape
         _lib.check(L.fgn_winograd4_input2_f32(_ptr(xs[0]), n0, h0, w0, _ptr(xs[1]), n1, h1, w1, _ptr(V), cin, t_pad, st),
@@ -810,8 +902,10 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
             off += n_t
     if prof is not None:
         ev.append(prof.arm())
-    use_x3 = layer.u3 is not None and L.fgn_x3_row_tile(G * t_pad, cout, cin, t_pad, total) > 0
-    if use_x3:
+    if use_h2:
+        _lib.check(L.fgn_winograd_gemm_h2_f32(_ptr(V), layer.uh.data_ptr(), _ptr(Mo), None, 1, total, t_pad, cin, cout,
+                                              layer.cout_pad, G, st), 'fgn_winograd_gemm_h2_f32')
+    elif use_x3:
         _lib.check(L.fgn_winograd_gemm_x3_f32(_ptr(V), layer.u3.data_ptr(), _ptr(Mo), None, 1, total, t_pad, cin, cout,
                                               layer.cout_pad, G, st), 'fgn_winograd_gemm_x3_f32')
     else:
@@ -836,8 +930,9 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
         prof.append(dict(kind='wg_in', kernel='wg4_input_kernel<%d, %s>' % (vi // 10, 'true' if vi % 10 else 'false'),
                          e0=ev[0][0], e1=ev[0][1], flop_direct=0.0, flop_issued=0.0, **common))
         gid = L.fgn_conv2d_kernel_id(G * t_pad, 1, 1, cin, cout, layer.cout_pad, 1, 1, 1, 0, 1, 0, 0, 4)
-        prof.append(dict(kind='wg_gemm', kernel=x3_kernel(G * t_pad, cout, cin, t_pad, total) if use_x3 else kernel_name(gid),
-                         math='x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
+        prof.append(dict(kind='wg_gemm', kernel=h2_kernel(G * t_pad, cout, cin, t_pad, total) if use_h2 else
+                         x3_kernel(G * t_pad, cout, cin, t_pad, total) if use_x3 else kernel_name(gid),
+                         math='h2' if use_h2 else 'x3' if use_x3 else 'f32', e0=ev[1][0], e1=ev[1][1],
                          flop_direct=2.0 * pixels * cout * 9 * cin, flop_issued=2.0 * G * total * cout * cin,
                          gemm=(G, total, cout, cin), **common))
         prof.append(dict(kind='wg_out', kernel='wg4_output_kernel<%d>' % (vo // 10), e0=ev[2][0], e1=ev[2][1],

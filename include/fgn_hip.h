@@ -122,6 +122,29 @@ int fgn_conv1x1_dual_x3_nhwc_f32(const float* x, const float* x2, const int32_t*
                                  int cout_pad, int relu, void* stream);
 int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const int32_t* n_img_dev, int n_img,
                              int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
+/* The same GEMMs with THREE f16 MFMA products per f32 product (conv_pw_h2_kernel, csrc/conv_pw_h2.h; the default of the
+ * host wrappers): an f32 value scaled by a power of two into the f16 range is h + l to within 2^-24 of itself (h = f16(x),
+ * l = f16(x - h), round to nearest), products of f16 values are exact in f32, and h_a h_b + h_a l_b + l_a h_b leaves out
+ * only l_a l_b <= 2^-24 |a b|; f32 accumulation, f32 in / out, the f32 kernels' error against fp64
+ * (tests/test_hip_conv.py::test_h2_*).  The scales are powers of two (exact) and taken out again inside the kernel: the
+ * weights' per output column at pack time (fgn_amd/ops.py::pack_h2), the activations' found by the kernel itself per wave
+ * and output tile (the first non-zero K-tile of a tile sets it; a later K-tile that would leave the f16 range picks a
+ * new one and the accumulators follow by the exact ratio).  Same call sites and arguments as the x3 entry points, with
+ *   w_h2: [groups][K / 32][2 planes][cout_pad][32] f16 of the column-scaled weights (k order and chunk swizzle of w_x3),
+ *         then [groups][cout_pad] f32 inverse column scales.  fgn_h2_image_bytes = the size of both.
+ * Shapes: as the x3 entry points (fgn_x3_row_tile decides for both).  fgn_gemm_h2_f32: the direct entry (tests, tools);
+ * bm 0 / 64 / 128 as fgn_gemm_x3_f32, 364 = 64 rows with three LDS stages (measured, not chosen). */
+size_t fgn_h2_image_bytes(int K, int npad, int n_groups);
+int fgn_gemm_h2_f32(const float* x, const void* w_h2, float* y, const float* shift, const float* residual, int rows, int K,
+                    int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups, int bm, void* stream);
+int fgn_conv1x1_h2_nhwc_f32(const float* x, const void* w_h2, float* y, const float* scale, const float* shift,
+                            const float* residual, const int32_t* n_img_dev, int n_img, int H, int W, int Cin, int Cout,
+                            int cout_pad, int relu, void* stream);
+int fgn_conv1x1_dual_h2_nhwc_f32(const float* x, const float* x2, const int32_t* x2_rows, int x2_total_rows,
+                                 const void* w_h2, float* y, const float* shift, int rows, int Cin1, int Cin2, int Cout,
+                                 int cout_pad, int relu, void* stream);
+int fgn_winograd_gemm_h2_f32(const float* V, const void* U_h2, float* Mo, const int32_t* n_img_dev, int n_img,
+                             int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
 
 /* The same convolution (w_packed, scale, shift, relu as in fgn_conv2d_nhwc_f32) on TWO NHWC tensors of different
  * geometry in one launch: x0 [n_img0,H0,W0,Cin] -> y0, x1 [n_img1,H1,W1,Cin] -> y1.  For the backbone layers that

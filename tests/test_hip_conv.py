@@ -395,3 +395,133 @@ def test_x3_gemm_epilogue_and_special_values():
     # per row: relative to that row's own scale (rows differ by 35 orders of magnitude)
     scale = (x.double().abs() @ w.double().abs().T).max(1, keepdim=True).values + res.double().abs()
     assert ((got - ref).abs() / scale).max().item() <= 2e-6
+
+
+@pytest.mark.parametrize('groups,grp_rows,valid,K,N', [(1, 14700, 14700, 1024, 1024), (1, 3001, 3001, 64, 76), (1, 130, 130, 96, 260),
+                                                       (36, 256, 201, 128, 132), (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256)])
+@pytest.mark.parametrize('mag', [1.0, 3e-5, 2e7])
+def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, valid, K, N, mag):
+    """conv_pw_h2_kernel through its direct entry (fgn_gemm_h2_f32): f32 operands, every product as three f16 MFMA products of
+    two-way splits of the power-of-two scaled operands (weights per output column at pack time, activations by the scale
+    the kernel finds per wave and output tile), f32 accumulation.  Against fp64 on post-ReLU activations x random weights,
+    with the activations at magnitudes inside, below and above the f16 range: within 2e-6 of the range like the f32 MFMA
+    kernels and conv_pw_x3_kernel, and no further from fp64 than 1.6x the f32 MFMA kernel on the same operands (measured:
+    closer than conv_pw_x3_kernel).  Ragged rows / channels, grouped launches with fewer valid rows than a group holds, K of
+    2 and 3 K-tiles.  The scales differ per wave and tile, so row tiles / stage counts may differ where an element's l plane
+    reaches the f16 subnormals: within 1e-7 of the range of each other."""
+    from fgn_amd import lib, ops
+    g = torch.Generator().manual_seed(groups * 1000 + K + N)
+    x = (torch.randn(groups, grp_rows, K, generator=g).relu_() * mag).cuda()
+    x[:, valid:] = 3e38                                  # what lies behind a group's valid rows must not reach a wave's scale
+    w = (torch.randn(groups, N, K, generator=g) / K ** 0.5).cuda()
+    w[:, 1::3] *= 40.0                                   # columns of different magnitude: the column scales differ
+    shift = (torch.randn(N, generator=g) * mag).cuda()
+    ref = torch.einsum('grk,gnk->grn', x[:, :valid].double(), w.double()) + shift.double()
+    rng = ref.abs().max().item()
+    img = ops.pack_h2(w)
+    outs = {}
+    for bm in (64, 128, 364):
+        tile = 128 if bm == 128 else 64
+        if groups > 1 and grp_rows % tile:
+            continue
+        if bm == 364 and K < 96:
+            continue
+        out = torch.full((groups, grp_rows, N), float('nan'), device='cuda')
+        ops.gemm_h2(x, img, N, shift=shift, groups=groups, grp_valid=valid, bm=bm, out=out)
+        outs[bm] = out
+        err = (out[:, :valid].double() - ref).abs().max().item()
+        assert err <= 2e-6 * rng, (bm, err / rng)
+        last = -(-valid // tile) * tile                  # rows of whole tiles past the last valid one of a group are not written
+        assert torch.isnan(out[:, last:]).all()
+    for bm in (128, 364):
+        if bm in outs:
+            assert (outs[64][:, :valid] - outs[bm][:, :valid]).abs().max().item() <= 1e-7 * rng
+    if groups == 1:
+        with ops.gemm_math('f32'):
+            layer = ops.pack_conv(w[0].reshape(N, K, 1, 1), bias=shift).to('cuda')
+        f32 = ops.conv2d(x.view(1, grp_rows, 1, K), layer).view(1, grp_rows, N)
+    else:
+        L = lib.load()
+        cout_pad = (N + 127) // 128 * 128
+        u = torch.zeros(groups, cout_pad, K, device='cuda')
+        u[:, :N] = w
+        f32 = torch.zeros(groups, grp_rows, N, device='cuda')
+        lib.check(L.fgn_winograd_gemm_f32(x.data_ptr(), u.data_ptr(), f32.data_ptr(), None, 1, valid, grp_rows, K, N, cout_pad,
+                                          groups, torch.cuda.current_stream().cuda_stream), 'wg')
+        f32 = f32 + shift
+    e32 = (f32[:, :valid].double() - ref).abs()
+    eh = (outs[64][:, :valid].double() - ref).abs()
+    assert eh.max().item() <= 1.6 * e32.max().item() + 1e-7 * rng
+    assert eh.mean().item() <= 1.6 * e32.mean().item() + 1e-8 * rng
+
+
+def test_h2_gemm_epilogue_and_dynamic_range():
+    """Residual + ReLU in the epilogue; rows past M untouched; zero rows and rows of 1e-7 among rows of 1 (a wave's 32 rows
+    share one scale: errors stay relative to the largest row); whole tiles of 1e-7 behind tiles of 1 (every wave scales its
+    own rows: errors relative to the row itself); a K-tile 3e4 above / 1e4 below the ones before it (the wave picks a new
+    scale and its accumulators follow / keeps the old one); an all-zero operand gives the epilogue of zero."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    rows, K, N = 1024, 128, 64
+    x = torch.randn(rows, K, generator=g)
+    x[::7] = 0.0
+    x[1::7] *= 1e-7
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    w[:, ::5] *= 1e-6
+    res = torch.randn(rows, N, generator=g)
+    img = ops.pack_h2(w.cuda())
+    for grow in (1.0, 3e4, 1e-4):
+        x2 = x.clone()
+        x2[:, 96:] *= grow
+        ref = torch.relu(x2.double() @ w.double().T + res.double())
+        out = torch.full((rows + 64, N), -7.0, device='cuda')
+        ops.gemm_h2(x2.cuda(), img, N, residual=res.cuda(), relu=True, bm=64, out=out[:rows])
+        got = out[:rows].cpu().double()
+        assert torch.isfinite(got).all() and (out[rows:] == -7.0).all()
+        row_scale = (x2.double().abs() @ w.double().abs().T).max(1, keepdim=True).values
+        assert ((got - ref).abs() <= 2e-6 * (row_scale.max() + res.double().abs())).all(), grow
+    x3 = x.clone()
+    x3[512:] *= 1e-7                                   # rows 512.. : whole 64-row tiles seven orders of magnitude down
+    x3[512::7] = x[512::7] * 1e-7 + 1e-9
+    got = ops.gemm_h2(x3.cuda(), img, N, bm=64).cpu().double()
+    ref = x3.double() @ w.double().T
+    row_scale = (x3.double().abs() @ w.double().abs().T).max(1, keepdim=True).values
+    blk = row_scale.view(-1, 32, 1).max(1, keepdim=True).values.expand(-1, 32, 1).reshape(rows, 1)     # a wave's 32 rows
+    assert ((got - ref).abs() <= 2e-6 * blk).all()
+    z = ops.gemm_h2(torch.zeros(256, K, device='cuda'), img, N, shift=res[0].cuda(), bm=64)
+    assert torch.equal(z, res[0].cuda().expand(256, N))
+
+
+def test_winograd_h2_is_as_close_to_fp64_as_x3():
+    """F(4x4) layers under GEMM_MATH 'h2' (the default) against the bf16-plane GEMM and fp64: the grouped GEMM on
+    conv_pw_h2_kernel adds nothing to F(4x4)'s own f32 error (~2.5e-6 of the range, csrc/winograd.hip); the input-scale
+    (guidance) and device-count arguments pass through; two tensors through one launch (conv3x3_winograd_multi) agree with
+    separate calls."""
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cin, cout = 256, 192
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    x = (torch.randn(6, 29, 45, cin, generator=g).relu_() * 3.0).cuda()
+    sc = (torch.rand(6, cin, generator=g) + 0.5).cuda()
+    with ops.gemm_math('h2'):
+        lh = ops.pack_winograd(w, bias=b, relu=True).to('cuda')
+    with ops.gemm_math('x3'):
+        l3 = ops.pack_winograd(w, bias=b, relu=True).to('cuda')
+    assert lh.uh is not None and lh.u3 is None and l3.uh is None and l3.u3 is not None
+    n_dev = torch.tensor([5], dtype=torch.int32, device='cuda')
+    conv64 = lambda t: torch.nn.functional.conv2d(t.permute(0, 3, 1, 2).double(), w.cuda().double(), b.cuda().double(),
+                                                  padding=1).relu_().permute(0, 2, 3, 1)
+    for kw in (dict(), dict(in_scale=sc), dict(n_img_dev=n_dev)):
+        yh, y3 = ops.conv3x3_winograd(x, lh, **kw), ops.conv3x3_winograd(x, l3, **kw)
+        n = 5 if 'n_img_dev' in kw else 6
+        ref = conv64(x[:n] * sc[:n, None, None, :] if 'in_scale' in kw else x[:n])
+        rng = ref.abs().max().item()
+        eh, e3 = (yh[:n].double() - ref).abs(), (y3[:n].double() - ref).abs()
+        assert eh.max().item() <= 1.3 * e3.max().item() + 5e-7 * rng and eh.mean().item() <= 1.2 * e3.mean().item() + 2e-8 * rng
+        assert eh.max().item() <= 1e-5 * rng
+    x1 = torch.randn(3, 16, 16, cin, generator=g).relu_().cuda()
+    o0, o1 = torch.empty(6, 29, 45, cout, device='cuda'), torch.empty(3, 16, 16, cout, device='cuda')
+    ops.conv3x3_winograd_multi([x, x1], lh, [o0, o1])
+    assert (o0 - ops.conv3x3_winograd(x, lh)).abs().max().item() <= 1e-5 * o0.abs().max().item()
+    assert (o1 - ops.conv3x3_winograd(x1, lh)).abs().max().item() <= 1e-5 * o1.abs().max().item()

@@ -44,10 +44,11 @@ for i in range(n):
     # frac: f32 products per second against the f32-input MFMA peak (conv_pw_x3_kernel can exceed 1: it does not run on
     # that pipe); frac_of_pipe: against the pipe the kernel runs on (x3: six bf16 MFMA products per f32 product / 2500)
     x3 = rec.get('math') == 'x3'
+    terms = {'x3': 6, 'h2': 3}.get(rec.get('math'))
     rows.append(dict(i=i, kind=rec['kind'], kernel=rec['kernel'], groups=g, M=M, N=N, K=K, tiles64=tiles, us=round(us, 1),
                      gflop=round(fl / 1e9, 2), tflops=round(fl / us / 1e6, 1) if fl else '',
                      frac=round(fl / us / 1e6 / 157.3, 3) if fl else '',
-                     frac_of_pipe=(round(fl / us / 1e6 * (6 / 2500.0 if x3 else 1 / 157.3), 3) if fl else ''),
+                     frac_of_pipe=(round(fl / us / 1e6 * (terms / 2500.0 if terms else 1 / 157.3), 3) if fl else ''),
                      layer_shape='x'.join(str(v) for v in rec['shape'])))
     tot_us += us
     tot_fl += fl

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""conv_pw_x3_kernel (three-bf16-plane products) against the f32-MFMA kernels: error against fp64 and time per launch on
+"""conv_pw_h2_kernel (two-f16-plane products) and conv_pw_x3_kernel (three-bf16-plane products) against the f32-MFMA kernels: error against fp64 and time per launch on
 the GEMM shapes of a cfg3 episode, the variants taking turns.  python tools/x3_probe.py [--reps 10]
 FGN_HIP_LIB=tools/micro/libfgn_hip_exp.so adds the instances that were measured and not chosen (128-row tiles, 16x16x32
 MFMA); FGN_HIP_LIB=tools/micro/libfgn_hip_x3ph.so --phases the phase clocks of one wave."""
@@ -73,6 +73,21 @@ def main():
         img32 = ops.pack_x3(w, mfma32=True)
         rec = dict(shape=name, gflop=2.0 * G * valid * K * N / 1e9)
         fns, outs = {}, {}
+        # conv_pw_h2_kernel (three f16 products of scaled two-way splits): 64 / 128 rows, 64 rows x 3 stages
+        imgh = ops.pack_h2(w)
+        for tag, bm in (('h2_bm64', 64), ('h2_bm128', 128), ('h2_bm64_st3', 364)):
+            if G > 1 and gr % (128 if bm == 128 else 64):
+                continue
+            out = torch.zeros(G, gr, N, device=dev)
+            fn = (lambda bm=bm, out=out: ops.gemm_h2(x, imgh, N, shift=shift, groups=G, grp_valid=valid, bm=bm, out=out))
+            try:
+                fn()
+            except ops._lib.FgnHipError:        # three stages need three K-tiles
+                continue
+            torch.cuda.synchronize()
+            d = (out[:, :valid].double() - ref).abs()
+            outs[tag], fns[tag] = out, fn
+            rec[tag] = dict(max_err=d.max().item() / scale, mean_err=d.mean().item() / scale)
         for tag, bm, nt in VARIANTS:
             if G > 1 and gr % (128 if bm % 1000 >= 128 else 64):
                 continue
