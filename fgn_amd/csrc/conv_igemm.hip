@@ -1676,15 +1676,29 @@ extern "C" int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float*
 
 // ------------------------------------------------------------------------------------------------
 // conv_pw_h2_kernel launches (conv_pw_h2.h): the same GEMMs with three f16 MFMA products per f32 product.  p carries the
-// two-plane f16 image of the column-scaled weights (ops.pack_h2: image, then the inverse column scales).  Row tile:
-// x3_pick_bm's rule (0 = leave the launch to the f32 kernels).
+// two-plane f16 image of the column-scaled weights (ops.pack_h2: image, then the inverse column scales).
+// Tile of a launch (h2_pick; 0 = leave the launch to the f32 kernels): x3_pick_bm's rule for the 128-column tiles
+// (64 / 128 rows), and for at most 64 output channels - where half of a 128-column tile would be padding - 128 rows x 64
+// columns as four waves along M (code 264): layer1's conv1 / 3x3 convolutions.
 // ------------------------------------------------------------------------------------------------
-template <int WMW, int RB, int NST>
-static int launch_h2_cfg(ConvParams& p, int M_max, hipStream_t stream) {
-    constexpr int BM = 32 * RB * WMW;
+static int h2_pick(long long M, int Cout, int K, int grp_rows, int grp_valid, int bm) {
+    if (bm == 264) return (grp_rows && grp_rows % 128) ? 0 : 264;
+    if (bm != 0) return x3_pick_bm(M, Cout, K, grp_rows, grp_valid, bm);
+    if (Cout <= 64) {
+        if (grp_rows && grp_rows % 128) return 0;
+        if (Cout < 48 || (M + 127) / 128 < 256) return 0;       // mostly padding / too few tiles for a persistent grid
+        return 264;
+    }
+    return x3_pick_bm(M, Cout, K, grp_rows, grp_valid, 0);
+}
+
+template <int WMW, int WNW, int RB, int NST, bool IM2COL>
+static int launch_h2_cfg(ConvParams& p, const H2Im2col& q2, int M_max, hipStream_t stream) {
+    constexpr int BM = 32 * RB * WMW, BN = 64 * WNW;
     const int m_tiles = cdiv(M_max, BM);
+    p.n_tiles_n = cdiv(p.Cout, BN);
     {   // banded raster: <= 2 MB of weight image per band (see ConvParams::band_nt)
-        const long long per_nt = (long long)H2_BN * p.K * 4;
+        const long long per_nt = (long long)BN * p.K * 4;
         p.band_nt = 0; p.band_mt = 0;
         if (per_nt * p.n_tiles_n > 2048 * 1024) {
             int nb = (int)std::max<long long>(1, 2048 * 1024 / per_nt);
@@ -1695,35 +1709,88 @@ static int launch_h2_cfg(ConvParams& p, int M_max, hipStream_t stream) {
     }
     const int tiles = m_tiles * p.n_tiles_n;
     static unsigned long long ok = 0ull;
-    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_h2_kernel<WMW, RB, NST>), &ok);
+    hipError_t attr = fgn_allow_full_lds(reinterpret_cast<const void*>(conv_pw_h2_kernel<WMW, WNW, RB, NST, IM2COL>), &ok);
     if (attr != hipSuccess) return (int)attr;
-    const size_t lds = (size_t)NST * (BM * 128 + H2_B_STAGE);
+    const size_t lds = (size_t)NST * (BM * 128 + 2 * BN * 64);
     const int per_cu = std::min(3, (int)(160 * 1024 / lds));         // resident workgroups per CU (LDS-bound)
     const int grid = std::min(256 * per_cu, (tiles + 7) / 8 * 8);
     p.stamp = fgn_next_stamp_record();
-    FGN_LAUNCH_TIMED((conv_pw_h2_kernel<WMW, RB, NST>), dim3(grid), dim3(128 * WMW), lds, stream, p, tiles);
+    FGN_LAUNCH_TIMED((conv_pw_h2_kernel<WMW, WNW, RB, NST, IM2COL>), dim3(grid), dim3(64 * WMW * WNW), lds, stream, p, q2, tiles);
     FGN_LAUNCH_CHECK();
     return FGN_OK;
 }
 
 extern "C" size_t fgn_h2_image_bytes(int K, int npad, int n_groups) { return (size_t)n_groups * npad * ((size_t)K * 4 + 4); }
+// the tile conv_pw_h2_kernel runs a GEMM of this shape on: 64 / 128 = rows of a 128-column tile, 264 = 128 rows x 64
+// columns, 0 = not supported / not profitable (the h2 entry points return FGN_ERR_SHAPE: use the f32 entry point)
+extern "C" int fgn_h2_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid) {
+    return h2_pick(M, Cout, K, grp_rows, grp_valid, 0);
+}
 
-// bm: 0 = choose, 64 / 128 = force the row tile (two LDS stages), 364 = 64 rows with three stages (measured, not chosen)
-static int launch_h2(const ConvParams& p0, int M_max, int n_groups, int bm, hipStream_t stream) {
+// bm: 0 = choose (h2_pick), 64 / 128 / 264 = force the tile, 364 = 64 rows with three stages (measured, not chosen)
+static int launch_h2(const ConvParams& p0, int M_max, int n_groups, int bm, hipStream_t stream, const H2Im2col* im = nullptr) {
     ConvParams p = p0;
     if (!p.w3 || p.npad3 % H2_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
-    p.n_tiles_n = cdiv(p.Cout, H2_BN);
     const size_t img = (size_t)n_groups * p.K * p.npad3 * 4;
     p.w3_bytes = (unsigned)img;
     p.w_inv = reinterpret_cast<const float*>(static_cast<const char*>(p.w3) + img);
+    H2Im2col none;
+    none.y1 = nullptr; none.x_off0 = none.x_off1 = 0u; none.M0 = none.M1 = 0; none.H1 = none.W1 = none.Ho1 = none.Wo1 = 1; none.cin_shift = 0;
     if (bm == 364) {
-        if (p.K < 3 * BK || (p.grp_rows && p.grp_rows % 64)) return FGN_ERR_SHAPE;
-        return launch_h2_cfg<2, 1, 3>(p, M_max, stream);
+        if (im || p.K < 3 * BK || (p.grp_rows && p.grp_rows % 64)) return FGN_ERR_SHAPE;
+        return launch_h2_cfg<2, 2, 1, 3, false>(p, none, M_max, stream);
     }
-    if (bm != 0 && bm != 64 && bm != 128) return FGN_ERR_SHAPE;
-    const int BM = x3_pick_bm(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, bm);
-    if (BM == 0) return FGN_ERR_SHAPE;
-    return BM == 128 ? launch_h2_cfg<2, 2, 2>(p, M_max, stream) : launch_h2_cfg<2, 1, 2>(p, M_max, stream);
+    if (bm != 0 && bm != 64 && bm != 128 && bm != 264) return FGN_ERR_SHAPE;
+    const int cfg = h2_pick(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, bm);
+    if (cfg == 0) return FGN_ERR_SHAPE;
+    if (im) {
+        if (cfg == 264) return launch_h2_cfg<4, 1, 1, 2, true>(p, *im, M_max, stream);
+        return cfg == 128 ? launch_h2_cfg<2, 2, 2, 2, true>(p, *im, M_max, stream) : launch_h2_cfg<2, 2, 1, 2, true>(p, *im, M_max, stream);
+    }
+    if (cfg == 264) return launch_h2_cfg<4, 1, 1, 2, false>(p, none, M_max, stream);
+    return cfg == 128 ? launch_h2_cfg<2, 2, 2, 2, false>(p, none, M_max, stream) : launch_h2_cfg<2, 2, 1, 2, false>(p, none, M_max, stream);
+}
+
+// A KH x KW (1x1 or 3x3) / stride / pad convolution with folded scale / shift / ReLU on ONE or TWO NHWC tensors that
+// share the weights (x1 == nullptr: one) as an implicit GEMM on conv_pw_h2_kernel: the im2col of conv_igemm_dma_kernel
+// (per row the offset of filter tap (0, 0) and a bit mask of the taps inside the image; per K-tile one wave-uniform tap
+// offset; out-of-image taps fetched out of bounds = zeros) in front of the f16-plane products.  w_h2 = ops.pack_h2 of the
+// packed weights [cout_pad][KH KW Cin] (K order: tap, channel).  Cin / 32 a power of two.  Both inputs must lie within
+// 2 GiB of each other (they do: the query map and the support maps of a layer share one buffer).
+extern "C" int fgn_conv2d_pair_h2_nhwc_f32(const float* x0, int n_img0, int H0, int W0, const float* x1, int n_img1, int H1,
+                                           int W1, const void* w_h2, float* y0, float* y1, const float* scale,
+                                           const float* shift, int Cin, int Cout, int cout_pad, int KH, int KW, int stride,
+                                           int pad, int relu, hipStream_t stream) {
+    if (!x0 || !w_h2 || !y0 || (x1 && !y1)) return FGN_ERR_ARG;
+    if (n_img0 <= 0 || (x1 && n_img1 <= 0)) return FGN_ERR_SHAPE;
+    const int ct = Cin / BK;
+    if (Cin % BK || (ct & (ct - 1)) || KH != KW || (KW != 1 && KW != 3) || stride < 1 || pad < 0 || (Cout & 3) ||
+        cout_pad % H2_BN || cout_pad < Cout || H0 <= 0 || W0 <= 0)
+        return FGN_ERR_SHAPE;
+    const int Ho0 = (H0 + 2 * pad - KH) / stride + 1, Wo0 = (W0 + 2 * pad - KW) / stride + 1;
+    const int Ho1 = x1 ? (H1 + 2 * pad - KH) / stride + 1 : 1, Wo1 = x1 ? (W1 + 2 * pad - KW) / stride + 1 : 1;
+    if (Ho0 <= 0 || Wo0 <= 0 || Ho1 <= 0 || Wo1 <= 0) return FGN_ERR_SHAPE;
+    const long long M0 = (long long)n_img0 * Ho0 * Wo0, M1 = x1 ? (long long)n_img1 * Ho1 * Wo1 : 0;
+    const long long b0 = (long long)n_img0 * H0 * W0 * Cin * 4, b1 = x1 ? (long long)n_img1 * H1 * W1 * Cin * 4 : 0;
+    const char* lo = reinterpret_cast<const char*>(x0);
+    if (x1 && reinterpret_cast<const char*>(x1) < lo) lo = reinterpret_cast<const char*>(x1);
+    const long long off0 = reinterpret_cast<const char*>(x0) - lo, off1 = x1 ? reinterpret_cast<const char*>(x1) - lo : 0;
+    const long long span = std::max(off0 + b0, off1 + b1);
+    const int K = KH * KW * Cin;
+    const long long wb = (long long)fgn_h2_image_bytes(K, cout_pad, 1);
+    if (span >= 0x7fffff00ll || wb >= 0x7fffff00ll || (M0 + M1) * Cout >= (1ll << 31)) return FGN_ERR_SHAPE;
+    ConvParams p;
+    x3_base_params(p);
+    p.x = reinterpret_cast<const float*>(lo); p.x_bytes = (unsigned)span; p.y = y0; p.scale = scale; p.shift = shift;
+    p.n_img = n_img0; p.H = H0; p.W = W0; p.Ho = Ho0; p.Wo = Wo0; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+    p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.K = K; p.kt_per_split = K / BK;
+    p.w3 = w_h2; p.npad3 = cout_pad;
+    H2Im2col q;
+    q.y1 = y1; q.x_off0 = (unsigned)off0; q.x_off1 = (unsigned)off1; q.M0 = (int)M0; q.M1 = (int)M1;
+    q.H1 = x1 ? H1 : 1; q.W1 = x1 ? W1 : 1; q.Ho1 = Ho1; q.Wo1 = Wo1;
+    q.cin_shift = 0;
+    while ((1 << q.cin_shift) < ct) ++q.cin_shift;
+    return launch_h2(p, (int)(M0 + M1), 1, 0, stream, &q);
 }
 
 // y[rows, Cout] = relu?(x[rows, K] * W^T + shift + residual) with W given as its two-plane f16 image (ops.pack_h2);

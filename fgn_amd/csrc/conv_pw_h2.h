@@ -67,16 +67,31 @@ __device__ __forceinline__ H2Frag h2_split(const float4& a, const float4& b, con
     return f;
 }
 
-constexpr int H2_BN = 128;
-constexpr int H2_B_STAGE = 2 * H2_BN * 64;       // bytes of one K-tile of the weight image for 128 columns
+constexpr int H2_BN = 128;                       // columns the weight image is padded to
 
-template <int WMW, int RB, int NST>
-__global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvParams p, const int total_tiles) {
-    constexpr int BM = 32 * RB * WMW, BN = H2_BN, NTHR = 128 * WMW, NW = 2 * WMW;
+// Second tensor / spatial structure of an IM2COL launch (conv_pw_h2_kernel<..., true>): a KH x KW / stride / pad convolution
+// (KW 1 or 3, Cin / 32 a power of two) as an implicit GEMM over the rows of ONE or TWO NHWC tensors with the same weights
+// (the query map and the support maps of a backbone layer): rows [0, M0) are the output pixels of tensor 0 (ConvParams:
+// n_img, H, W, Ho, Wo; input at x + x_off0 bytes, output y), rows [M0, M0 + M1) those of tensor 1 (input at x + x_off1,
+// output y1).  Both inputs lie inside the one buffer descriptor [x, x + x_bytes).
+struct H2Im2col {
+    float* y1;
+    unsigned x_off0, x_off1;
+    int M0, M1;
+    int H1, W1, Ho1, Wo1;
+    int cin_shift;            // log2(Cin / 32)
+};
+
+template <int WMW, int WNW, int RB, int NST, bool IM2COL>
+__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_pw_h2_kernel(const ConvParams p, const H2Im2col q2, const int total_tiles) {
+    constexpr int BM = 32 * RB * WMW, BN = 64 * WNW, NTHR = 64 * WMW * WNW, NW = WMW * WNW;
     constexpr int A_LD = BM / 8 / NW;                       // activation wave-instructions per wave per K-tile (8 rows each)
     constexpr int A_STAGE = BM * 128;                       // bytes
-    constexpr int STAGE = A_STAGE + H2_B_STAGE;             // bytes
-    constexpr int B_LD = 16 / NW;                           // weight wave-instructions per wave per K-tile
+    constexpr int B_STAGE = 2 * BN * 64;                    // bytes of one K-tile of the weight image for BN columns
+    constexpr int STAGE = A_STAGE + B_STAGE;                // bytes
+    constexpr int BQ = BN / 16;                             // weight wave-instructions per plane per K-tile (16 rows each)
+    constexpr int B_LD = 2 * BQ / NW;                       // weight wave-instructions per wave per K-tile
+    static_assert(A_LD * 8 * NW == BM && B_LD * NW == 2 * BQ, "tile / wave split");
     constexpr int PER = A_LD + B_LD;                        // LDS-DMA wave-instructions per wave per K-tile
     constexpr int D = NST - 1;                              // K-tiles in flight ahead of the one being multiplied
     constexpr int ROWS_PER_PASS = NTHR / 8;                 // A rows one pass of the workgroup's DMAs covers
@@ -84,8 +99,8 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int M = (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
+    const int wm = wv / WNW, wn = wv % WNW;
+    const int M = IM2COL ? q2.M0 + q2.M1 : (p.n_img_dev ? min(p.n_img, *p.n_img_dev) : p.n_img) * p.Ho * p.Wo;
     int grp_valid = p.grp_valid;
     if (p.grp_rows && p.grp_count_dev) grp_valid = min(grp_valid, min(p.grp_items, *p.grp_count_dev) * p.grp_rows_per_item);
 
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
     const int src_c4 = col4 ^ ((row0 >> 1) & 7);
     const i32x4 x_rs = make_rsrc(p.x, p.x_bytes);
     const i32x4 w_rs = make_rsrc(p.w3, p.w3_bytes);
-    const bool dual = p.x2 != nullptr;
+    const bool dual = !IM2COL && p.x2 != nullptr;
     const i32x4 x2_rs = make_rsrc(dual ? p.x2 : p.x, dual ? p.x2_bytes : p.x_bytes);
     const int KT = p.K / BK;                                                  // >= D (checked by the launcher)
     const unsigned kt_bytes = (unsigned)(2 * p.npad3 * 64);          // one K-tile of the image, both planes, all rows
@@ -132,12 +147,14 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
         return -1;
     };
 
+    // IM2COL: a[i] = byte offset of filter tap (0, 0) of the row's receptive field (may lie before the tensor: wraps),
+    // a2[i] = bit (ky KW + kx) set when the tap is inside the image (and the row < M) | bit 31 when the row is of tensor 1
     struct Offs { unsigned a[A_LD], a2[A_LD], b[B_LD]; };
     unsigned b_lds[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-        const int q = wv + NW * i;                     // wave-instruction q of 16: plane q / 8, rows 16 * (q % 8) ..
-        b_lds[i] = __builtin_amdgcn_readfirstlane((unsigned)(A_STAGE + (q >> 3) * (BN * 64) + (q & 7) * 1024));
+        const int q = wv + NW * i;                     // wave-instruction q of 2 BQ: plane q / BQ, rows 16 * (q % BQ) ..
+        b_lds[i] = __builtin_amdgcn_readfirstlane((unsigned)(A_STAGE + (q / BQ) * (BN * 64) + (q % BQ) * 1024));
     }
     auto offsets = [&](int m0, int n0) -> Offs {
         Offs o;
@@ -147,6 +164,30 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int m = m0 + row0 + ROWS_PER_PASS * i;
+            if constexpr (IM2COL) {
+                o.a[i] = 0u; o.a2[i] = 0u;
+                if (m < M) {
+                    const bool t1 = m >= q2.M0;
+                    const int mm = t1 ? m - q2.M0 : m;
+                    const int H = t1 ? q2.H1 : p.H, W = t1 ? q2.W1 : p.W, Wo = t1 ? q2.Wo1 : p.Wo;
+                    const int HoWo = (t1 ? q2.Ho1 : p.Ho) * Wo;
+                    const int img = mm / HoWo;
+                    const int rem = mm - img * HoWo;
+                    const int oy = rem / Wo;
+                    const int ox = rem - oy * Wo;
+                    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                    o.a[i] = (t1 ? q2.x_off1 : q2.x_off0) + (unsigned)((((img * H + iy0) * W + ix0) * p.Cin + src_c4 * 4) * 4);
+                    unsigned tm = t1 ? 0x80000000u : 0u;
+                    int tp = 0;
+                    for (int ky = 0; ky < p.KH; ++ky) {
+                        const bool y_ok = (unsigned)(iy0 + ky) < (unsigned)H;
+                        for (int kx = 0; kx < p.KW; ++kx, ++tp)
+                            if (y_ok && (unsigned)(ix0 + kx) < (unsigned)W) tm |= 1u << tp;
+                    }
+                    o.a2[i] = tm;
+                }
+                continue;
+            }
             const bool in = m < M && m < g_end;
             o.a[i] = in ? (unsigned)((m * p.Cin + src_c4 * 4) * 4) : OOB;
             o.a2[i] = OOB;
@@ -157,7 +198,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int q = wv + NW * i;
-            const int plane = q >> 3, row = (q & 7) * 16 + (lane >> 2);
+            const int plane = q / BQ, row = (q % BQ) * 16 + (lane >> 2);
             o.b[i] = g0 + (unsigned)(((plane * p.npad3 + n0 + row) * 4 + (lane & 3)) * 16);
         }
         return o;
@@ -166,7 +207,21 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
         const unsigned st = lds_base + stage * STAGE;
         const unsigned sa = st + wave_row_bytes;
         const unsigned ko = (unsigned)(kt * BK * 4);
-        if (dual && kt >= p.kt1) {
+        if constexpr (IM2COL) {
+            // K-tile -> (filter tap, channel slice), wave-uniform; the tap's byte offset differs with the tensor's width
+            const int tap = kt >> q2.cin_shift;
+            const int c0 = (kt - (tap << q2.cin_shift)) * BK;
+            const int ky = p.KW == 3 ? (tap * 43) >> 7 : tap;             // tap / 3 for tap <= 8; KW == 1: one column
+            const int kx = tap - ky * p.KW;
+            const unsigned off0 = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * 4);
+            const unsigned off1 = (unsigned)(((ky * q2.W1 + kx) * p.Cin + c0) * 4);
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = (o.a2[i] >> tap) & 1u;
+                const unsigned voff = ok ? o.a[i] + ((o.a2[i] >> 31) ? off1 : off0) : OOB;     // out-of-image taps: zeros
+                lds_dma16_s(x_rs, sa + i * ROWS_PER_PASS * 128, voff, 0u);
+            }
+        } else if (dual && kt >= p.kt1) {
             const unsigned ko2 = (unsigned)((kt - p.kt1) * BK * 4);
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) lds_dma16_s(x2_rs, sa + i * ROWS_PER_PASS * 128, o.a2[i], ko2);
@@ -338,8 +393,8 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
                     }
             }
             __syncthreads();
-            constexpr int C4 = BN / 4, RPP = NTHR / C4, NPASS = PR / RPP;
-            static_assert(NPASS % 4 == 0, "row sweeps in groups of four");
+            constexpr int C4 = BN / 4, RPP = NTHR / C4, NPASS = PR / RPP, SW = NPASS < 4 ? NPASS : 4;
+            static_assert(NPASS % SW == 0, "row sweeps in groups of SW");
             const int c4 = t % C4, rr = t / C4;
             const int n = en0 + c4 * 4;
             if (n < p.Cout) {
@@ -348,16 +403,16 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
                 if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + n);
                 const float4 iv = *reinterpret_cast<const float4*>(winv + n);     // the column scales out again (exact)
 #pragma unroll
-                for (int k0 = 0; k0 < NPASS; k0 += 4) {
-                    float4 res[4];
+                for (int k0 = 0; k0 < NPASS; k0 += SW) {
+                    float4 res[SW];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < SW; ++k) {
                         const int m = em0 + PR * pass + rr + RPP * (k0 + k);
                         res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (p.residual && m < M) res[k] = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.Cout + n);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < SW; ++k) {
                         const int row = rr + RPP * (k0 + k);
                         const int m = em0 + PR * pass + row;
                         if (m >= M) continue;
@@ -368,7 +423,8 @@ __global__ __launch_bounds__(128 * WMW, 2) void conv_pw_h2_kernel(const ConvPara
                         if (p.relu) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         }
-                        *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = v;
+                        float* const yrow = (IM2COL && m >= q2.M0) ? q2.y1 + (size_t)(m - q2.M0) * p.Cout : p.y + (size_t)m * p.Cout;
+                        *reinterpret_cast<float4*>(yrow + n) = v;
                     }
                 }
             }

@@ -63,6 +63,8 @@ SIGNATURES = {
     'fgn_conv1x1_dual_x3_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_winograd_gemm_x3_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_h2_image_bytes': (C.c_size_t, [_i, _i, _i]),
+    'fgn_h2_row_tile': (_i, [C.c_longlong, _i, _i, _i, _i]),
+    'fgn_conv2d_pair_h2_nhwc_f32': (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_gemm_h2_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_conv1x1_h2_nhwc_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'fgn_conv1x1_dual_h2_nhwc_f32': (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

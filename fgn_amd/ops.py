@@ -37,7 +37,9 @@ FUSED_SHORTCUT = os.environ.get('FGN_FUSED_SHORTCUT', '1') != '0'
 GEMM_MATH = os.environ.get('FGN_GEMM_MATH', 'h2')
 # by row tile (fgn_x3_row_tile); template arguments: waves along M, 32-row blocks per wave, terms, LDS stages, 16x16x32 MFMA
 X3_KERNELS = {64: 'conv_pw_x3_kernel<2, 1, 6, 2, true>', 128: 'conv_pw_x3_kernel<2, 2, 6, 2, true>'}
-H2_KERNELS = {64: 'conv_pw_h2_kernel<2, 1, 2>', 128: 'conv_pw_h2_kernel<2, 2, 2>'}     # waves along M, row blocks per wave, LDS stages
+# by tile (fgn_h2_row_tile: 64 / 128 rows x 128 columns, 264 = 128 rows x 64 columns); template arguments: waves along M,
+# waves along N, 32-row blocks per wave, LDS stages, implicit-GEMM loader (3x3 / strided convolutions)
+H2_KERNELS = {64: 'conv_pw_h2_kernel<2, 2, 1, 2, %s>', 128: 'conv_pw_h2_kernel<2, 2, 2, 2, %s>', 264: 'conv_pw_h2_kernel<4, 1, 1, 2, %s>'}
 
 
 def x3_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0) -> str:
@@ -45,9 +47,9 @@ def x3_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 
     return X3_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_x3_kernel<?>')
 
 
-def h2_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0) -> str:
-    """The same for conv_pw_h2_kernel (it takes conv_pw_x3_kernel's row tile rule)."""
-    return H2_KERNELS.get(_lib.load().fgn_x3_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_h2_kernel<?>')
+def h2_kernel(rows: int, cout: int, k: int, grp_rows: int = 0, grp_valid: int = 0, im2col: bool = False) -> str:
+    """The same for conv_pw_h2_kernel."""
+    return H2_KERNELS.get(_lib.load().fgn_h2_row_tile(rows, cout, k, grp_rows, grp_valid), 'conv_pw_h2_kernel<?, %s>') % ('true' if im2col else 'false')
 
 
 class gemm_math:
@@ -277,9 +279,17 @@ def _x3_ok(cin: int, cout: int) -> bool:
 
 
 def _h2_ok(cin: int, cout: int) -> bool:
-    """The same for the f16-plane image of conv_pw_h2_kernel (GEMM_MATH 'h2': it takes the launches 'x3' would)."""
+    """The same for the f16-plane image of conv_pw_h2_kernel (GEMM_MATH 'h2': the launches 'x3' would take, and - on its
+    64-column tile - layers of 48 .. 64 output channels; fgn_h2_row_tile decides per launch)."""
     npad = (cout + 127) // 128 * 128
-    return GEMM_MATH == 'h2' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout * 10 >= npad * 7
+    return GEMM_MATH == 'h2' and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and (cout * 10 >= npad * 7 or 48 <= cout <= 64)
+
+
+def _h2_conv_ok(cin: int, cout: int, kh: int, kw: int) -> bool:
+    """Whether a 3x3 (any stride) or strided 1x1 convolution gets an f16-plane image for the implicit-GEMM form of
+    conv_pw_h2_kernel (fgn_conv2d_pair_h2_nhwc_f32): Cin / 32 a power of two."""
+    ct = cin // 32
+    return _h2_ok(cin, cout) and (kh, kw) in ((1, 1), (3, 3)) and ct & (ct - 1) == 0
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[dict] = None,
@@ -316,7 +326,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Opt
         shift = bias.detach().float().clone()
     pw = kh == 1 and kw == 1 and stride == 1 and pad == 0
     w3 = pack_x3(w) if (pw and _x3_ok(cin, cout)) else None
-    wh = pack_h2(w) if (pw and _h2_ok(cin, cout)) else None
+    wh = pack_h2(w) if ((pw and _h2_ok(cin, cout)) or (not pw and cin != 4 and _h2_conv_ok(cin, cout, kh, kw))) else None
     return ConvLayer(w.contiguous(), None if scale is None else scale.contiguous(),
                      None if shift is None else shift.contiguous(), cin, cout, cout_pad, kh, kw,
                      stride, pad, relu, w3, wh)
@@ -357,8 +367,25 @@ def conv2d(x: torch.Tensor, layer: ConvLayer, residual: Optional[torch.Tensor] =
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
-    if (layer.w3 is not None or layer.wh is not None) and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
-            x.numel() * 4 < 0x7fffff00 and out.numel() < (1 << 31) and L.fgn_x3_row_tile(n_img * ho * wo, layer.cout, cin, 0, 0) > 0:
+    pw = layer.kh == 1 and layer.kw == 1 and layer.stride == 1 and layer.pad == 0
+    if layer.wh is not None and not pw and in_scale is None and a_img_div == 1 and tile_hint == 0 and residual is None and \
+            n_img_dev is None and x.numel() * 4 < 0x7fffff00 and out.numel() < (1 << 31) and \
+            L.fgn_h2_row_tile(n_img * ho * wo, layer.cout, layer.kh * layer.kw * cin, 0, 0) > 0:
+        # 3x3 / strided convolution as an implicit GEMM on conv_pw_h2_kernel (one tensor)
+        rc = L.fgn_conv2d_pair_h2_nhwc_f32(_ptr(x), n_img, H, W, None, 0, 1, 1, layer.wh.data_ptr(), _ptr(out), None,
+                                           _ptr(layer.scale), _ptr(layer.shift), cin, layer.cout, layer.cout_pad, layer.kh,
+                                           layer.kw, layer.stride, layer.pad, int(layer.relu), _stream())
+        _lib.check(rc, 'fgn_conv2d_pair_h2_nhwc_f32')
+        if prof is not None:
+            k = layer.kh * layer.kw * cin
+            flop = 2.0 * ho * wo * layer.cout * k
+            prof.append(dict(kind='conv', kernel=h2_kernel(n_img * ho * wo, layer.cout, k, im2col=True), math='h2', e0=e0, e1=e1,
+                             flop_direct=flop, flop_issued=flop, n_img=n_img, n_img_dev=None, gemm=(1, ho * wo, layer.cout, k),
+                             residual=False, shape=(n_img, H, W, cin, layer.cout, layer.kh, layer.stride)))
+        return out
+    if pw and (layer.w3 is not None or layer.wh is not None) and in_scale is None and a_img_div == 1 and tile_hint == 0 and \
+            x.numel() * 4 < 0x7fffff00 and out.numel() < (1 << 31) and \
+            (L.fgn_h2_row_tile if layer.wh is not None else L.fgn_x3_row_tile)(n_img * ho * wo, layer.cout, cin, 0, 0) > 0:
         h2 = layer.wh is not None
         f = L.fgn_conv1x1_h2_nhwc_f32 if h2 else L.fgn_conv1x1_x3_nhwc_f32
         rc = f(_ptr(x), (layer.wh if h2 else layer.w3).data_ptr(), _ptr(out), _ptr(layer.scale), _ptr(layer.shift),
@@ -588,7 +615,7 @@ def conv1x1_dual(x1: torch.Tensor, x2: torch.Tensor, layer: DualConvLayer, out: 
     if prof is not None:
         e0, e1 = prof.arm()
     use_x3 = (layer.w3 is not None or layer.wh is not None) and max(x1.numel(), x2.numel()) * 4 < 0x7fffff00 and \
-        L.fgn_x3_row_tile(rows, layer.cout, layer.cin1 + layer.cin2, 0, 0) > 0
+        (L.fgn_h2_row_tile if layer.wh is not None else L.fgn_x3_row_tile)(rows, layer.cout, layer.cin1 + layer.cin2, 0, 0) > 0
     use_h2 = use_x3 and layer.wh is not None
     if use_x3:
         f = L.fgn_conv1x1_dual_h2_nhwc_f32 if use_h2 else L.fgn_conv1x1_dual_x3_nhwc_f32
@@ -633,6 +660,24 @@ def conv2d_pair(x0: torch.Tensor, x1: torch.Tensor, layer: ConvLayer, out0: Opti
     L = _lib.load()
     if prof is not None:
         e0, e1 = prof.arm()
+    rows = sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)
+    k = layer.kh * layer.kw * layer.cin
+    span = abs(x0.data_ptr() - x1.data_ptr()) + max(x0.numel(), x1.numel()) * 4
+    if layer.wh is not None and layer.cin != 4 and span < 0x7fffff00 and rows * layer.cout < (1 << 31) and \
+            L.fgn_h2_row_tile(rows, layer.cout, k, 0, 0) > 0:
+        # the implicit GEMM of both tensors on conv_pw_h2_kernel
+        rc = L.fgn_conv2d_pair_h2_nhwc_f32(_ptr(x0), x0.shape[0], x0.shape[1], x0.shape[2], _ptr(x1), x1.shape[0], x1.shape[1],
+                                           x1.shape[2], layer.wh.data_ptr(), _ptr(outs[0]), _ptr(outs[1]), _ptr(layer.scale),
+                                           _ptr(layer.shift), layer.cin, layer.cout, layer.cout_pad, layer.kh, layer.kw,
+                                           layer.stride, layer.pad, int(layer.relu), _stream())
+        _lib.check(rc, 'fgn_conv2d_pair_h2_nhwc_f32')
+        if prof is not None:
+            flop = 2.0 * layer.cout * k * rows
+            prof.append(dict(kind='conv', kernel=h2_kernel(rows, layer.cout, k, im2col=True), math='h2', e0=e0, e1=e1,
+                             flop_direct=flop, flop_issued=flop, n_img=1, n_img_dev=None, gemm=(1, rows, layer.cout, k),
+                             shape=(x0.shape[0] + x1.shape[0], x0.shape[1], x0.shape[2], layer.cin, layer.cout, layer.kh,
+                                    layer.stride)))
+        return outs[0], outs[1]
     rc = L.fgn_conv2d_pair_nhwc_f32(_ptr(x0), _ptr(outs[0]), x0.shape[0], x0.shape[1], x0.shape[2],
                                     _ptr(x1), _ptr(outs[1]), x1.shape[0], x1.shape[1], x1.shape[2],
                                     _ptr(layer.w), _ptr(layer.scale), _ptr(layer.shift), layer.cin, layer.cout,
@@ -813,7 +858,8 @@ def conv3x3_winograd(x: torch.Tensor, layer: WinogradLayer, in_scale: Optional[t
     ev = [] if prof is not None else None
     if ev is not None:
         ev.append(prof.arm())
-    use_x3 = (layer.u3 is not None or layer.uh is not None) and L.fgn_x3_row_tile(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) > 0
+    use_x3 = (layer.u3 is not None or layer.uh is not None) and \
+        (L.fgn_h2_row_tile if layer.uh is not None else L.fgn_x3_row_tile)(G * t_pad, layer.cout, cin, t_pad, n_img * tiles) > 0
     use_h2 = use_x3 and layer.uh is not None
     use_x3 = use_x3 and not use_h2
     _lib.check(f_in(_ptr(x), _ptr(in_scale), _ptr(V), _ptr(n_img_dev), n_img, a_img_div, H, W, cin, t_pad, st),
@@ -886,7 +932,8 @@ def conv3x3_winograd_multi(xs, layer: WinogradLayer, outs) -> None:
     ev = []
     if prof is not None:
         ev.append(prof.arm())
-    use_x3 = (layer.u3 is not None or layer.uh is not None) and L.fgn_x3_row_tile(G * t_pad, cout, cin, t_pad, total) > 0
+    use_x3 = (layer.u3 is not None or layer.uh is not None) and \
+        (L.fgn_h2_row_tile if layer.uh is not None else L.fgn_x3_row_tile)(G * t_pad, cout, cin, t_pad, total) > 0
     use_h2 = use_x3 and layer.uh is not None
     use_x3 = use_x3 and not use_h2
     if pair:

@@ -132,9 +132,18 @@ int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const 
  * new one and the accumulators follow by the exact ratio).  Same call sites and arguments as the x3 entry points, with
  *   w_h2: [groups][K / 32][2 planes][cout_pad][32] f16 of the column-scaled weights (k order and chunk swizzle of w_x3),
  *         then [groups][cout_pad] f32 inverse column scales.  fgn_h2_image_bytes = the size of both.
- * Shapes: as the x3 entry points (fgn_x3_row_tile decides for both).  fgn_gemm_h2_f32: the direct entry (tests, tools);
- * bm 0 / 64 / 128 as fgn_gemm_x3_f32, 364 = 64 rows with three LDS stages (measured, not chosen). */
+ * Shapes: as the x3 entry points, and Cout 48..64 on a 64-column tile (fgn_h2_row_tile decides).  fgn_gemm_h2_f32: the direct entry (tests, tools);
+ * bm 0 (= fgn_h2_row_tile) / 64 / 128 / 264, 364 = 64 rows with three LDS stages (measured, not chosen). */
 size_t fgn_h2_image_bytes(int K, int npad, int n_groups);
+int fgn_h2_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid);   /* 64 / 128: rows of a 128-column tile; 264: 128 rows x 64 columns (Cout 48..64); 0: use the f32 entry point */
+/* A 3x3 or 1x1 convolution of any stride / padding with folded scale / shift / ReLU on ONE or TWO NHWC tensors that share
+ * the weights (x1 == NULL: one; two: the query map and the support maps of a backbone layer, fgn_conv2d_pair_nhwc_f32's
+ * call sites) as an implicit GEMM on conv_pw_h2_kernel.  w_h2 = the f16-plane image of the packed weights
+ * [cout_pad][KH KW Cin] (K order tap, channel: fgn_amd/ops.py::pack_conv, pack_h2); Cin / 32 a power of two; the two
+ * inputs within 2 GiB of each other. */
+int fgn_conv2d_pair_h2_nhwc_f32(const float* x0, int n_img0, int H0, int W0, const float* x1, int n_img1, int H1, int W1,
+                                const void* w_h2, float* y0, float* y1, const float* scale, const float* shift, int Cin,
+                                int Cout, int cout_pad, int KH, int KW, int stride, int pad, int relu, void* stream);
 int fgn_gemm_h2_f32(const float* x, const void* w_h2, float* y, const float* shift, const float* residual, int rows, int K,
                     int Cout, int npad, int relu, int grp_rows, int grp_valid, int n_groups, int bm, void* stream);
 int fgn_conv1x1_h2_nhwc_f32(const float* x, const void* w_h2, float* y, const float* scale, const float* shift,

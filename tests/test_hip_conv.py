@@ -164,7 +164,7 @@ def test_repeated_runs_are_bit_identical_at_full_occupancy():
 @pytest.mark.parametrize('rows,cin,cout,res,relu', [(49 * 300, 512, 1024, True, True), (103664, 64, 256, True, True),
                                                     (26016, 128, 512, False, True), (49 * 300 + 17, 1024, 1024, False, False),
                                                     (4200 * 5, 96, 260, True, False)])
-@pytest.mark.parametrize('math', ['f32', 'x3'])
+@pytest.mark.parametrize('math', ['f32', 'x3', 'h2'])
 def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, cin, cout, res, relu, math):
     """conv_pw_persist_kernel (the dominant kernel of an episode: 1x1 / stride 1 launches with more 64x64 output tiles
     than its 1024 persistent workgroups) at the episode's own shapes and at ragged ones (a last row tile of 17 rows, a
@@ -173,7 +173,8 @@ def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, 
     the two differ only in the order of the K sum inside a 16-deep step (16x16x4 vs 32x32x2 MFMA: 2e-6 of the range),
     and every output element must be covered exactly once (a tile walked twice or skipped shows at once).
     math = 'x3': the same launches on conv_pw_x3_kernel (six bf16 MFMA products per f32 product, the build's default) -
-    the same bound against fp64, and within 4e-6 of the range of the f32 one-tile kernel's pieces."""
+    the same bound against fp64, and within 4e-6 of the range of the f32 one-tile kernel's pieces; 'h2': on
+    conv_pw_h2_kernel (three f16 products; the default)."""
     from fgn_amd import lib, ops
     g = torch.Generator().manual_seed(rows + cin)
     x = torch.randn(rows, cin, generator=g)
@@ -184,6 +185,7 @@ def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, 
     with ops.gemm_math(math):
         layer = ops.pack_conv(wt, bn=bn, relu=relu).to('cuda')
         assert (layer.w3 is not None) == ops._x3_ok(cin, cout)         # (Cout 260: 68 % of its 128-column tiles -> f32)
+        assert (layer.wh is not None) == ops._h2_ok(cin, cout)
     xc = x.cuda().view(1, rows, 1, cin)
     rc = None if r is None else r.cuda().view(1, rows, 1, cout)
     L = lib.load()
@@ -208,41 +210,78 @@ def test_persistent_pointwise_kernel_matches_fp64_and_the_one_tile_kernel(rows, 
 
 
 @pytest.mark.parametrize('cin,cout,k,stride', [(128, 128, 3, 2), (256, 512, 1, 2), (64, 64, 3, 1), (4, 64, 7, 2)])
-def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride):
+@pytest.mark.parametrize('math', ['f32', 'h2'])
+def test_two_tensor_launch_equals_one_launch_per_tensor(cin, cout, k, stride, math):
     """``ops.conv2d_pair``: the query map and the support maps of a strided backbone layer in ONE launch.  Per tensor it
     is the arithmetic of ``conv2d`` without split-K: identical bytes where the single launch is not split, within
-    rounding of the K order where it is (the small support half alone is split to fill the chip)."""
+    rounding of the K order where it is (the small support half alone is split to fill the chip).
+    math = 'h2' (the default): the 3x3 / strided layers as implicit GEMMs on conv_pw_h2_kernel (fgn_conv2d_pair_h2_nhwc_f32;
+    the stem, Cin 4, stays on the f32 kernels): against fp64 like every conv kernel, the two-tensor launch within the
+    accumulation's rounding of one launch per tensor (a wave's rows, and so its scale, differ between the two), and the
+    query half alone falls back to nothing - the library's own kernel id confirms which kernels ran."""
     from fgn_amd import lib, ops
     g = torch.Generator().manual_seed(17)
     real_cin = 3 if cin == 4 else cin
     wt = torch.randn(cout, real_cin, k, k, generator=g) / (real_cin * k * k) ** 0.5
     bn = dict(weight=torch.rand(cout, generator=g) + 0.5, bias=torch.randn(cout, generator=g) * 0.1,
               running_mean=torch.randn(cout, generator=g) * 0.1, running_var=torch.rand(cout, generator=g) + 0.5)
-    layer = ops.pack_conv(wt, bn=bn, stride=stride, pad=k // 2, relu=True, **({'pad_cin_to': 4} if cin == 4 else {})).to('cuda')
-    xq = torch.randn(1, 101, 167, cin, generator=g).cuda()
+    with ops.gemm_math(math):
+        layer = ops.pack_conv(wt, bn=bn, stride=stride, pad=k // 2, relu=True, **({'pad_cin_to': 4} if cin == 4 else {})).to('cuda')
+    h2 = math == 'h2' and cin != 4
+    assert (layer.wh is not None) == h2
+    xq = torch.randn(1, 201, 335, cin, generator=g).cuda()
     xs = torch.randn(9, 32, 32, cin, generator=g).cuda()
     if cin == 4:
         xq[..., 3] = 0
         xs[..., 3] = 0
     yq, ys = ops.conv2d_pair(xq, xs, layer)
     L = lib.load()
+    sc = bn['weight'].double() / torch.sqrt(bn['running_var'].double() + 1e-5)
     for x, y in ((xq, yq), (xs, ys)):
         ref = ops.conv2d(x, layer)
         assert y.shape == ref.shape
+        if h2:
+            r64 = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double(), stride=stride, padding=k // 2)
+            r64 = torch.relu(r64 * sc[None, :, None, None] + (bn['bias'].double() - bn['running_mean'].double() * sc)[None, :, None, None])
+            r64 = r64.permute(0, 2, 3, 1)
+            rng = r64.abs().max().item()
+            assert (y.cpu().double() - r64).abs().max().item() <= 2e-6 * rng
+            assert (ref.cpu().double() - r64).abs().max().item() <= 2e-6 * rng
+            assert (y - ref).abs().max().item() <= 2.5e-6 * rng      # (a small single launch runs on the f32 kernels)
+            continue
         split = L.fgn_conv2d_workspace_bytes(x.shape[0], x.shape[1], x.shape[2], cin, cout, k, k, stride, k // 2, 0) > 0
         if split:
             assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
         else:
             assert torch.equal(y, ref)
+    if h2:      # the launch shapes of this test are large enough for the h2 tile rule (else the pair fell back to the f32 kernel)
+        rows = yq.shape[0] * yq.shape[1] * yq.shape[2] + ys.shape[0] * ys.shape[1] * ys.shape[2]
+        assert L.fgn_h2_row_tile(rows, cout, k * k * cin, 0, 0) > 0
     # outputs into caller-provided buffers (views of one allocation, as the backbone uses them)
     buf = torch.empty(yq.numel() + ys.numel(), device='cuda')
     oq, os_ = buf[:yq.numel()].view(yq.shape), buf[yq.numel():].view(ys.shape)
     ops.conv2d_pair(xq, xs, layer, oq, os_)
     assert torch.equal(oq, yq) and torch.equal(os_, ys)
+    # the two inputs as views of one allocation (how the backbone holds them: the implicit-GEMM form addresses both through
+    # one buffer descriptor and leaves inputs more than 2 GiB apart - separate allocations can be - to the f32 kernels), the
+    # query map first and the support maps first: identical bytes, and the fp64 bound again
+    res = []
+    for first in ('q', 's'):
+        xb = torch.empty(xq.numel() + xs.numel(), device='cuda')
+        if first == 'q':
+            xq2, xs2 = xb[:xq.numel()].view(xq.shape), xb[xq.numel():].view(xs.shape)
+        else:
+            xs2, xq2 = xb[:xs.numel()].view(xs.shape), xb[xs.numel():].view(xq.shape)
+        xs2.copy_(xs); xq2.copy_(xq)
+        res.append(ops.conv2d_pair(xq2, xs2, layer))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    tol = 2.5e-6 if h2 else 2e-6
+    assert (res[0][0] - yq).abs().max().item() <= tol * yq.abs().max().item()
+    assert (res[0][1] - ys).abs().max().item() <= tol * ys.abs().max().item()
 
 
 @pytest.mark.parametrize('rows,cin1,cin2,cout', [(103664, 64, 64, 256), (5000, 32, 96, 132), (777, 128, 32, 64)])
-@pytest.mark.parametrize('math', ['f32', 'x3'])
+@pytest.mark.parametrize('math', ['f32', 'x3', 'h2'])
 def test_dual_operand_pointwise_conv_is_conv3_plus_shortcut(rows, cin1, cin2, cout, math):
     """``conv1x1_dual`` (fgn_conv1x1_dual_nhwc_f32): relu(bn3(conv3(y)) + bn_d(conv_d(x))) of the first Bottleneck of a
     stride-1 stage as ONE K loop over [y | x] with the BatchNorm scales folded into the weights - against fp64, and
@@ -398,7 +437,8 @@ def test_x3_gemm_epilogue_and_special_values():
 
 
 @pytest.mark.parametrize('groups,grp_rows,valid,K,N', [(1, 14700, 14700, 1024, 1024), (1, 3001, 3001, 64, 76), (1, 130, 130, 96, 260),
-                                                       (36, 256, 201, 128, 132), (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256)])
+                                                       (36, 256, 201, 128, 132), (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256),
+                                                       (1, 40000, 40000, 256, 64), (1, 33000, 33000, 576, 52)])
 @pytest.mark.parametrize('mag', [1.0, 3e-5, 2e7])
 def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, valid, K, N, mag):
     """conv_pw_h2_kernel through its direct entry (fgn_gemm_h2_f32): f32 operands, every product as three f16 MFMA products of
@@ -420,8 +460,10 @@ def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     rng = ref.abs().max().item()
     img = ops.pack_h2(w)
     outs = {}
-    for bm in (64, 128, 364):
-        tile = 128 if bm == 128 else 64
+    assert lib.load().fgn_h2_row_tile(groups * grp_rows, N, K, grp_rows if groups > 1 else 0, valid if groups > 1 else 0) == \
+        {1024: 128, 76: 0, 260: 0, 132: 0, 128: 0, 512: 0, 256: 64, 64: 264, 52: 264}[N]
+    for bm in (64, 128, 364, 264):                     # 264: 128 rows x 64 columns (the tile of layers with <= 64 channels)
+        tile = 64 if bm in (64, 364) else 128
         if groups > 1 and grp_rows % tile:
             continue
         if bm == 364 and K < 96:
@@ -433,7 +475,7 @@ def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
         assert err <= 2e-6 * rng, (bm, err / rng)
         last = -(-valid // tile) * tile                  # rows of whole tiles past the last valid one of a group are not written
         assert torch.isnan(out[:, last:]).all()
-    for bm in (128, 364):
+    for bm in (128, 364, 264):
         if bm in outs:
             assert (outs[64][:, :valid] - outs[bm][:, :valid]).abs().max().item() <= 1e-7 * rng
     if groups == 1:
@@ -450,9 +492,11 @@ def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
                                           groups, torch.cuda.current_stream().cuda_stream), 'wg')
         f32 = f32 + shift
     e32 = (f32[:, :valid].double() - ref).abs()
-    eh = (outs[64][:, :valid].double() - ref).abs()
-    assert eh.max().item() <= 1.6 * e32.max().item() + 1e-7 * rng
-    assert eh.mean().item() <= 1.6 * e32.mean().item() + 1e-8 * rng
+    for bm in (64, 264):
+        if bm in outs:
+            eh = (outs[bm][:, :valid].double() - ref).abs()
+            assert eh.max().item() <= 1.6 * e32.max().item() + 1e-7 * rng
+            assert eh.mean().item() <= 1.6 * e32.mean().item() + 1e-8 * rng
 
 
 def test_h2_gemm_epilogue_and_dynamic_range():

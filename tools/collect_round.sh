@@ -11,10 +11,14 @@ last_json() { grep '^{' "$1" | tail -1; }
 # 1. the driver's command (CPU baseline + accuracy legs)
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_default.out" 2> "$OUT/bench_default.err"; last_json "$OUT/bench_default.out" > "$OUT/${R}_bench_line.json"
 echo "default: $(cut -c1-160 "$OUT/${R}_bench_line.json")"
-# 1a. the same command with the GEMM-shaped launches on the f32-input MFMA kernels (FGN_GEMM_MATH=f32), and both over 100 steps
+# 1a. the same command with the GEMM-shaped launches on conv_pw_x3_kernel (FGN_GEMM_MATH=x3) and on the f32-input MFMA kernels
+# (FGN_GEMM_MATH=f32), and all three over 100 steps, arms alternating
+FGN_GEMM_MATH=x3 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/b.out" 2> "$OUT/bench_x3.err"; last_json "$OUT/b.out" > "$OUT/${R}_bench_line_x3.json"
+echo "x3: $(cut -c1-160 "$OUT/${R}_bench_line_x3.json")"
 FGN_GEMM_MATH=f32 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/b.out" 2> "$OUT/bench_f32.err"; last_json "$OUT/b.out" > "$OUT/${R}_bench_line_f32_mfma.json"
 echo "f32 MFMA: $(cut -c1-160 "$OUT/${R}_bench_line_f32_mfma.json")"
-for m in x3 f32 x3 f32; do
+rm -f "$OUT/${R}_ab_gemm_math_100steps.jsonl"
+for m in h2 x3 f32 h2 x3 f32; do
   FGN_GEMM_MATH=$m python bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'gemm_math': d['gemm_math'], 'steps': d['steps'], 'img_per_s': round(d['value'],1), 'ms_per_step': round(d['ms_per_step'],3), 'kernel': d['roofline']['kernel'], 'frac': d['roofline']['frac'], 'f32_equivalent_tflops': d['roofline']['f32_equivalent_tflops']}))" | tee -a "$OUT/${R}_ab_gemm_math_100steps.jsonl"
 done
 # 1b. where in the timed window the isolated instrumented step sits: step 0 (the first work after the barrier's device
@@ -38,14 +42,12 @@ cp "$OUT"/stats_b8/*/*kernel_stats.csv "$OUT/${R}_kernel_stats_cfg4_b8.csv" 2>/d
 # 4. multi-rank rehearsal on the one GPU (gloo, 5 ranks: the box allows 6 GPU processes)
 FGN_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 5 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/r5.out" 2> "$OUT/r5.err"; last_json "$OUT/r5.out" > "$OUT/${R}_rehearsal_5rank_gloo.json"
 echo "5 ranks: $(cut -c1-160 "$OUT/${R}_rehearsal_5rank_gloo.json")"
-# 5. per-launch roofline table of one episode, in-kernel clock of the large GEMMs under sustained load
+# 5. per-launch roofline table of one episode, the three arithmetics
 timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch.csv" 7 > "$OUT/per_launch.txt" 2>&1; tail -14 "$OUT/per_launch.txt"
+FGN_GEMM_MATH=x3 timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch_x3.csv" 7 > "$OUT/per_launch_x3.txt" 2>&1; head -8 "$OUT/per_launch_x3.txt" | tail -6
 FGN_GEMM_MATH=f32 timeout -k 10 200 python tools/per_launch.py "$OUT/${R}_per_launch_f32_mfma.csv" 7 > "$OUT/per_launch_f32.txt" 2>&1; head -8 "$OUT/per_launch_f32.txt" | tail -6
-timeout -k 10 200 tools/micro/gemm_clock 2.5 0 > "$OUT/${R}_gemm_clock.jsonl" 2> "$OUT/gemm_clock.err"; cut -c1-260 "$OUT/${R}_gemm_clock.jsonl"
-# 6. conv_pw_x3_kernel beside the f32 MFMA kernels on the GEMM shapes of an episode (variants take turns), and its phase clocks
-FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_exp.so timeout -k 10 400 python tools/x3_probe.py --reps 10 > "$OUT/${R}_x3_probe.jsonl" 2> "$OUT/x3_probe.err"; echo "x3 probe rc $?"
-[ -f tools/micro/libfgn_hip_x3ph.so ] && FGN_HIP_LIB=$ROOT/tools/micro/libfgn_hip_x3ph.so timeout -k 10 300 python tools/x3_probe.py --reps 3 --phases > "$OUT/${R}_x3_phases.jsonl" 2> "$OUT/x3_phases.err"
-timeout -k 10 200 bash tools/pmc_x3.sh relq 0 "gpurun_out/collect_$R/${R}_pmc_x3_relq.json" > "$OUT/pmc_x3.log" 2>&1; echo "pmc x3 rc $?"
+# 6. conv_pw_h2_kernel / conv_pw_x3_kernel beside the f32 MFMA kernels on the GEMM shapes of an episode (variants take turns)
+timeout -k 10 500 python tools/x3_probe.py --reps 10 > "$OUT/${R}_h2_probe.jsonl" 2> "$OUT/h2_probe.err"; echo "h2 / x3 probe rc $?"
 # 7. one training step (forward_train + backward of the heads + Adagrad + re-pack; the frozen backbone on the default arithmetic)
 timeout -k 10 400 python tools/train_bench.py --steps 10 --out "$OUT/${R}_train_step.json" > "$OUT/train_bench.log" 2>&1; tail -2 "$OUT/train_bench.log" | cut -c1-300
 ls "$OUT"

@@ -10,7 +10,7 @@ import re
 import sys
 
 # every kernel inside bench.py's HIP-event brackets
-CONV_FAMILY = ('conv_igemm', 'conv_pw_persist', 'conv_pw_x3', 'splitk_epilogue', 'wg_input', 'wg_output', 'wg4_input', 'wg4_output')
+CONV_FAMILY = ('conv_igemm', 'conv_pw_persist', 'conv_pw_x3', 'conv_pw_h2', 'splitk_epilogue', 'wg_input', 'wg_output', 'wg4_input', 'wg4_output')
 
 
 def short(name):
