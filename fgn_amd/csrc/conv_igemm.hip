@@ -1689,7 +1689,12 @@ static int h2_pick(long long M, int Cout, int K, int grp_rows, int grp_valid, in
         if (Cout < 48 || (M + 127) / 128 < 256) return 0;       // mostly padding / too few tiles for a persistent grid
         return 264;
     }
-    return x3_pick_bm(M, Cout, K, grp_rows, grp_valid, 0);
+    // 128 rows: x3_pick_bm's conditions, for the grouped (Winograd) launches only - measured with this kernel
+    // (profiles/r05_h2_probe_record_vs_own_scale.jsonl, own scale): the 300-RoI / AG-RPN Winograd GEMMs 99.1 -> 94.2 / 246.6 ->
+    // 239.6 us on 128 rows, the plain 1x1 launches equal or slower (shared-head conv3 62.5 -> 66.5, conv1 62.4 -> 70.6, relation Q
+    // 109.1 -> 109.0): three 64-row workgroups per CU hide more of each other's phases than two 128-row ones
+    const int bm_x3 = x3_pick_bm(M, Cout, K, grp_rows, grp_valid, 0);
+    return (bm_x3 == 128 && !grp_rows) ? 64 : bm_x3;
 }
 
 template <int WMW, int WNW, int RB, int NST, bool IM2COL>

@@ -461,7 +461,7 @@ def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     img = ops.pack_h2(w)
     outs = {}
     assert lib.load().fgn_h2_row_tile(groups * grp_rows, N, K, grp_rows if groups > 1 else 0, valid if groups > 1 else 0) == \
-        {1024: 128, 76: 0, 260: 0, 132: 0, 128: 0, 512: 0, 256: 64, 64: 264, 52: 264}[N]
+        {1024: 64, 76: 0, 260: 0, 132: 0, 128: 0, 512: 0, 256: 64, 64: 264, 52: 264}[N]
     for bm in (64, 128, 364, 264):                     # 264: 128 rows x 64 columns (the tile of layers with <= 64 channels)
         tile = 64 if bm in (64, 364) else 128
         if groups > 1 and grp_rows % tile:
