@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_pw_h2_kernel(const Con
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         bool have_s = false;                        // no scale chosen yet for this output tile
-        float a_lim = -1.f;                         // |x| above this leaves the f16 range under the current scale
+        float a_lim = 0.f;                          // |x| above this leaves the f16 range under the current scale (no scale yet:
+                                                    // any non-zero element; an all-zero fragment - padded rows - passes as it is)
         a_s = 1.f; a_inv = 1.f;
         for (int kt = 0; kt < KT; ++kt) {
             // K-tile `kt` has landed: everything (first K-tile of an output tile: the previous epilogue's stores share
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_pw_h2_kernel(const Con
                     big = fmaxf(big, fmaxf(fabsf(ahi[i].x), fabsf(ahi[i].y)));
                     big = fmaxf(big, fmaxf(fabsf(ahi[i].z), fabsf(ahi[i].w)));
                 }
-                // (a_lim < 0 until a scale is chosen: the first K-tile with a non-zero element chooses it)
+                // (a_lim = 0 until a scale is chosen: the first K-tile with a non-zero element chooses it)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(big <= a_lim)) != 0ull, 0)) adapt();
             }
 #pragma unroll
