@@ -1732,7 +1732,7 @@ extern "C" int fgn_h2_row_tile(long long M, int Cout, int K, int grp_rows, int g
     return h2_pick(M, Cout, K, grp_rows, grp_valid, 0);
 }
 
-// bm: 0 = choose (h2_pick), 64 / 128 / 264 = force the tile, 364 = 64 rows with three stages (measured, not chosen)
+// bm: 0 = choose (h2_pick), 64 / 128 / 264 = force the tile
 static int launch_h2(const ConvParams& p0, int M_max, int n_groups, int bm, hipStream_t stream, const H2Im2col* im = nullptr) {
     ConvParams p = p0;
     if (!p.w3 || p.npad3 % H2_BN || p.npad3 < p.Cout || (p.Cout & 3) || p.K % BK || p.K < 2 * BK || p.splits != 1) return FGN_ERR_SHAPE;
@@ -1741,10 +1741,6 @@ static int launch_h2(const ConvParams& p0, int M_max, int n_groups, int bm, hipS
     p.w_inv = reinterpret_cast<const float*>(static_cast<const char*>(p.w3) + img);
     H2Im2col none;
     none.y1 = nullptr; none.x_off0 = none.x_off1 = 0u; none.M0 = none.M1 = 0; none.H1 = none.W1 = none.Ho1 = none.Wo1 = 1; none.cin_shift = 0;
-    if (bm == 364) {
-        if (im || p.K < 3 * BK || (p.grp_rows && p.grp_rows % 64)) return FGN_ERR_SHAPE;
-        return launch_h2_cfg<2, 2, 1, 3, false>(p, none, M_max, stream);
-    }
     if (bm != 0 && bm != 64 && bm != 128 && bm != 264) return FGN_ERR_SHAPE;
     const int cfg = h2_pick(M_max, p.Cout, p.K, p.grp_rows, p.grp_valid, bm);
     if (cfg == 0) return FGN_ERR_SHAPE;

@@ -3,9 +3,11 @@
 //
 // Why.  conv_pw_x3_kernel is power-bound: what it costs is the number of MFMA products per f32 product.  An f32 value
 // scaled by a power of two into the f16 range is h + l + e with h = f16(x), l = f16(x - h) (both round-to-nearest, the
-// subtraction exact) and |e| <= 2^-24 |x| - half an ulp of the f32 value itself, i.e. the two planes hold x as well as f32
-// does.  Products of two f16 values are exact in f32 (22 significant bits), so a * b = ha hb + ha lb + la hb + (la lb,
-// <= 2^-24 |a b|, left out - below the rounding of one f32 FMA): three v_mfma_f32_16x16x32_f16 per f32 MFMA's worth of K,
+// subtraction exact) and |e| <= 2^-23 |x|: l keeps 11 of the at most 13 bits h leaves, so the two planes hold x to one ulp
+// of the f32 value at worst, a quarter of it on average.  Products of two f16 values are exact in f32 (22 significant
+// bits), so a * b = ha hb + ha lb + la hb + (la lb <= 2^-22 |a b|, left out): each product within 2^-21 |a b| at worst and
+// ~2^-24 |a b| rms - the order of the rounding an f32 FMA chain makes at every step: three v_mfma_f32_16x16x32_f16 per f32
+// MFMA's worth of K,
 // accumulated in f32 by the matrix pipe.  Against fp64 the result is as close as the f32 kernels' (the accumulation's own
 // rounding dominates all three arithmetics: tests/test_hip_conv.py::test_h2_*, tools/x3_probe.py).
 //
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_pw_h2_kernel(const Con
     constexpr int PER = A_LD + B_LD;                        // LDS-DMA wave-instructions per wave per K-tile
     constexpr int D = NST - 1;                              // K-tiles in flight ahead of the one being multiplied
     constexpr int ROWS_PER_PASS = NTHR / 8;                 // A rows one pass of the workgroup's DMAs covers
-    static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");
+    static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");      // (three: measured 5-12 % slower, DESIGN appendix A row 53)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;

@@ -482,7 +482,7 @@ def gemm_x3(x: torch.Tensor, image: torch.Tensor, cout: int, shift: Optional[tor
 def pack_h2(w: torch.Tensor) -> torch.Tensor:
     """w [G, N, K] (or [N, K]) f32 -> the weight image of ``conv_pw_h2_kernel`` (csrc/conv_pw_h2.h): every output column n of
     a group scaled by the power of two that puts its largest |w| into [2^14, 2^15) (an all-zero column: 1), then every value
-    as two f16 planes, hi = f16(w s) and lo = f16(w s - hi) (round to nearest; hi + lo = w s to within 2^-24 |w s|), laid
+    as two f16 planes, hi = f16(w s) and lo = f16(w s - hi) (round to nearest; hi + lo = w s to within 2^-23 |w s|: one f32 ulp at worst), laid
     out [G][K / 32][plane][Npad][32] f16 with ``pack_x3``'s k order and chunk swizzle, followed by the inverse scales
     [G][Npad] f32.  uint8 tensor on w's device."""
     w = w.detach().float()

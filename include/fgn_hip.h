@@ -123,9 +123,9 @@ int fgn_conv1x1_dual_x3_nhwc_f32(const float* x, const float* x2, const int32_t*
 int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const int32_t* n_img_dev, int n_img,
                              int tiles_per_img, int t_pad, int Cin, int Cout, int cout_pad, int n_groups, void* stream);
 /* The same GEMMs with THREE f16 MFMA products per f32 product (conv_pw_h2_kernel, csrc/conv_pw_h2.h; the default of the
- * host wrappers): an f32 value scaled by a power of two into the f16 range is h + l to within 2^-24 of itself (h = f16(x),
+ * host wrappers): an f32 value scaled by a power of two into the f16 range is h + l to within 2^-23 of itself (h = f16(x),
  * l = f16(x - h), round to nearest), products of f16 values are exact in f32, and h_a h_b + h_a l_b + l_a h_b leaves out
- * only l_a l_b <= 2^-24 |a b|; f32 accumulation, f32 in / out, the f32 kernels' error against fp64
+ * only l_a l_b <= 2^-22 |a b| (per product ~2^-24 |a b| rms: the order of an f32 FMA chain's own rounding); f32 accumulation, f32 in / out, the f32 kernels' error against fp64
  * (tests/test_hip_conv.py::test_h2_*).  The scales are powers of two (exact) and taken out again inside the kernel: the
  * weights' per output column at pack time (fgn_amd/ops.py::pack_h2), the activations' found by the kernel itself per wave
  * and output tile (the first non-zero K-tile of a tile sets it; a later K-tile that would leave the f16 range picks a
@@ -133,7 +133,7 @@ int fgn_winograd_gemm_x3_f32(const float* V, const void* U_x3, float* Mo, const 
  *   w_h2: [groups][K / 32][2 planes][cout_pad][32] f16 of the column-scaled weights (k order and chunk swizzle of w_x3),
  *         then [groups][cout_pad] f32 inverse column scales.  fgn_h2_image_bytes = the size of both.
  * Shapes: as the x3 entry points, and Cout 48..64 on a 64-column tile (fgn_h2_row_tile decides).  fgn_gemm_h2_f32: the direct entry (tests, tools);
- * bm 0 (= fgn_h2_row_tile) / 64 / 128 / 264, 364 = 64 rows with three LDS stages (measured, not chosen). */
+ * bm 0 (= fgn_h2_row_tile) / 64 / 128 / 264 force the tile. */
 size_t fgn_h2_image_bytes(int K, int npad, int n_groups);
 int fgn_h2_row_tile(long long M, int Cout, int K, int grp_rows, int grp_valid);   /* 64 / 128: rows of a 128-column tile; 264: 128 rows x 64 columns (Cout 48..64); 0: use the f32 entry point */
 /* A 3x3 or 1x1 convolution of any stride / padding with folded scale / shift / ReLU on ONE or TWO NHWC tensors that share

@@ -925,3 +925,79 @@ def test_x3_routing_rule_is_host_logic():
     assert L.fgn_x3_row_tile(36 * 100, 512, 512, 100, 100) == 0          # a group that is not a whole number of 64-row tiles
     assert L.fgn_x3_image_bytes(1024, 1024, 36) == 36 * 1024 * 1024 * 6
     assert L.fgn_winograd_t_pad(819) == 896 and L.fgn_winograd_t_pad(1280) == 1280
+
+
+def test_h2_weight_image_holds_the_scaled_weights_to_half_an_f32_ulp_and_the_gemm_it_defines_is_f32_accurate():
+    """``ops.pack_h2`` (host logic, no GPU): every output column scaled by a power of two that puts its largest |w| into
+    [2^14, 2^15), two f16 planes hi = f16(w s), lo = f16(w s - hi), the k order / chunk swizzle of the kernel's MFMA operand,
+    the inverse scales behind the image.  Un-permuted: hi + lo reproduces w s to within 2^-23 |w s| (one f32 ulp) wherever
+    lo is a normal f16, the scales are exact powers of two, padded columns are zero with scale 1.  And the arithmetic the
+    image defines - h_a h_b + h_a l_b + l_a h_b with the activations split the same way under one power-of-two scale - is as
+    close to fp64 as an f32 GEMM (numpy emulation of conv_pw_h2_kernel's products, csrc/conv_pw_h2.h)."""
+    import numpy as np
+    from fgn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(2, 200, 96, generator=g) * torch.logspace(-3, 2, 200)[None, :, None]     # columns five orders apart
+    w[0, 5, :] = 0.0
+    w[1, 7, 3] = 0.0
+    G, N, K = w.shape
+    npad = 256
+    img = ops.pack_h2(w)
+    assert img.dtype == torch.uint8 and img.numel() == G * npad * (K * 4 + 4)
+    inv = img[G * K * npad * 4:].view(torch.float32).view(G, npad)
+    pl = img[:G * K * npad * 4].view(torch.int16).view(G, K // 32, 2, npad, 4, 8).permute(0, 2, 3, 1, 4, 5)   # G, plane, n, kt, chunk, 8
+    n = torch.arange(npad)
+    swz = torch.tensor([0, 3, 2, 1])[(n >> 2) & 3]
+    idx = torch.arange(4)[None, :] ^ swz[:, None]                                                # logical chunk -> physical
+    pl = torch.gather(pl, 4, idx[None, None, :, None, :, None].expand(G, 2, npad, K // 32, 4, 8)).reshape(G, 2, npad, K // 32, 32)
+    korder = torch.tensor([4 * q + j if j < 4 else 16 + 4 * q + j - 4 for q in range(4) for j in range(8)])
+    back = torch.empty(32, dtype=torch.long)
+    back[korder] = torch.arange(32)
+    planes = pl[..., back].reshape(G, 2, npad, K).contiguous().view(torch.float16).double()
+    hi, lo = planes[:, 0], planes[:, 1]
+    # scales: exact powers of two, column maximum into [2^14, 2^15); zero / padded columns: 1
+    m, e = np.frexp(inv.numpy().astype(np.float64))
+    assert (m == 0.5).all()
+    colmax = w.abs().amax(2)
+    scaled_max = (colmax.double() / inv[:, :N].double())
+    assert ((scaled_max >= 2.0 ** 14) & (scaled_max < 2.0 ** 15) | (colmax == 0)).all()
+    assert (inv[:, N:] == 1).all() and (inv[0, 5] == 1) and (hi[:, N:] == 0).all() and (lo[:, N:] == 0).all()
+    ws = w.double() / inv[:, :N, None].double()
+    err = (hi[:, :N] + lo[:, :N] - ws).abs()
+    normal = lo[:, :N].abs() >= 2.0 ** -14                       # below: f16 subnormals, absolute error <= 2^-25
+    assert (err[normal] <= ws.abs()[normal] * 2.0 ** -23).all() and (err[~normal] <= 2.0 ** -25).all()
+    assert err[normal].mean() <= (ws.abs()[normal] * 2.0 ** -25).mean()                # a quarter of an ulp on average
+    assert (lo[:, :N].abs() <= hi[:, :N].abs() * 2.0 ** -10 + 2.0 ** -24).all()
+    # the GEMM the image defines, emulated: activations split the same way under one scale, three products, against fp64 / f32
+    x = torch.randn(300, K, generator=g).relu_() * 0.37
+    e_x = int(np.floor(np.log2(float(x.abs().max()))))
+    s = 2.0 ** (13 - e_x)
+    xs = (x.double() * s)
+    xh = xs.to(torch.float16).double()
+    xl = (xs - xh).to(torch.float16).double()
+    for gi in range(G):
+        got = (xl @ hi[gi, :N].T + xh @ lo[gi, :N].T + xh @ hi[gi, :N].T) / s * inv[gi, :N].double()[None, :]
+        ref = x.double() @ w[gi].double().T
+        f32 = (x @ w[gi].T).double()
+        scale = ref.abs().max(0, keepdim=True).values.clamp_min(1e-30)       # per column: the columns are orders apart
+        assert ((got - ref).abs() / scale).max().item() <= 3e-7
+        assert ((got - ref).abs() / scale).max().item() <= ((f32 - ref).abs() / scale).max().item() + 1e-7
+
+
+def test_h2_routing_rule_is_host_logic():
+    """``fgn_h2_row_tile`` (no GPU involved): the tile conv_pw_h2_kernel runs a launch on - conv_pw_x3_kernel's rule for the
+    128-column tiles with the 128-row tile kept for the grouped (Winograd) launches, and 128 rows x 64 columns (264) for
+    layers of 48..64 output channels with at least 256 such tiles."""
+    from fgn_amd import lib
+    L = lib.load()
+    assert L.fgn_h2_row_tile(14700, 1024, 1024, 0, 0) == 64              # relation Q: plain 1x1 launches stay on 64 rows
+    assert L.fgn_h2_row_tile(36 * 1280, 512, 512, 1280, 1236) == 128     # Winograd GEMM of 300 + 9 RoIs
+    assert L.fgn_h2_row_tile(36 * 896, 1024, 1024, 896, 819) == 128      # AG-RPN
+    assert L.fgn_h2_row_tile(36 * 512, 512, 512, 512, 400) == 64         # mask head
+    assert L.fgn_h2_row_tile(103664, 64, 256, 0, 0) == 264               # layer1 conv1: the 64-column tile
+    assert L.fgn_h2_row_tile(103664, 64, 576, 0, 0) == 264               # layer1's 3x3 as an implicit GEMM
+    assert L.fgn_h2_row_tile(25916, 128, 1152, 0, 0) == 64               # layer2.0's strided 3x3
+    assert L.fgn_h2_row_tile(12600, 76, 1024, 0, 0) == 0                 # RPN head: 76 of 128 columns (measured: no gain)
+    assert L.fgn_h2_row_tile(3000, 64, 256, 0, 0) == 0                   # 24 tiles of 128 x 64
+    assert L.fgn_h2_row_tile(103664, 40, 256, 0, 0) == 0                 # mostly padding
+    assert L.fgn_h2_row_tile(441, 512, 1024, 0, 0) == 0                  # 9 support RoIs

@@ -73,17 +73,14 @@ def main():
         img32 = ops.pack_x3(w, mfma32=True)
         rec = dict(shape=name, gflop=2.0 * G * valid * K * N / 1e9)
         fns, outs = {}, {}
-        # conv_pw_h2_kernel (three f16 products of scaled two-way splits): 64 / 128 rows, 64 rows x 3 stages
+        # conv_pw_h2_kernel (three f16 products of scaled two-way splits): 64 / 128 rows
         imgh = ops.pack_h2(w)
-        for tag, bm in (('h2_bm64', 64), ('h2_bm128', 128), ('h2_bm64_st3', 364)):
+        for tag, bm in (('h2_bm64', 64), ('h2_bm128', 128)):
             if G > 1 and gr % (128 if bm == 128 else 64):
                 continue
             out = torch.zeros(G, gr, N, device=dev)
             fn = (lambda bm=bm, out=out: ops.gemm_h2(x, imgh, N, shift=shift, groups=G, grp_valid=valid, bm=bm, out=out))
-            try:
-                fn()
-            except ops._lib.FgnHipError:        # three stages need three K-tiles
-                continue
+            fn()
             torch.cuda.synchronize()
             d = (out[:, :valid].double() - ref).abs()
             outs[tag], fns[tag] = out, fn
