@@ -16,7 +16,7 @@
 //    [npad] floats, lie behind the image and multiply the C tile in the epilogue);
 //  * the activations by a scale the kernel finds itself, per WAVE and OUTPUT TILE: the first K-tile of the tile whose
 //    32 RB x 32 fragment holds a non-zero element sets S so that the fragment's largest |x| lands in [2^13, 2^14); every
-//    later K-tile is looked at once (max |x| of the raw fragment against 65504 / S, ~0.5 vector instruction per element),
+//    later K-tile is looked at once (max |x| of the raw fragment against 65504 / S: `v_max3_f32` with |.| modifiers, 0.25 vector instruction per element),
 //    and one that would leave the f16 range - an element 4x .. 8x above what S was chosen for - picks a new S from its
 //    own maximum and multiplies the accumulators by the ratio (a power of two: exact).  S comes out of the accumulators
 //    when they go to the C tile.  An element within 2^15 of the maximum S was chosen for keeps both planes at full
@@ -67,6 +67,24 @@ __device__ __forceinline__ H2Frag h2_split(const float4& a, const float4& b, con
     f.hi = __builtin_bit_cast(f16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
     f.lo = __builtin_bit_cast(f16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
     return f;
+}
+
+// max |x| over sixteen f32 values: eight v_max3_f32 with |.| source modifiers (the compiler's own sequence for the same
+// fmaxf / fabsf tree is three times as long: it does not fold the inner maximum)
+__device__ __forceinline__ float h2_absmax16(const float4& a, const float4& b, const float4& c, const float4& d) {
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, 0\n\t"
+        "v_max3_f32 %0, |%3|, |%4|, %0\n\t"
+        "v_max3_f32 %0, |%5|, |%6|, %0\n\t"
+        "v_max3_f32 %0, |%7|, |%8|, %0\n\t"
+        "v_max3_f32 %0, |%9|, |%10|, %0\n\t"
+        "v_max3_f32 %0, |%11|, |%12|, %0\n\t"
+        "v_max3_f32 %0, |%13|, |%14|, %0\n\t"
+        "v_max3_f32 %0, |%15|, |%16|, %0"
+        : "=&v"(m)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w),
+          "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+    return m;
 }
 
 constexpr int H2_BN = 128;                       // columns the weight image is padded to
@@ -351,14 +369,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_pw_h2_kernel(const Con
                 have_s = true;
             };
             {                                        // one look at the raw fragment per K-tile, then straight-line code
-                float big = 0.f;
-#pragma unroll
-                for (int i = 0; i < 2 * RB; ++i) {
-                    big = fmaxf(big, fmaxf(fabsf(alo[i].x), fabsf(alo[i].y)));
-                    big = fmaxf(big, fmaxf(fabsf(alo[i].z), fabsf(alo[i].w)));
-                    big = fmaxf(big, fmaxf(fabsf(ahi[i].x), fabsf(ahi[i].y)));
-                    big = fmaxf(big, fmaxf(fabsf(ahi[i].z), fabsf(ahi[i].w)));
-                }
+                float big = h2_absmax16(alo[0], ahi[0], alo[1], ahi[1]);
+                if constexpr (RB == 2) big = fmaxf(big, h2_absmax16(alo[2], ahi[2], alo[3], ahi[3]));
                 // (a_lim = 0 until a scale is chosen: the first K-tile with a non-zero element chooses it)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(big <= a_lim)) != 0ull, 0)) adapt();
             }

@@ -436,10 +436,15 @@ def test_x3_gemm_epilogue_and_special_values():
     assert ((got - ref).abs() / scale).max().item() <= 2e-6
 
 
-@pytest.mark.parametrize('groups,grp_rows,valid,K,N', [(1, 14700, 14700, 1024, 1024), (1, 3001, 3001, 64, 76), (1, 130, 130, 96, 260),
-                                                       (36, 256, 201, 128, 132), (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256),
-                                                       (1, 40000, 40000, 256, 64), (1, 33000, 33000, 576, 52)])
-@pytest.mark.parametrize('mag', [1.0, 3e-5, 2e7])
+_H2_SHAPES = [(1, 14700, 14700, 1024, 1024), (1, 3001, 3001, 64, 76), (1, 130, 130, 96, 260), (36, 256, 201, 128, 132),
+              (36, 256, 100, 64, 128), (16, 128, 128, 256, 512), (1, 70000, 70000, 64, 256), (1, 40000, 40000, 256, 64),
+              (1, 33000, 33000, 576, 52)]
+# every shape at magnitude 1; magnitudes below / above the f16 range on four of them
+_H2_CASES = [sh + (1.0,) for sh in _H2_SHAPES] + \
+    [sh + (mag,) for sh in _H2_SHAPES if (sh[0], sh[3], sh[4]) in ((1, 1024, 1024), (36, 128, 132), (1, 256, 64), (1, 96, 260)) for mag in (3e-5, 2e7)]
+
+
+@pytest.mark.parametrize('groups,grp_rows,valid,K,N,mag', _H2_CASES)
 def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, valid, K, N, mag):
     """conv_pw_h2_kernel through its direct entry (fgn_gemm_h2_f32): f32 operands, every product as three f16 MFMA products of
     two-way splits of the power-of-two scaled operands (weights per output column at pack time, activations by the scale
@@ -450,8 +455,6 @@ def test_h2_gemm_is_as_close_to_fp64_as_the_f32_mfma_kernel(groups, grp_rows, va
     2 and 3 K-tiles.  The scales differ per wave and tile, so the tiles may differ where an element's l plane
     reaches the f16 subnormals: within 1e-7 of the range of each other."""
     from fgn_amd import lib, ops
-    if mag != 1.0 and (groups, K, N) not in ((1, 1024, 1024), (36, 128, 132), (1, 256, 64), (1, 96, 260)):
-        pytest.skip('the magnitudes outside the f16 range on four of the shapes')
     g = torch.Generator().manual_seed(groups * 1000 + K + N)
     x = (torch.randn(groups, grp_rows, K, generator=g).relu_() * mag).cuda()
     x[:, valid:] = 3e38                                  # what lies behind a group's valid rows must not reach a wave's scale
