@@ -774,8 +774,8 @@ extern "C" int fgn_rpn_proposals_f32(const float* scores, const float* deltas, c
     if (attr != hipSuccess) return (int)attr;
     p.pre_sorted = nullptr; p.pre_info = nullptr;
     p.pre_boxes = nullptr; p.pre_valid = nullptr; p.pre_mt = nullptr;
-    static const int use_matrix = getenv("FGN_RPN_MATRIX") ? atoi(getenv("FGN_RPN_MATRIX")) : 1;   // 0: IoU tests inside the proposal kernel
-    static const int multi = getenv("FGN_RPN_MULTI") ? atoi(getenv("FGN_RPN_MULTI")) : 1;   // 0: single-workgroup path only
+    constexpr int use_matrix = 1;    // (0: IoU tests inside the proposal kernel - round 3's A/B)
+    constexpr int multi = 1;         // (0: single-workgroup path only)
     if (multi && pre_zeroed && n_sel > RPN_FAST_SEL && p.n_total > RPN_FAST_CAP) {
         unsigned char* z = reinterpret_cast<unsigned char*>(pre_zeroed);
         uint32_t* hist1 = reinterpret_cast<uint32_t*>(z);

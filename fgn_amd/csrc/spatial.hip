@@ -316,8 +316,7 @@ extern "C" int fgn_roi_align2_nhwc_f32(const float* fmap, const float* fmap2, co
     // threads per bin, measured on the 300 proposals of a cfg3 episode (1024 + 512 channels = 384 quads; us per call):
     // 64: 92, 128: 61, 192: 52, 256: 55, 384: 67 - two whole items per thread on three waves
     const int quads = (C + C2) / 4;
-    static const int forced = getenv("FGN_ROI_THREADS") ? atoi(getenv("FGN_ROI_THREADS")) : 0;
-    const int threads = forced ? forced : (quads % 192 == 0 ? 192 : (quads >= 256 ? 256 : (quads >= 128 ? 128 : 64)));
+    const int threads = quads % 192 == 0 ? 192 : (quads >= 256 ? 256 : (quads >= 128 ? 128 : 64));
     hipLaunchKernelGGL(roi_align_kernel, dim3(n_rois * out_size * out_size), dim3(threads), 0, stream, fmap,
                        rois, out, n_rois_dev, n_rois, H, W, C, out_size, spatial_scale, sampling_ratio,
                        aligned, (const float*)nullptr, 0, fmap2, out2, C2, post_shift2, relu2);

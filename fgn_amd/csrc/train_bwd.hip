@@ -621,8 +621,6 @@ __global__ void gemm_tn_reduce_kernel(const float4* __restrict__ part, float4* _
 // few output tiles -> row slabs
 #include <cstdlib>
 static inline bool tn_big(int R, int M, int N) {
-    static const int force = getenv("FGN_TN_BIG") ? atoi(getenv("FGN_TN_BIG")) : -1;       // tools/gemm_tn_bench.py
-    if (force >= 0) return force != 0 && M >= 128 && N >= 128;
     return M >= 1024 && N >= 1024 && R >= 1024;      // measured: 96 vs 87 TFLOP/s at 1024 x 1024 x 6272 rows, a loss below
 }
 

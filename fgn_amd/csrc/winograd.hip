@@ -383,16 +383,10 @@ __global__ __launch_bounds__(256) void wg4_output_kernel(const float* __restrict
 // the column-by-column form is a chain of six dependent memory round trips); with it, 8-byte vectors are best or within
 // 1.5 us of the best at every layer of an episode (34.0 / 21.7 / 16.5 / 13.7 us on the four large ones, 6-7 us - the
 // floor of a launch whose every thread does one load and one store round trip - on the rest); 16-byte vectors are kept
-// for launches with several million elements (batched AG-RPN maps).  FGN_WG4_VEC / FGN_WG4_EAGER force a choice (tuning).
-static int wg4_vec(long long elems) {
-    static const int forced = getenv("FGN_WG4_VEC") ? atoi(getenv("FGN_WG4_VEC")) : 0;
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return elems >= (4ll << 20) ? 4 : 2;
-}
-static bool wg4_eager(long long threads) {
-    static const long long eager_thr = getenv("FGN_WG4_EAGER") ? atoll(getenv("FGN_WG4_EAGER")) : (1ll << 40);
-    return threads < eager_thr;
-}
+// for launches with several million elements (batched AG-RPN maps).  (The A/B was driven by environment variables, removed
+// since: the library reads none.)
+static int wg4_vec(long long elems) { return elems >= (4ll << 20) ? 4 : 2; }
+static bool wg4_eager(long long) { return true; }
 // vec * 10 + eager of the input transform / vec * 10 of the output transform for a layer (lets a profiler name the
 // kernel instance a launch uses)
 extern "C" int fgn_winograd4_variant(int tiles_total, int C, int is_output) {

@@ -12,7 +12,7 @@ def t(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-print('FGN_WG4_EAGER', os.environ.get('FGN_WG4_EAGER'))
+print('(the library no longer reads FGN_WG4_VEC / FGN_WG4_EAGER: this times the default form)')
 for name, n, H, W, cin, cout, div in (('agrpn', 1, 50, 84, 1024, 1024, 3), ('sh300', 300, 7, 7, 512, 512, 1), ('sh100', 100, 7, 7, 512, 512, 1),
                                       ('mask0', 100, 7, 7, 1024, 256, 1), ('mask1', 100, 7, 7, 256, 256, 1), ('l3', 1, 50, 84, 256, 256, 1),
                                       ('l2', 1, 100, 167, 128, 128, 1), ('l1', 1, 200, 334, 64, 64, 1), ('spp_l3', 9, 16, 16, 256, 256, 1), ('spp_l2', 9, 32, 32, 128, 128, 1)):
