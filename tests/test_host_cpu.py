@@ -1001,3 +1001,52 @@ def test_h2_routing_rule_is_host_logic():
     assert L.fgn_h2_row_tile(3000, 64, 256, 0, 0) == 0                   # 24 tiles of 128 x 64
     assert L.fgn_h2_row_tile(103664, 40, 256, 0, 0) == 0                 # mostly padding
     assert L.fgn_h2_row_tile(441, 512, 1024, 0, 0) == 0                  # 9 support RoIs
+
+
+def test_h2_per_wave_scale_search_is_exact_in_the_scales():
+    """The activation side of conv_pw_h2_kernel restated in numpy (csrc/conv_pw_h2.h: per wave and output tile the first
+    K-tile with a non-zero element sets S so that its largest |x| lands in [2^13, 2^14); a later K-tile with an element
+    above 65504 / S picks a new S from its own maximum and the accumulator is multiplied by the power-of-two ratio; all-zero
+    K-tiles pass as they are; S comes out at the end).  On fragments whose K-tiles differ by orders of magnitude in both
+    directions the result stays within f32 accuracy of fp64, no plane ever leaves the f16 range, and the number of scale
+    changes is what the rule predicts."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+
+    def run(x, w):                                   # x [rows, K] f32 (one wave's rows), w [K, n] f16-exact weights (scaled)
+        acc = np.zeros((x.shape[0], w.shape[1]), np.float32)
+        s, inv, lim, have, changes = np.float32(1), np.float32(1), np.float32(0), False, 0
+        wh = w.astype(np.float16).astype(np.float32)
+        wl = (w - wh).astype(np.float16).astype(np.float32)
+        for k0 in range(0, x.shape[1], 32):
+            f = x[:, k0:k0 + 32]
+            big = np.abs(f).max()
+            if not (big <= lim):
+                e = int(np.floor(np.log2(big)))
+                ns = np.float32(2.0 ** (13 - e))
+                if have:
+                    acc *= ns * inv                  # a power of two: exact
+                    changes += 1
+                s, inv, lim, have = ns, np.float32(2.0 ** (e - 13)), np.float32(65504.0 * 2.0 ** (e - 13)), True
+            fs = f * s
+            h = fs.astype(np.float16)
+            assert np.isfinite(h).all()              # never leaves the f16 range
+            hf = h.astype(np.float32)
+            lo = (fs - hf).astype(np.float16).astype(np.float32)
+            kw_h, kw_l = wh[k0:k0 + 32], wl[k0:k0 + 32]
+            acc = (acc + lo @ kw_h + hf @ kw_l + hf @ kw_h).astype(np.float32)
+        return acc * inv, changes
+
+    K, n = 256, 24
+    w = (rng.standard_normal((K, n)) * 2.0 ** 10).astype(np.float32)
+    for mags, expect in (([1.0] * 8, 0), ([1e-3, 1.0, 1.0, 1e3, 1e3, 1e-6, 1.0, 1e5], 3), ([0.0, 0.0, 1.0, 1.0, 0.0, 1e4, 1.0, 0.0], 1),
+                         ([1e6, 1.0, 1e-4, 1.0, 1.0, 1.0, 1.0, 1.0], 0)):
+        x = np.maximum(rng.standard_normal((32, K)), 0).astype(np.float32)
+        for t, m in enumerate(mags):
+            x[:, 32 * t:32 * t + 32] *= np.float32(m)
+        got, changes = run(x, w)
+        ref = x.astype(np.float64) @ w.astype(np.float64)
+        f32 = (x @ w).astype(np.float64)
+        scale = np.abs(ref).max()
+        assert changes == expect, (mags, changes)
+        assert np.abs(got - ref).max() <= max(3e-7 * scale, 2.0 * np.abs(f32 - ref).max()), mags
